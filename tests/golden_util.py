@@ -1,0 +1,34 @@
+"""Helpers to read tests/golden/*.npz (written by tests/golden/gen_golden.py from the reference)."""
+import glob
+import json
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SAMPLE_TARGET = 2048
+
+SIDE = ["utt_t_orig", "utt_v_orig", "utt_a_orig", "utt_private_t", "utt_private_v", "utt_private_a",
+        "utt_shared_t", "utt_shared_v", "utt_shared_a", "utt_t_recon", "utt_v_recon", "utt_a_recon"]
+
+
+def case_names():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def sample_idx(n):
+    stride = max(1, n // SAMPLE_TARGET)
+    return np.arange(0, n, stride)
+
+
+def load_case(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+    meta = json.loads(bytes(z["meta"]).decode())
+    cfg = SimpleNamespace(**meta["cfg"])
+    return z, meta, cfg
+
+
+def batch_of(z):
+    return {k: torch.from_numpy(z["in::" + k]) for k in ("t", "v", "a", "l", "emo")}
