@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Throughput of the MISA training hot path on MI355X:  python bench.py --gpus N --steps K --warmup W
+
+One "step" = one full reference loop iteration (solver.py:139-186: zero_grad, forward, six losses, backward,
+clip_grad_value_, Adam; dropout ON) on one synthetic MOSEI-shaped batch per GPU that is already resident in HBM.
+N=1 workload = BASELINE.json configs[1]: B=32, T=50, (d_t,d_v,d_a)=(300,35,74), hidden 128, V=20000, bf16 MFMA operands
+with fp32 accumulate.  N>1: one process per GPU (torchrun), the same per-GPU batch on every rank (weak scaling), one RCCL
+all-reduce of the flat gradient bucket per step.  Rank 0 prints ONE JSON line.
+
+Extra legs on the same line (rank 0, N=1 only for cpu_baseline):
+  roofline     - the dominant kernel (the biLSTM recurrence), timed with HIP events on its own stream inside the timed region
+  cpu_baseline - the oracle's stock-PyTorch CPU training loop on the same shapes, bounded sample
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[1]: 32; configs[2]: 256)")
+    ap.add_argument("--seq-len", type=int, default=50)
+    ap.add_argument("--vocab", type=int, default=20000)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--ragged", type=int, default=0)
+    ap.add_argument("--confidnet", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=0, help="0 = pick a count that takes ~10-30 s")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mmda_amd import make_config
+    from mmda_amd.solver import Solver
+    from mmda_amd.data import synth_batch
+    from mmda_amd import _lib
+
+    torch.manual_seed(0)
+    cfg = make_config(vocab_size=args.vocab, precision=args.precision, device=str(dev), batch_size=args.batch,
+                      seq_len=args.seq_len, use_confidNet=bool(args.confidnet), pretrained_emb=torch.randn(args.vocab, 300))
+    solver = Solver(cfg, cfg, cfg, None, None, None, is_train=True).build()
+    model = solver.model
+    model.train()
+    t, v, a, y, emo, lengths, *_ = synth_batch(cfg, args.batch, args.seq_len, seed=rank, ragged=bool(args.ragged), device=dev)
+    sync = solver.dp.sync if solver.dp is not None else None
+
+    def step():
+        model.train_step(t, v, a, lengths, emo, lr=cfg.learning_rate, clip=cfg.clip, grad_sync=sync)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    lib = model._lib
+    if rank == 0:
+        _lib.check(lib.mmda_misa_timing_begin(model._h, args.steps), "timing_begin")
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    losses = model.read_losses()
+    if not all(x == x for x in losses.values()):
+        raise SystemExit(f"non-finite losses: {losses}")
+
+    if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel (biLSTM recurrence; 4 launches per step with equal algorithmic FLOPs)
+    ms4 = (C.c_float * 4)()
+    nst = C.c_int()
+    _lib.check(lib.mmda_misa_timing_collect(model._h, C.byref(ms4), C.byref(nst)), "timing_collect")
+    lib.mmda_misa_timing_end(model._h)
+    ms = [float(x) for x in ms4]
+    sumH2 = 300 ** 2 + 35 ** 2 + 74 ** 2
+    real_steps = float(lengths.sum().item())            # sum_b len_b (= T*B when not ragged)
+    flops_per_launch = 16.0 * real_steps * sumH2        # 2 dirs * 2 FLOP/MAC * 4H*H per (sample, step), summed over modalities
+    names = ["lstm_fwd_kernel(layer1)", "lstm_fwd_kernel(layer2)", "lstm_bwd_kernel(layer2)", "lstm_bwd_kernel(layer1)"]
+    k = max(range(4), key=lambda i: ms[i])
+    peak = 2500.0 if args.precision == "bf16" else 157.3
+    achieved = flops_per_launch / (ms[k] * 1e-3) / 1e12 if ms[k] > 0 else 0.0
+    roofline = {"bound": "mfma", "kernel": names[k], "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 6), "traffic": None, "launch_ms": round(ms[k], 4),
+                "all_launch_ms": {n: round(m, 4) for n, m in zip(names, ms)},
+                "recurrent_share_of_step": round(sum(ms) / (elapsed / args.steps * 1e3), 3), "timed_steps": nst.value}
+
+    total_samples = args.batch * world * args.steps
+    value = total_samples / elapsed
+    out = {
+        "metric": "training samples/sec on MOSEI-shaped synthetic batch", "value": round(value, 2), "unit": "samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": f"MISA train step, MOSEI shapes B={args.batch}/GPU T={args.seq_len} (d_t,d_v,d_a)=(300,35,74) "
+                               f"hidden=128 V={args.vocab}, {args.precision} MFMA operands fp32 accumulate, dropout on, "
+                               f"{'ragged' if args.ragged else 'full'} lengths",
+                   "global_batch": args.batch * world, "seq_len": args.seq_len,
+                   "parallelism": f"dp{world}" if world > 1 else "single", "use_confidNet": bool(args.confidnet)},
+        "gflop_per_sample": 1.184 if args.seq_len == 50 else round(3 * (7736080 * args.seq_len + 7832576) / 1e9, 3),
+        "roofline": roofline,
+        "losses": {k_: round(v_, 5) for k_, v_ in losses.items()},
+    }
+
+    # ---- CPU baseline: the oracle's stock-PyTorch port of the reference loop on this box's host cores (N=1 only)
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import misa_oracle as orc
+        ncores = os.cpu_count() or 1
+        torch.set_num_threads(ncores)
+        ocfg = orc.default_config(vocab_size=args.vocab, use_confidNet=bool(args.confidnet))
+        cb = {"t": t.cpu(), "v": v.cpu(), "a": a.cpu(), "l": lengths.cpu(), "emo": emo.cpu()}
+        nsteps = args.cpu_steps
+        if nsteps <= 0:
+            probe = orc.baseline_train_steps(ocfg, cb, steps=2, warmup=1) / 2
+            nsteps = int(max(3, min(60, 15.0 / max(probe, 1e-3))))
+        secs = orc.baseline_train_steps(ocfg, cb, steps=nsteps, warmup=1)
+        out["cpu_baseline"] = {"value": round(args.batch * nsteps / secs, 2), "unit": "samples/s", "cores": torch.get_num_threads(),
+                               "kind": "port",
+                               "sample": f"{nsteps} training steps of the same B={args.batch},T={args.seq_len} batch "
+                                         f"(oracle.ModuleBaseline: nn.LSTM/nn.TransformerEncoderLayer/torch.optim.Adam fp32)"}
+        out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+    print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,264 @@
+/*
+ * mmda_hip.h - C ABI of libmmda_hip.so: the MI355X (gfx950) hot path of MISA training.
+ *
+ * The reference (SoyeonHH/MMDA) is 100 % Python and has no FFI: every FLOP is a stock PyTorch module call
+ * (SURVEY.md section 8b).  Each entry point below therefore names the reference *call site* whose arithmetic it
+ * replaces.  The Python host in mmda_amd/ binds these with ctypes (mmda_amd/_lib.py); INTEGRATION.md shows the
+ * binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every pointer is DEVICE memory unless the name ends in _host
+ *   - all matrices row-major fp32; sequences time-major (T,B,d) like the reference (data_loader.py:70-72)
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream)
+ *   - return 0 on success, negative MMDA_E* on error (no exceptions cross the ABI); the caller owns all buffers
+ *   - `mode`: MMDA_F32 = exact fp32 (f32 MFMA, parity 1e-4), MMDA_BF16 = bf16 MFMA operands, fp32 accumulate/state
+ */
+#ifndef MMDA_HIP_H
+#define MMDA_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMDA_F32 0
+#define MMDA_BF16 1
+
+#define MMDA_OK 0
+#define MMDA_EINVAL (-1)   /* bad argument / unsupported shape */
+#define MMDA_ELAUNCH (-2)  /* hipLaunch / runtime error (hipGetLastError text via mmda_last_error) */
+
+/* activation ids (reference config.py:25-27 activation_dict; prelu/rrelu unsupported) */
+#define MMDA_ACT_NONE 0
+#define MMDA_ACT_RELU 1
+#define MMDA_ACT_SIGMOID 2
+#define MMDA_ACT_LEAKYRELU 3
+#define MMDA_ACT_TANH 4
+#define MMDA_ACT_ELU 5
+#define MMDA_ACT_HARDTANH 6
+#define MMDA_ACT_HARDSHRINK 7
+
+const char* mmda_last_error(void);
+int mmda_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------- GEMM
+ * C[b] = epilogue( opA(A[b] (+A2[b])) * opB(B[b]) + bias[b] + bias2[b] (+ C[b] if accumulate) )
+ *   opA: transA=0 -> A is (M,K) row-major with leading dim lda; transA=1 -> A is (K,M) row-major
+ *   opB: transB=1 -> B is (N,K) row-major (an nn.Linear weight: y = x W^T); transB=0 -> B is (K,N)
+ *   gather: optional int64 row ids: row m of A is A + gather[m]*lda (embedding lookup fused into the GEMM)
+ *   epilogue: act (MMDA_ACT_*), then optional inverted dropout (p, seed, site) on the result,
+ *             then optional gate: C *= (gate[m,n] > 0 ? gate_scale : 0)   (relu/dropout backward)
+ * Replaces: every nn.Linear / aten::mm / addmm on the path (models.py:48-55 W_ih, :63-153, :160-161) and their
+ * autograd transposes. */
+typedef struct mmda_gemm_args {
+  int mode, transA, transB, M, N, K, batch;
+  const float* A;  int lda;  int64_t strideA;
+  const float* A2;                              /* optional, same layout as A */
+  const int64_t* gather;                        /* optional, M entries (transA must be 0) */
+  const float* B;  int ldb;  int64_t strideB;
+  float* C;        int ldc;  int64_t strideC;
+  const float* bias; const float* bias2; int64_t strideBias;
+  int accumulate, act;
+  float drop_p; uint64_t drop_seed; int drop_site;
+  const float* gate; int ldgate; float gate_scale;
+  float alpha;                                  /* scales the product before bias/accumulate; 0 is read as 1 */
+} mmda_gemm_args;
+int mmda_gemm(const mmda_gemm_args* args, void* stream);
+
+/* column sums: out[n] += sum_m X[m*ld + n] (and out2[n] += the same, if out2 != NULL)   (bias gradients; atomics) */
+int mmda_colsum(const float* X, int ld, int M, int N, float* out, float* out2, void* stream);
+
+/* ---------------------------------------------------------------------------------------------- embedding
+ * models.py:47,201 nn.Embedding forward; backward = dense scatter-add (sparse=False). */
+int mmda_embed_gather(const float* W, const int64_t* ids, int rows, int dim, float* out, void* stream);
+int mmda_embed_scatter_add(float* dW, const int64_t* ids, int rows, int dim, const float* dX, void* stream);
+
+/* ---------------------------------------------------------------------------------------------- LayerNorm
+ * y = LN(act(x) + res * dropmask) * gamma + beta over the last dim n (eps 1e-5).   models.py:155-157,172 and the
+ * LayerNorms inside project_* (models.py:65-80) and the fusion layer (torch TransformerEncoderLayer norm1/norm2).
+ *   permute_sb > 0: rows are (s,b) with s-major, b < permute_sb... output row (s*Bp + b) is written at
+ *   out + b*(S*n) + s*n  (i.e. (S,B,n) -> (B,S,n)), used to emit h = cat(h[0..5],dim=1) (models.py:245).
+ *   stash: mean,rstd (rows each). */
+typedef struct mmda_ln_args {
+  int rows, n;
+  const float* x; const float* res;             /* res optional */
+  const float* gamma; const float* beta;
+  float* y; float* mean; float* rstd;
+  int act;                                      /* applied to x before the residual add */
+  float drop_p; uint64_t drop_seed; int drop_site;   /* dropout on res */
+  int permute_S, permute_B;                     /* 0,0 = no permutation */
+  float eps;
+} mmda_ln_args;
+int mmda_layernorm_fwd(const mmda_ln_args* a, void* stream);
+/* backward: dx_pre = LN'(dy); outputs: d_x = dx_pre * act'(x) (written or accumulated), d_res = dx_pre*dropmask,
+ * dgamma += , dbeta += .  dy may be given in permuted (B,S,n) layout (same permute args as forward). */
+typedef struct mmda_ln_bwd_args {
+  int rows, n;
+  const float* dy; const float* x; const float* res; const float* gamma;
+  const float* mean; const float* rstd;
+  float* d_x; int accumulate_dx; float* d_res;  /* either may be NULL */
+  float* dgamma; float* dbeta;                  /* accumulated with atomics */
+  int act; float drop_p; uint64_t drop_seed; int drop_site;
+  int permute_S, permute_B;
+} mmda_ln_bwd_args;
+int mmda_layernorm_bwd(const mmda_ln_bwd_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------- biLSTM
+ * Recurrent part of nn.LSTM(bidirectional=True) on a packed sequence (models.py:48-55 via extract_features
+ * :163-180), PyTorch gate order i,f,g,o, variable lengths (a sample stops updating at t >= len_b; the reverse
+ * direction starts at len_b-1), final h written straight into the utterance layout of models.py:203.
+ *
+ * Weight packing: W_hh (4H,H) of each direction must first be packed into MFMA fragment order with
+ * mmda_lstm_pack_whh (once per optimizer step).  Packed sizes from mmda_lstm_packed_bytes. */
+int64_t mmda_lstm_packed_bytes(int mode, int H, int backward);
+int mmda_lstm_pack_whh(int mode, int H, const float* whh, void* packed_fwd, void* packed_bwd, void* stream);
+
+typedef struct mmda_lstm_desc {
+  int H;
+  float* gates;        /* (T,B,2,4H)  in: x W_ih^T + b_ih + b_hh per direction; out: activated i,f,g,o (stash) */
+  float* cstash;       /* (T,B,2,H)   cell state after each step (stash) */
+  float* hseq;         /* (T,B,2H)    layer output [fwd H | rev H], zero at padded positions */
+  const void* wpack[2];/* packed W_hh per direction (forward packing for fwd, backward packing for bwd) */
+  float* utt;          /* (B,4H)      final-h destination / its gradient source in backward */
+  int layer;           /* 0 or 1: column block (dir*2+layer)*H of utt */
+  const float* d_hseq; /* backward only: (T,B,2H) gradient w.r.t. hseq, or NULL */
+} mmda_lstm_desc;
+/* up to 4 independent biLSTMs (modalities) in ONE launch; all share B, T and lengths (device int32, B entries) */
+int mmda_lstm_fwd(int mode, int n, const mmda_lstm_desc* descs, int B, int T, const int32_t* lengths, void* stream);
+/* backward: reads gates/cstash (forward stash), utt = d(utterance), d_hseq; overwrites `gates` with d(pre-activation)
+ * (zero at padded positions) for the time-batched weight/input gradient GEMMs. */
+int mmda_lstm_bwd(int mode, int n, const mmda_lstm_desc* descs, int B, int T, const int32_t* lengths, void* stream);
+
+/* ---------------------------------------------------------------------------------------------- fusion attention
+ * Self-attention core of nn.TransformerEncoderLayer(d_model=E, nhead) on (S,B,E) with S small (6): softmax(QK^T/sqrt(hd))V
+ * per (sample, head), attention-prob dropout.  qkv: (S*B, 3E) rows (s,b); ctx: (S*B, E); probs: (B,nhead,S,S). */
+int mmda_attn_fwd(const float* qkv, int S, int B, int E, int nhead, float* ctx, float* probs,
+                  float drop_p, uint64_t seed, int site, void* stream);
+int mmda_attn_bwd(const float* qkv, const float* probs, const float* dctx, int S, int B, int E, int nhead,
+                  float* dqkv, float drop_p, uint64_t seed, int site, void* stream);
+
+/* ---------------------------------------------------------------------------------------------- elementwise
+ * y = a + b */
+int mmda_add(const float* a, const float* b, float* y, int64_t n, void* stream);
+/* d *= y*(1-y)  (sigmoid backward, in place) */
+int mmda_sigmoid_bwd_inplace(float* d, const float* y, int64_t n, void* stream);
+/* h = dropout(act(z));  dz = dh * dropmask * act'(z)   (discriminator hidden layer, models.py:124-126) */
+int mmda_act_dropout_fwd(const float* z, float* h, int64_t n, int act, float drop_p, uint64_t seed, int site, void* stream);
+int mmda_act_dropout_bwd(const float* dh, const float* z, float* dz, int64_t n, int act, float drop_p, uint64_t seed, int site,
+                         void* stream);
+
+/* ---------------------------------------------------------------------------------------------- heads + losses
+ * logits12 (B,12) = h [W_conf;W_cls]^T + b.  tcp = sigmoid(logits[:, :6]); scores = sigmoid(dropout(logits[:,6:]));
+ * labels = scores > threshold.   models.py:138-153,247-249, functions.py:112-115 */
+int mmda_heads_fwd(const float* logits, int B, int ncls, float threshold, float* tcp, float* scores, float* labels,
+                   float drop_p, uint64_t seed, int site, void* stream);
+/* dlogits from dscores/dtcp (either may be NULL = zero) */
+int mmda_heads_bwd(const float* tcp, const float* scores, const float* dtcp, const float* dscores, int B, int ncls,
+                   float* dlogits, float drop_p, uint64_t seed, int site, void* stream);
+
+/* Every loss entry point computes the loss value AND d(loss)/d(inputs) in one pass ("gradient in forward").
+ * `scale` multiplies the gradients (loss weight); *loss gets the UNscaled value added (zero it first).
+ * Gradients are ACCUMULATED into the d_* buffers.
+ * cls: solver.py:373-385   sum_c mean_b BCE (log clamp -100) */
+int mmda_loss_cls(const float* scores, const float* emo, int B, int ncls, float scale, float* loss, float* dscores, void* stream);
+/* conf: solver.py:451-462 */
+int mmda_loss_conf(const float* scores, const float* tcp, const float* emo, int B, int ncls, float scale,
+                   float* loss, float* dscores, float* dtcp, void* stream);
+/* diff: solver.py:422-441 + functions.py:54-78.  x: 6 tensors (B,D) at x + k*stride, order
+ * [private_t, private_v, private_a, shared_t, shared_v, shared_a]; the six reference pairs are built in. */
+int mmda_loss_diff(const float* x, int64_t stride, int B, int D, float scale, float* loss, float* dx, float* work, void* stream);
+int64_t mmda_loss_diff_work_floats(int B, int D);
+/* general form: nt (2..6) tensors at x + k*stride, np (1..6) index pairs (host array of 2*np ints).  The utils.DiffLoss
+ * module call DiffLoss()(a, b) (functions.py:54-78) is nt=2, pairs={0,1}. */
+int mmda_loss_diff_pairs(const float* x, int64_t stride, int nt, int np, const int* pairs_host, int B, int D, float scale,
+                         float* loss, float* dx, float* work, void* stream);
+/* cmd: solver.py:409-420 + functions.py:88-109 over shared_t, shared_v, shared_a = x + k*stride (k=0..2), 5 moments */
+int mmda_loss_cmd(const float* x, int64_t stride, int B, int D, float scale, float* loss, float* dx, void* stream);
+/* general form: nt (2..3) tensors, np pairs, n_moments (1..5); *loss += value_scale * sum over pairs; gradients are
+ * scaled by scale*value_scale.  utils.CMD()(x1, x2, n) (functions.py:88-109) is nt=2, pairs={0,1}, value_scale=1. */
+int mmda_loss_cmd_pairs(const float* x, int64_t stride, int nt, int np, const int* pairs_host, int n_moments, int B, int D,
+                        float scale, float value_scale, float* loss, float* dx, void* stream);
+/* recon: solver.py:443-449.  recon/orig: 3 tensors (B,D) each at +k*stride */
+int mmda_loss_recon(const float* recon, const float* orig, int64_t stride, int B, int D, float scale, float* loss,
+                    float* drecon, float* dorig, void* stream);
+/* domain: solver.py:388-407.  dom: (3,B,3) logits stacked t,v,a; labels 0/1/2 */
+int mmda_loss_domain(const float* dom, int B, float scale, float* loss, float* ddom, void* stream);
+
+/* ---------------------------------------------------------------------------------------------- optimizer
+ * clip_grad_value_(clip) then Adam (solver.py:185-186, :97-99; betas 0.9/0.999, eps 1e-8, no weight decay), fused over
+ * a flat bucket.  step = 1-based step count.  grad_scale multiplies g first (1/world for DP averaging). */
+int mmda_clamp_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                    float eps, float clip, float grad_scale, int step, void* stream);
+int mmda_clamp(float* g, int64_t n, float clip, void* stream);
+
+/* ============================================================================================== whole-model API
+ * The reference's per-batch loop body (solver.py:139-186) as five calls.  `mmda_misa` is the native runtime object
+ * behind mmda_amd.models.MISA: it owns NO device memory - the host binds one flat fp32 parameter bucket (+ grad, Adam
+ * m/v buckets of the same size) and one workspace; the library only lays tensors out inside them.
+ *
+ * Flat bucket layout: all non-embedding parameters first ("dense" part, the RCCL all-reduce bucket), embed.weight last.
+ * mmda_misa_param_info enumerates (state_dict key, offset, rows, cols) - keys are exactly the reference's
+ * state_dict keys, so reference checkpoints load by name. */
+typedef struct mmda_misa mmda_misa;
+typedef struct mmda_misa_config {
+  int vocab, d_t, d_v, d_a, hidden, ncls;       /* config.embedding_size / visual_size / acoustic_size / hidden_size / num_classes */
+  int act;                                      /* MMDA_ACT_* for project_* and the discriminator (config.activation) */
+  int use_cmd_sim, use_confidNet;               /* config.use_cmd_sim / use_confidNet */
+  float dropout;                                /* config.dropout: classifier + discriminator dropout */
+  float fusion_dropout;                         /* nn.TransformerEncoderLayer default 0.1 (not a reference flag) */
+  float threshold, reverse_grad_weight;         /* config.threshold, config.reverse_grad_weight */
+  float diff_weight, sim_weight, recon_weight, conf_weight;   /* config.py:134-138 */
+  int mode;                                     /* MMDA_F32 / MMDA_BF16 for the encoder + fusion GEMMs and the recurrences */
+} mmda_misa_config;
+
+int mmda_misa_create(const mmda_misa_config* cfg, mmda_misa** out);
+void mmda_misa_destroy(mmda_misa* m);
+int mmda_misa_num_params(const mmda_misa* m);
+int mmda_misa_param_info(const mmda_misa* m, int i, const char** name, int64_t* offset, int* rows, int* cols);
+int64_t mmda_misa_flat_floats(const mmda_misa* m);    /* whole bucket incl. embedding (multiple of 4) */
+int64_t mmda_misa_dense_floats(const mmda_misa* m);   /* non-embedding prefix */
+int mmda_misa_bind(mmda_misa* m, float* params, float* grads, float* adam_m, float* adam_v);
+int64_t mmda_misa_workspace_floats(const mmda_misa* m, int B, int T);
+int mmda_misa_set_workspace(mmda_misa* m, float* ws, int64_t floats, int B, int T);
+/* offset (in floats, inside the workspace) of a named activation / activation-gradient, -1 if unknown. Names:
+ *   scores labels tcp logits hfused x6 orig recon dom utt_t utt_v utt_a losses
+ *   d_scores d_tcp d_x6 d_orig d_recon d_dom
+ * x6 = [private_t, private_v, private_a, shared_t, shared_v, shared_a] each (B,hidden); orig/recon = (3,B,hidden);
+ * losses = float[8]: cls, diff, sim, recon, conf, total */
+int64_t mmda_misa_tensor_offset(const mmda_misa* m, const char* name);
+/* set the mode / loss switches after creation (bench toggles) */
+int mmda_misa_set_mode(mmda_misa* m, int mode);
+
+/* models.py:282-285 forward.  t_ids (T,B) int64, v (T,B,d_v), a (T,B,d_a) device; lengths (B) int32 device.
+ * training != 0 enables dropout with the given seed.  Packs W_hh first (weights may have changed). */
+int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float* v, const float* a, const int32_t* lengths,
+                      int training, uint64_t seed, void* stream);
+/* solver.py:163-181: the six losses into `losses`; with_grads != 0 also zeroes and seeds the d_* activation gradients
+ * with the weighted loss gradients (loss.backward() seeds). emo (B,ncls) fp32. */
+int mmda_misa_losses(mmda_misa* m, const float* emo, int with_grads, void* stream);
+/* solver.py:183 loss.backward(): from d_scores/d_tcp/d_x6/d_orig/d_recon/d_dom to every parameter gradient
+ * (ACCUMULATED into the bound grad bucket: zero it first with mmda_misa_zero_grad).  External seeds (the autograd
+ * compat path) are whatever the caller left in the d_* buffers. */
+int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const float* v, const float* a, const int32_t* lengths,
+                       void* stream);
+int mmda_misa_zero_grad(mmda_misa* m, void* stream);
+int mmda_misa_zero_act_grads(mmda_misa* m, void* stream);
+/* solver.py:185-186: clip_grad_value_(clip) + Adam over the whole bucket; grad_scale = 1/world after an all-reduce */
+int mmda_misa_adam_step(mmda_misa* m, float lr, float clip, float grad_scale, int step, void* stream);
+/* zero_grad + forward + losses + backward (+ adam if do_adam) = one reference loop iteration */
+int mmda_misa_train_step(mmda_misa* m, const int64_t* t_ids, const float* v, const float* a, const int32_t* lengths,
+                         const float* emo, int training, uint64_t seed, int do_adam, float lr, float clip, int step,
+                         void* stream);
+
+/* Per-kernel timing of the recurrent launches with HIP events recorded on the SAME stream the kernels run on
+ * (bench.py's roofline leg).  begin(max_steps) arms it; every train_step/forward/backward then brackets its four
+ * recurrent launches (0: fwd layer1, 1: fwd layer2, 2: bwd layer2, 3: bwd layer1); collect() synchronises the events and
+ * returns the mean milliseconds per launch of each and the number of timed steps; end() disarms and frees the events. */
+int mmda_misa_timing_begin(mmda_misa* m, int max_steps);
+int mmda_misa_timing_collect(mmda_misa* m, float mean_ms[4], int* steps);
+int mmda_misa_timing_end(mmda_misa* m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,161 @@
+"""ctypes binding of libmmda_hip.so (the C ABI declared in include/mmda_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or a call fails, this raises.  PyTorch is used by
+callers only to own device memory and streams; every pointer handed over here is ``tensor.data_ptr()``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmmda_hip.so")
+
+F32, BF16 = 0, 1
+ACT = {"none": 0, "relu": 1, "sigmoid": 2, "leakyrelu": 3, "tanh": 4, "elu": 5, "hardtanh": 6, "hardshrink": 7}
+
+c_f32p = C.c_void_p      # device pointers travel as integers
+c_stream = C.c_void_p
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("mode", C.c_int), ("transA", C.c_int), ("transB", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("batch", C.c_int),
+                ("A", C.c_void_p), ("lda", C.c_int), ("strideA", C.c_int64),
+                ("A2", C.c_void_p), ("gather", C.c_void_p),
+                ("B", C.c_void_p), ("ldb", C.c_int), ("strideB", C.c_int64),
+                ("C", C.c_void_p), ("ldc", C.c_int), ("strideC", C.c_int64),
+                ("bias", C.c_void_p), ("bias2", C.c_void_p), ("strideBias", C.c_int64),
+                ("accumulate", C.c_int), ("act", C.c_int),
+                ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_site", C.c_int),
+                ("gate", C.c_void_p), ("ldgate", C.c_int), ("gate_scale", C.c_float),
+                ("alpha", C.c_float)]
+
+
+class LnArgs(C.Structure):
+    _fields_ = [("rows", C.c_int), ("n", C.c_int), ("x", C.c_void_p), ("res", C.c_void_p), ("gamma", C.c_void_p),
+                ("beta", C.c_void_p), ("y", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("act", C.c_int),
+                ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_site", C.c_int),
+                ("permute_S", C.c_int), ("permute_B", C.c_int), ("eps", C.c_float)]
+
+
+class LnBwdArgs(C.Structure):
+    _fields_ = [("rows", C.c_int), ("n", C.c_int), ("dy", C.c_void_p), ("x", C.c_void_p), ("res", C.c_void_p),
+                ("gamma", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
+                ("d_x", C.c_void_p), ("accumulate_dx", C.c_int), ("d_res", C.c_void_p),
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
+                ("act", C.c_int), ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_site", C.c_int),
+                ("permute_S", C.c_int), ("permute_B", C.c_int)]
+
+
+class LstmDesc(C.Structure):
+    _fields_ = [("H", C.c_int), ("gates", C.c_void_p), ("cstash", C.c_void_p), ("hseq", C.c_void_p),
+                ("wpack", C.c_void_p * 2), ("utt", C.c_void_p), ("layer", C.c_int), ("d_hseq", C.c_void_p)]
+
+
+class MisaConfig(C.Structure):
+    _fields_ = [("vocab", C.c_int), ("d_t", C.c_int), ("d_v", C.c_int), ("d_a", C.c_int), ("hidden", C.c_int), ("ncls", C.c_int),
+                ("act", C.c_int), ("use_cmd_sim", C.c_int), ("use_confidNet", C.c_int),
+                ("dropout", C.c_float), ("fusion_dropout", C.c_float), ("threshold", C.c_float),
+                ("reverse_grad_weight", C.c_float),
+                ("diff_weight", C.c_float), ("sim_weight", C.c_float), ("recon_weight", C.c_float), ("conf_weight", C.c_float),
+                ("mode", C.c_int)]
+
+
+# name -> (restype, argtypes).  Every symbol include/mmda_hip.h declares appears here (tests/test_abi.py checks it).
+_P, _I, _I64, _F, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
+SIGNATURES = {
+    "mmda_last_error": (C.c_char_p, []),
+    "mmda_abi_version": (_I, []),
+    "mmda_gemm": (_I, [C.POINTER(GemmArgs), _P]),
+    "mmda_colsum": (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    "mmda_embed_gather": (_I, [_P, _P, _I, _I, _P, _P]),
+    "mmda_embed_scatter_add": (_I, [_P, _P, _I, _I, _P, _P]),
+    "mmda_layernorm_fwd": (_I, [C.POINTER(LnArgs), _P]),
+    "mmda_layernorm_bwd": (_I, [C.POINTER(LnBwdArgs), _P]),
+    "mmda_lstm_packed_bytes": (_I64, [_I, _I, _I]),
+    "mmda_lstm_pack_whh": (_I, [_I, _I, _P, _P, _P, _P]),
+    "mmda_lstm_fwd": (_I, [_I, _I, C.POINTER(LstmDesc), _I, _I, _P, _P]),
+    "mmda_lstm_bwd": (_I, [_I, _I, C.POINTER(LstmDesc), _I, _I, _P, _P]),
+    "mmda_attn_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _U64, _I, _P]),
+    "mmda_attn_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _F, _U64, _I, _P]),
+    "mmda_add": (_I, [_P, _P, _P, _I64, _P]),
+    "mmda_sigmoid_bwd_inplace": (_I, [_P, _P, _I64, _P]),
+    "mmda_act_dropout_fwd": (_I, [_P, _P, _I64, _I, _F, _U64, _I, _P]),
+    "mmda_act_dropout_bwd": (_I, [_P, _P, _P, _I64, _I, _F, _U64, _I, _P]),
+    "mmda_heads_fwd": (_I, [_P, _I, _I, _F, _P, _P, _P, _F, _U64, _I, _P]),
+    "mmda_heads_bwd": (_I, [_P, _P, _P, _P, _I, _I, _P, _F, _U64, _I, _P]),
+    "mmda_loss_cls": (_I, [_P, _P, _I, _I, _F, _P, _P, _P]),
+    "mmda_loss_conf": (_I, [_P, _P, _P, _I, _I, _F, _P, _P, _P, _P]),
+    "mmda_loss_diff": (_I, [_P, _I64, _I, _I, _F, _P, _P, _P, _P]),
+    "mmda_loss_diff_work_floats": (_I64, [_I, _I]),
+    "mmda_loss_diff_pairs": (_I, [_P, _I64, _I, _I, C.POINTER(C.c_int), _I, _I, _F, _P, _P, _P, _P]),
+    "mmda_loss_cmd_pairs": (_I, [_P, _I64, _I, _I, C.POINTER(C.c_int), _I, _I, _I, _F, _F, _P, _P, _P]),
+    "mmda_loss_cmd": (_I, [_P, _I64, _I, _I, _F, _P, _P, _P]),
+    "mmda_loss_recon": (_I, [_P, _P, _I64, _I, _I, _F, _P, _P, _P, _P]),
+    "mmda_loss_domain": (_I, [_P, _I, _F, _P, _P, _P]),
+    "mmda_clamp_adam": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _I, _P]),
+    "mmda_clamp": (_I, [_P, _I64, _F, _P]),
+    "mmda_misa_create": (_I, [C.POINTER(MisaConfig), C.POINTER(C.c_void_p)]),
+    "mmda_misa_destroy": (None, [_P]),
+    "mmda_misa_num_params": (_I, [_P]),
+    "mmda_misa_param_info": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(_I64), C.POINTER(_I), C.POINTER(_I)]),
+    "mmda_misa_flat_floats": (_I64, [_P]),
+    "mmda_misa_dense_floats": (_I64, [_P]),
+    "mmda_misa_bind": (_I, [_P, _P, _P, _P, _P]),
+    "mmda_misa_workspace_floats": (_I64, [_P, _I, _I]),
+    "mmda_misa_set_workspace": (_I, [_P, _P, _I64, _I, _I]),
+    "mmda_misa_tensor_offset": (_I64, [_P, C.c_char_p]),
+    "mmda_misa_set_mode": (_I, [_P, _I]),
+    "mmda_misa_forward": (_I, [_P, _P, _P, _P, _P, _I, _U64, _P]),
+    "mmda_misa_losses": (_I, [_P, _P, _I, _P]),
+    "mmda_misa_backward": (_I, [_P, _P, _P, _P, _P, _P]),
+    "mmda_misa_zero_grad": (_I, [_P, _P]),
+    "mmda_misa_zero_act_grads": (_I, [_P, _P]),
+    "mmda_misa_adam_step": (_I, [_P, _F, _F, _F, _I, _P]),
+    "mmda_misa_timing_begin": (_I, [_P, _I]),
+    "mmda_misa_timing_collect": (_I, [_P, C.POINTER(C.c_float * 4), C.POINTER(_I)]),
+    "mmda_misa_timing_end": (_I, [_P]),
+    "mmda_misa_train_step": (_I, [_P, _P, _P, _P, _P, _P, _I, _U64, _I, _F, _F, _I, _P]),
+}
+
+_lib = None
+
+
+class MMDAError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library once.  Raises (never falls back) if it is missing: build it with
+    ``python -c 'import __graft_entry__ as g; g.build()'`` or ``make -C mmda_amd/csrc``."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MMDAError(f"{LIB_PATH} not found: the HIP hot-path library is not built (make -C mmda_amd/csrc); "
+                        "there is no CPU/PyTorch fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/binding drift
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        lib = load()
+        msg = lib.mmda_last_error()
+        raise MMDAError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

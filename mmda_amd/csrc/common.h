@@ -1,0 +1,114 @@
+// Shared device/host helpers for the gfx950 kernels (wave64, MFMA fragment types, RNG, reductions).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/mmda_hip.h"
+
+#define WAVE 64
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 = one 16x16x32 A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4;     // 16x16 accumulator fragment
+
+void mmda_set_error(const char* what, hipError_t e);
+#define MMDA_CHECK_LAUNCH(name)                                   \
+  do {                                                            \
+    hipError_t _e = hipGetLastError();                            \
+    if (_e != hipSuccess) { mmda_set_error(name, _e); return MMDA_ELAUNCH; } \
+  } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
+
+// fp32 -> bf16 round-to-nearest-even via the hardware cast (keeps NaN a NaN, MI355X_MICROARCH correctness table)
+__device__ __forceinline__ unsigned short f2bf(float x) {
+  __bf16 b = (__bf16)x;
+  return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float bf2f(unsigned short u) {
+  return __builtin_bit_cast(float, ((unsigned)u) << 16);
+}
+
+// accurate versions (fp32 parity path and every non-recurrent kernel)
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// tanh via exp(-2|x|): saturates cleanly, |err| ~1e-7
+__device__ __forceinline__ float tanhf_(float x) {
+  float ax = fabsf(x);
+  float e = expf(-2.0f * ax);
+  float t = (1.0f - e) / (1.0f + e);
+  return copysignf(t, x);
+}
+// fast versions (v_exp_f32 + v_rcp_f32) for the bf16 recurrent kernels where the gate math sits on the serial chain
+__device__ __forceinline__ float sigmoid_fast(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) {
+  float ax = fabsf(x);
+  float e = __expf(-2.0f * ax);
+  float t = (1.0f - e) * __frcp_rn(1.0f + e);
+  return copysignf(t, x);
+}
+
+// Counter-based dropout RNG: murmur3 fmix64 of (seed, site, element index).  The same triple gives the same bit in
+// forward and backward, so masks are never stored.
+__device__ __forceinline__ uint32_t rng_u32(uint64_t seed, int site, uint64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(site + 1) + idx * 0xD6E8FEB86659FD93ull;
+  z ^= z >> 33; z *= 0xff51afd7ed558ccdull;
+  z ^= z >> 33; z *= 0xc4ceb9fe1a85ec53ull;
+  z ^= z >> 33;
+  return (uint32_t)(z >> 16);
+}
+// inverted-dropout multiplier: 0 with probability p, else 1/(1-p)
+__device__ __forceinline__ float drop_mul(float p, uint64_t seed, int site, uint64_t idx) {
+  if (p <= 0.0f) return 1.0f;
+  uint32_t r = rng_u32(seed, site, idx);
+  float u = (float)(r >> 8) * (1.0f / 16777216.0f);
+  return u < p ? 0.0f : 1.0f / (1.0f - p);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+// block-wide sum for blockDim.x <= 1024 (multiple of 64); `red` is >= 16 floats of LDS. All threads get the result.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+
+__device__ __forceinline__ float act_fwd(int act, float x) {
+  switch (act) {
+    case MMDA_ACT_RELU: return x > 0.f ? x : 0.f;
+    case MMDA_ACT_SIGMOID: return sigmoidf_(x);
+    case MMDA_ACT_LEAKYRELU: return x > 0.f ? x : 0.01f * x;
+    case MMDA_ACT_TANH: return tanhf_(x);
+    case MMDA_ACT_ELU: return x > 0.f ? x : (__expf(x) - 1.0f);
+    case MMDA_ACT_HARDTANH: return fminf(fmaxf(x, -1.f), 1.f);
+    case MMDA_ACT_HARDSHRINK: return (x > 0.5f || x < -0.5f) ? x : 0.f;
+    default: return x;
+  }
+}
+// derivative w.r.t. the pre-activation x
+__device__ __forceinline__ float act_bwd(int act, float x) {
+  switch (act) {
+    case MMDA_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+    case MMDA_ACT_SIGMOID: { float s = sigmoidf_(x); return s * (1.f - s); }
+    case MMDA_ACT_LEAKYRELU: return x > 0.f ? 1.f : 0.01f;
+    case MMDA_ACT_TANH: { float t = tanhf_(x); return 1.f - t * t; }
+    case MMDA_ACT_ELU: return x > 0.f ? 1.f : __expf(x);
+    case MMDA_ACT_HARDTANH: return (x > -1.f && x < 1.f) ? 1.f : 0.f;
+    case MMDA_ACT_HARDSHRINK: return (x > 0.5f || x < -0.5f) ? 1.f : 0.f;
+    default: return 1.f;
+  }
+}

@@ -1,0 +1,191 @@
+// Generic LDS-tiled MFMA GEMM for gfx950: fp32 data in HBM, f32 MFMA (exact) or bf16 MFMA (fp32 accumulate).
+// One kernel serves every nn.Linear forward (NT), its input gradient (NN) and weight gradient (TN) on the path;
+// operands whose inner dimension is 35/74/140/296/300 are handled by bounds-checked staging (zero fill).
+//
+// Tile 64x64x32, 256 threads = 4 waves (2x2), each wave a 32x32 sub-tile = 2x2 MFMA 16x16 accumulators.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 64, BN = 64, BK = 32;
+constexpr int LDS_F32_LD = 34;   // floats per LDS row: (2*row + k) % 32 distinct for the 16x16x4 operand reads
+constexpr int LDS_BF16_LD = 40;  // shorts per LDS row (80 B, 16-B aligned rows for ds_read_b128)
+
+template <int MODE>
+__global__ __launch_bounds__(256) void gemm_kernel(mmda_gemm_args g) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BM * LDS_F32_LD * 4];
+  float* As_f = reinterpret_cast<float*>(smem);
+  float* Bs_f = As_f + BM * LDS_F32_LD;
+  unsigned short* As_h = reinterpret_cast<unsigned short*>(smem);
+  unsigned short* Bs_h = As_h + BM * LDS_BF16_LD;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const int row0 = blockIdx.y * BM, col0 = blockIdx.x * BN;
+  const int64_t bz = blockIdx.z;
+  const float* A = g.A + bz * g.strideA;
+  const float* A2 = g.A2 ? g.A2 + bz * g.strideA : nullptr;
+  const float* Bm = g.B + bz * g.strideB;
+  float* C = g.C + bz * g.strideC;
+  const int M = g.M, N = g.N, K = g.K;
+
+  // per-thread staging coordinates (fixed across k-tiles)
+  int a_r[8], a_k[8], b_r[8], b_k[8];
+  int64_t a_row_off[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    int e = tid + 256 * i;
+    if (g.transA) { a_r[i] = e & 63; a_k[i] = e >> 6; } else { a_r[i] = e >> 5; a_k[i] = e & 31; }
+    if (g.transB) { b_r[i] = e >> 5; b_k[i] = e & 31; } else { b_r[i] = e & 63; b_k[i] = e >> 6; }
+    int m = row0 + a_r[i];
+    int64_t src = m;
+    if (g.gather && m < M) src = g.gather[m];
+    a_row_off[i] = src;
+  }
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float ra[8], rb[8];
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int m = row0 + a_r[i], k = k0 + a_k[i];
+      float v = 0.f;
+      if (m < M && k < K) {
+        int64_t off = g.transA ? (int64_t)k * g.lda + m : a_row_off[i] * g.lda + k;
+        v = A[off];
+        if (A2) v += A2[off];
+      }
+      ra[i] = v;
+      int n = col0 + b_r[i];
+      k = k0 + b_k[i];
+      float u = 0.f;
+      if (n < N && k < K) u = g.transB ? Bm[(int64_t)n * g.ldb + k] : Bm[(int64_t)k * g.ldb + n];
+      rb[i] = u;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (MODE == MMDA_BF16) {
+        As_h[a_r[i] * LDS_BF16_LD + a_k[i]] = f2bf(ra[i]);
+        Bs_h[b_r[i] * LDS_BF16_LD + b_k[i]] = f2bf(rb[i]);
+      } else {
+        As_f[a_r[i] * LDS_F32_LD + a_k[i]] = ra[i];
+        Bs_f[b_r[i] * LDS_F32_LD + b_k[i]] = rb[i];
+      }
+    }
+  };
+
+  const int nk = (K + BK - 1) / BK;
+  load_tile(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();            // previous tile's fragment reads are done
+    store_tile();
+    __syncthreads();
+    if (kt + 1 < nk) load_tile((kt + 1) * BK);   // global loads fly under the MFMAs below
+    const int fr = lane & 15, fq = lane >> 4;
+    if (MODE == MMDA_BF16) {
+      bf16x8 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = *reinterpret_cast<const bf16x8*>(&As_h[(wm * 32 + i * 16 + fr) * LDS_BF16_LD + fq * 8]);
+        b[i] = *reinterpret_cast<const bf16x8*>(&Bs_h[(wn * 32 + i * 16 + fr) * LDS_BF16_LD + fq * 8]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < BK / 4; ++kk) {
+        float a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          a[i] = As_f[(wm * 32 + i * 16 + fr) * LDS_F32_LD + kk * 4 + fq];
+          b[i] = Bs_f[(wn * 32 + i * 16 + fr) * LDS_F32_LD + kk * 4 + fq];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+
+  // epilogue: C/D fragment map col = lane&15, row = (lane>>4)*4 + reg
+  const float* bias = g.bias ? g.bias + bz * g.strideBias : nullptr;
+  const float* bias2 = g.bias2 ? g.bias2 + bz * g.strideBias : nullptr;
+  const float alpha = g.alpha == 0.f ? 1.f : g.alpha;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int n = col0 + wn * 32 + j * 16 + (lane & 15);
+      if (n >= N) continue;
+      float bsum = 0.f;
+      if (bias) bsum += bias[n];
+      if (bias2) bsum += bias2[n];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int m = row0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r;
+        if (m >= M) continue;
+        float v = alpha * acc[i][j][r] + bsum;
+        int64_t ci = (int64_t)m * g.ldc + n;
+        if (g.accumulate) v += C[ci];
+        v = act_fwd(g.act, v);
+        if (g.drop_p > 0.f) v *= drop_mul(g.drop_p, g.drop_seed, g.drop_site, ((uint64_t)bz * M + m) * N + n);
+        if (g.gate) v *= (g.gate[bz * g.strideC + (int64_t)m * g.ldgate + n] > 0.f) ? g.gate_scale : 0.f;
+        C[ci] = v;
+      }
+    }
+}
+
+__global__ void colsum_kernel(const float* __restrict__ X, int ld, int M, int N, float* out, float* out2, int rows_per_block) {
+  __shared__ float red[4][64];
+  int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  int rg = threadIdx.x >> 6;
+  int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float s = 0.f;
+  if (c < N)
+    for (int r = r0 + rg; r < r1; r += 4) s += X[(int64_t)r * ld + c];
+  red[rg][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rg == 0 && c < N) {
+    float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    atomicAdd(&out[c], t);
+    if (out2) atomicAdd(&out2[c], t);
+  }
+}
+
+}  // namespace
+
+extern "C" int mmda_gemm(const mmda_gemm_args* a, void* stream) {
+  if (!a || !a->A || !a->B || !a->C) return MMDA_EINVAL;
+  if (a->M < 0 || a->N < 0 || a->batch < 0 || a->K < 0 || (a->gather && a->transA)) return MMDA_EINVAL;
+  if (a->M == 0 || a->N == 0 || a->batch == 0) return MMDA_OK;
+  if (a->mode != MMDA_F32 && a->mode != MMDA_BF16) return MMDA_EINVAL;
+  dim3 grid(ceil_div(a->N, BN), ceil_div(a->M, BM), a->batch);
+  if (grid.y > 65535 || grid.z > 65535) return MMDA_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (a->mode == MMDA_BF16) hipLaunchKernelGGL(gemm_kernel<MMDA_BF16>, grid, dim3(256), 0, s, *a);
+  else hipLaunchKernelGGL(gemm_kernel<MMDA_F32>, grid, dim3(256), 0, s, *a);
+  MMDA_CHECK_LAUNCH("mmda_gemm");
+  return MMDA_OK;
+}
+
+extern "C" int mmda_colsum(const float* X, int ld, int M, int N, float* out, float* out2, void* stream) {
+  if (!X || !out || M < 0 || N <= 0) return MMDA_EINVAL;
+  if (M == 0) return MMDA_OK;
+  int rpb = 256;
+  dim3 grid(ceil_div(N, 64), ceil_div(M, rpb));
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, ld, M, N, out, out2, rpb);
+  MMDA_CHECK_LAUNCH("mmda_colsum");
+  return MMDA_OK;
+}

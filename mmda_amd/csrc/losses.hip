@@ -1,0 +1,449 @@
+// Output heads and the loss functions of the reference solver (solver.py:373-462, utils/functions.py:49-109).
+// Every loss kernel produces the value AND the gradient w.r.t. its inputs in the same pass ("gradient in forward"):
+// the total loss is a fixed weighted sum (solver.py:175-181), so the backward seed of each term is its weight.
+// These are batch-statistic reductions over (B, 128)-sized tensors: latency work on a handful of workgroups.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ heads
+__global__ void heads_fwd_kernel(const float* __restrict__ logits, int B, int ncls, float thr, float* tcp, float* scores,
+                                 float* labels, float p, uint64_t seed, int site) {
+  const int NC = 6 + ncls;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < B * NC; e += gridDim.x * blockDim.x) {
+    int b = e / NC, c = e % NC;
+    float z = logits[e];
+    if (c < 6) {
+      tcp[b * 6 + c] = sigmoidf_(z);
+    } else {
+      int k = c - 6;
+      float s = sigmoidf_(z * drop_mul(p, seed, site, (uint64_t)(b * ncls + k)));
+      scores[b * ncls + k] = s;
+      labels[b * ncls + k] = s > thr ? 1.f : 0.f;
+    }
+  }
+}
+
+__global__ void heads_bwd_kernel(const float* __restrict__ tcp, const float* __restrict__ scores, const float* dtcp,
+                                 const float* dscores, int B, int ncls, float* dlogits, float p, uint64_t seed, int site) {
+  const int NC = 6 + ncls;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < B * NC; e += gridDim.x * blockDim.x) {
+    int b = e / NC, c = e % NC;
+    float g = 0.f;
+    if (c < 6) {
+      if (dtcp) { float t = tcp[b * 6 + c]; g = dtcp[b * 6 + c] * t * (1.f - t); }
+    } else {
+      int k = c - 6;
+      if (dscores) {
+        float s = scores[b * ncls + k];
+        g = dscores[b * ncls + k] * s * (1.f - s) * drop_mul(p, seed, site, (uint64_t)(b * ncls + k));
+      }
+    }
+    dlogits[e] = g;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ cls (BCE)
+// loss = sum_c (1/B) sum_b -(y log s + (1-y) log(1-s)), logs clamped at -100 (torch BCELoss);
+// grad  = (s - y) / max(s (1-s), 1e-12) / B   (torch binary_cross_entropy_backward)
+__global__ __launch_bounds__(256) void cls_kernel(const float* __restrict__ s, const float* __restrict__ y, int B, int ncls,
+                                                  float scale, float* loss, float* ds) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  for (int e = threadIdx.x; e < B * ncls; e += blockDim.x) {
+    float sv = s[e], yv = y[e];
+    float lp = fmaxf(logf(sv), -100.f), lq = fmaxf(log1pf(-sv), -100.f);
+    acc += -(yv * lp + (1.f - yv) * lq);
+    if (ds) ds[e] += scale * (sv - yv) / fmaxf(sv * (1.f - sv), 1e-12f) / B;
+  }
+  float t = block_sum(acc, red);
+  if (threadIdx.x == 0 && loss) atomicAdd(loss, t / B);
+}
+
+// ------------------------------------------------------------------------------------------------ conf (ConfidNet)
+// One workgroup per class c (solver.py:458-460):
+//   tcp  : mean_b (tcp - y*s)^2 / nnz
+//   mcp  : CrossEntropyLoss on a 1-D input with float target = -sum_b y_b * log_softmax_over_batch(s)_b / nnz
+__global__ __launch_bounds__(256) void conf_kernel(const float* __restrict__ s, const float* __restrict__ tcp,
+                                                   const float* __restrict__ y, int B, int ncls, float scale, float* loss,
+                                                   float* ds, float* dtcp) {
+  __shared__ float red[16];
+  __shared__ float smax[4];
+  const int c = blockIdx.x;
+  float nz = 0.f, sy = 0.f, mx = -INFINITY;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    float yv = y[b * ncls + c];
+    nz += (yv != 0.f) ? 1.f : 0.f;
+    sy += yv;
+    mx = fmaxf(mx, s[b * ncls + c]);
+  }
+  nz = block_sum(nz, red);
+  sy = block_sum(sy, red);
+  mx = wave_max(mx);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+  float se = 0.f;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) se += expf(s[b * ncls + c] - mx);
+  se = block_sum(se, red);
+  const float lse = mx + logf(se);
+  float lt = 0.f, lm = 0.f;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    int e = b * ncls + c;
+    float sv = s[e], yv = y[e], tv = tcp[e];
+    float diff = tv - yv * sv;
+    lt += diff * diff;
+    lm += -yv * (sv - lse);
+    float gt = 2.f * diff / (B * nz);
+    if (dtcp) dtcp[e] += scale * gt;
+    if (ds) ds[e] += scale * (-yv * gt + (-yv + sy * expf(sv - lse)) / nz);
+  }
+  lt = block_sum(lt, red);
+  lm = block_sum(lm, red);
+  if (threadIdx.x == 0 && loss) atomicAdd(loss, lt / (B * nz) + lm / nz);
+}
+
+// ------------------------------------------------------------------------------------------------ diff
+// (1) per tensor: centre over the batch, divide rows by (detached L2 norm + 1e-6)            -> Ahat, invn
+// (2) K_k = Ahat_k Ahat_k^T (B x B) for the six tensors (batched MFMA GEMM)
+// (3) loss_pair(i,j) = mean((Ahat_i^T Ahat_j)^2) = sum(K_i o K_j)/D^2 ;  Ksum_i = sum_{j in pairs(i)} K_j * 2*scale/D^2
+// (4) dAhat_i = Ksum_i Ahat_i (batched GEMM)
+// (5) dx_i += dAhat_i*invn - colmean(dAhat_i*invn)   (norm detached, centring backward)
+__global__ __launch_bounds__(256) void diff_prep_kernel(const float* __restrict__ x, int64_t stride, int B, int D, float* Ahat,
+                                                        float* invn, float* mean) {
+  const int k = blockIdx.x;
+  const float* X = x + k * stride;
+  float* M = mean + k * D;
+  for (int i = threadIdx.x; i < D; i += blockDim.x) {
+    float s = 0.f;
+    for (int r = 0; r < B; ++r) {
+      float v = X[(int64_t)r * D + i];
+      v = (v != v) ? 0.f : fminf(fmaxf(v, -3.402823466e38f), 3.402823466e38f);   // nan_to_num
+      s += v;
+    }
+    M[i] = s / B;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = wave; r < B; r += 4) {
+    float ss = 0.f;
+    for (int i = lane; i < D; i += 64) {
+      float v = X[(int64_t)r * D + i];
+      v = (v != v) ? 0.f : fminf(fmaxf(v, -3.402823466e38f), 3.402823466e38f);
+      float c = v - M[i];
+      ss += c * c;
+    }
+    ss = wave_sum(ss);
+    float inv = 1.0f / (sqrtf(ss) + 1e-6f);
+    if (lane == 0) invn[k * B + r] = inv;
+    for (int i = lane; i < D; i += 64) {
+      float v = X[(int64_t)r * D + i];
+      v = (v != v) ? 0.f : fminf(fmaxf(v, -3.402823466e38f), 3.402823466e38f);
+      Ahat[((int64_t)k * B + r) * D + i] = (v - M[i]) * inv;
+    }
+  }
+}
+
+struct PairList { int nt, np; int a[6], b[6]; };
+
+__device__ __forceinline__ float sel6(const float (&v)[6], int i) {
+  // register-resident select (a runtime-indexed local array would go to scratch)
+  float r = v[0];
+  r = i == 1 ? v[1] : r; r = i == 2 ? v[2] : r; r = i == 3 ? v[3] : r; r = i == 4 ? v[4] : r; r = i == 5 ? v[5] : r;
+  return r;
+}
+
+__global__ __launch_bounds__(256) void diff_combine_kernel(const float* __restrict__ K, int B, int D, float scale, float* loss,
+                                                           float* Ksum, PairList pl) {
+  __shared__ float red[16];
+  const int64_t BB = (int64_t)B * B;
+  float acc = 0.f;
+  const float gscale = 2.f * scale / ((float)D * D);
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < BB; e += (int64_t)gridDim.x * blockDim.x) {
+    float kv[6], ks[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 6; ++t) kv[t] = t < pl.nt ? K[t * BB + e] : 0.f;
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+      if (p < pl.np) {
+        const int i = pl.a[p], j = pl.b[p];
+        const float ki = sel6(kv, i), kj = sel6(kv, j);
+        acc += ki * kj;
+#pragma unroll
+        for (int t = 0; t < 6; ++t) ks[t] += (t == i ? kj : 0.f) + (t == j ? ki : 0.f);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+      if (t < pl.nt) Ksum[t * BB + e] = ks[t] * gscale;
+  }
+  float t = block_sum(acc, red);
+  if (threadIdx.x == 0 && loss) atomicAdd(loss, t / ((float)D * D));
+}
+
+__global__ __launch_bounds__(256) void diff_finish_kernel(const float* __restrict__ dA, const float* __restrict__ invn, int B,
+                                                          int D, int64_t stride, float* dx) {
+  const int k = blockIdx.x;
+  for (int i = threadIdx.x; i < D; i += blockDim.x) {
+    float s = 0.f;
+    for (int r = 0; r < B; ++r) s += dA[((int64_t)k * B + r) * D + i] * invn[k * B + r];
+    float cm = s / B;
+    for (int r = 0; r < B; ++r) dx[k * stride + (int64_t)r * D + i] += dA[((int64_t)k * B + r) * D + i] * invn[k * B + r] - cm;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ cmd
+// One workgroup; thread per (tensor, column).  Moments k=1..5 per column, pair norms, then the analytic gradient
+//   d/dx[r,i] = scale/(3B) * [U1[i] + sum_{k=2..5} U_k[i] * k * (s[r,i]^(k-1) - c_{k-1}[i])]
+// with U_k = sum over pairs of (+/-) (m_a,k - m_b,k)/||m_a,k - m_b,k|| and c_1 = 0.
+__global__ __launch_bounds__(256) void cmd_kernel(const float* __restrict__ x, int64_t stride, int B, int D, float scale,
+                                                  float vscale, float* loss, float* dx, PairList pl, int nmom) {
+  extern __shared__ float sm[];
+  __shared__ float red[16];
+  __shared__ float nrm[6][5];
+  float* mom = sm;                 // [3][5][D]
+  float* U = sm + 15 * D;          // [3][5][D]
+  for (int it = threadIdx.x; it < pl.nt * D; it += blockDim.x) {
+    int k = it / D, i = it % D;
+    const float* X = x + k * stride;
+    float s = 0.f;
+    for (int r = 0; r < B; ++r) s += X[(int64_t)r * D + i];
+    float m = s / B;
+    float c2 = 0.f, c3 = 0.f, c4 = 0.f, c5 = 0.f;
+    for (int r = 0; r < B; ++r) {
+      float d = X[(int64_t)r * D + i] - m;
+      float d2 = d * d;
+      c2 += d2; c3 += d2 * d; c4 += d2 * d2; c5 += d2 * d2 * d;
+    }
+    mom[(k * 5 + 0) * D + i] = m;
+    mom[(k * 5 + 1) * D + i] = c2 / B;
+    mom[(k * 5 + 2) * D + i] = c3 / B;
+    mom[(k * 5 + 3) * D + i] = c4 / B;
+    mom[(k * 5 + 4) * D + i] = c5 / B;
+  }
+  __syncthreads();
+  float total = 0.f;
+  for (int p = 0; p < pl.np; ++p)
+    for (int k = 0; k < nmom; ++k) {
+      float acc = 0.f;
+      for (int i = threadIdx.x; i < D; i += blockDim.x) {
+        float d = mom[(pl.a[p] * 5 + k) * D + i] - mom[(pl.b[p] * 5 + k) * D + i];
+        acc += d * d;
+      }
+      float t = sqrtf(block_sum(acc, red));
+      if (threadIdx.x == 0) nrm[p][k] = t;
+      total += t;
+    }
+  __syncthreads();
+  if (threadIdx.x == 0 && loss) atomicAdd(loss, total * vscale);
+  if (!dx) return;
+  for (int it = threadIdx.x; it < 15 * D; it += blockDim.x) U[it] = 0.f;
+  __syncthreads();
+  for (int it = threadIdx.x; it < nmom * D; it += blockDim.x) {
+    int k = it / D, i = it % D;
+    for (int p = 0; p < pl.np; ++p) {
+      float d = mom[(pl.a[p] * 5 + k) * D + i] - mom[(pl.b[p] * 5 + k) * D + i];
+      float u = d / nrm[p][k];              // 0/0 -> NaN exactly like sqrt'(0) in the reference
+      U[(pl.a[p] * 5 + k) * D + i] += u;    // same thread owns column i for every p: no race
+      U[(pl.b[p] * 5 + k) * D + i] -= u;
+    }
+  }
+  __syncthreads();
+  const float gs = scale * vscale / B;
+  for (int it = threadIdx.x; it < pl.nt * D; it += blockDim.x) {
+    int k = it / D, i = it % D;
+    const float* X = x + k * stride;
+    float m = mom[(k * 5) * D + i];
+    float c2 = mom[(k * 5 + 1) * D + i], c3 = mom[(k * 5 + 2) * D + i], c4 = mom[(k * 5 + 3) * D + i];
+    float u1 = U[(k * 5) * D + i], u2 = U[(k * 5 + 1) * D + i], u3 = U[(k * 5 + 2) * D + i];
+    float u4 = U[(k * 5 + 3) * D + i], u5 = U[(k * 5 + 4) * D + i];
+    for (int r = 0; r < B; ++r) {
+      float d = X[(int64_t)r * D + i] - m;
+      float d2 = d * d;
+      float g = u1 + u2 * 2.f * d + u3 * 3.f * (d2 - c2) + u4 * 4.f * (d2 * d - c3) + u5 * 5.f * (d2 * d2 - c4);
+      dx[k * stride + (int64_t)r * D + i] += gs * g;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ recon (MSE)
+__global__ __launch_bounds__(256) void recon_kernel(const float* __restrict__ rec, const float* __restrict__ orig, int64_t n,
+                                                    float inv_n, float scale, float* loss, float* drec, float* dorig) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    float d = rec[e] - orig[e];
+    acc += d * d;
+    float g = 2.f * d * inv_n * scale;
+    if (drec) drec[e] += g;
+    if (dorig) dorig[e] -= g;
+  }
+  float t = block_sum(acc, red);
+  if (threadIdx.x == 0 && loss) atomicAdd(loss, t * inv_n);
+}
+
+// ------------------------------------------------------------------------------------------------ domain (CE)
+__global__ __launch_bounds__(256) void domain_kernel(const float* __restrict__ dom, int B, float scale, float* loss, float* ddom) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  const int rows = 3 * B;
+  for (int r = threadIdx.x; r < rows; r += blockDim.x) {
+    int label = r / B;
+    float z0 = dom[r * 3], z1 = dom[r * 3 + 1], z2 = dom[r * 3 + 2];
+    float m = fmaxf(z0, fmaxf(z1, z2));
+    float e0 = expf(z0 - m), e1 = expf(z1 - m), e2 = expf(z2 - m);
+    float se = e0 + e1 + e2;
+    float lse = m + logf(se);
+    float zl = label == 0 ? z0 : (label == 1 ? z1 : z2);
+    acc += lse - zl;
+    if (ddom) {
+      float g = scale / rows;
+      ddom[r * 3 + 0] += g * (e0 / se - (label == 0 ? 1.f : 0.f));
+      ddom[r * 3 + 1] += g * (e1 / se - (label == 1 ? 1.f : 0.f));
+      ddom[r * 3 + 2] += g * (e2 / se - (label == 2 ? 1.f : 0.f));
+    }
+  }
+  float t = block_sum(acc, red);
+  if (threadIdx.x == 0 && loss) atomicAdd(loss, t / rows);
+}
+
+}  // namespace
+
+extern "C" int mmda_heads_fwd(const float* logits, int B, int ncls, float threshold, float* tcp, float* scores, float* labels,
+                              float drop_p, uint64_t seed, int site, void* stream) {
+  if (!logits || !tcp || !scores || !labels || B <= 0 || ncls <= 0) return MMDA_EINVAL;
+  int n = B * (6 + ncls);
+  hipLaunchKernelGGL(heads_fwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, logits, B, ncls, threshold, tcp,
+                     scores, labels, drop_p, seed, site);
+  MMDA_CHECK_LAUNCH("mmda_heads_fwd");
+  return MMDA_OK;
+}
+
+extern "C" int mmda_heads_bwd(const float* tcp, const float* scores, const float* dtcp, const float* dscores, int B, int ncls,
+                              float* dlogits, float drop_p, uint64_t seed, int site, void* stream) {
+  if (!tcp || !scores || !dlogits || B <= 0 || ncls <= 0) return MMDA_EINVAL;
+  int n = B * (6 + ncls);
+  hipLaunchKernelGGL(heads_bwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, tcp, scores, dtcp, dscores, B,
+                     ncls, dlogits, drop_p, seed, site);
+  MMDA_CHECK_LAUNCH("mmda_heads_bwd");
+  return MMDA_OK;
+}
+
+extern "C" int mmda_loss_cls(const float* scores, const float* emo, int B, int ncls, float scale, float* loss, float* dscores,
+                             void* stream) {
+  if (!scores || !emo || B <= 0 || ncls <= 0) return MMDA_EINVAL;
+  hipLaunchKernelGGL(cls_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scores, emo, B, ncls, scale, loss, dscores);
+  MMDA_CHECK_LAUNCH("mmda_loss_cls");
+  return MMDA_OK;
+}
+
+extern "C" int mmda_loss_conf(const float* scores, const float* tcp, const float* emo, int B, int ncls, float scale, float* loss,
+                              float* dscores, float* dtcp, void* stream) {
+  if (!scores || !tcp || !emo || B <= 0 || ncls != 6) return MMDA_EINVAL;   // tcp has 6 columns (models.py:139)
+  hipLaunchKernelGGL(conf_kernel, dim3(ncls), dim3(256), 0, (hipStream_t)stream, scores, tcp, emo, B, ncls, scale, loss, dscores, dtcp);
+  MMDA_CHECK_LAUNCH("mmda_loss_conf");
+  return MMDA_OK;
+}
+
+extern "C" int64_t mmda_loss_diff_work_floats(int B, int D) {
+  return (int64_t)12 * B * D + 6 * B + 6 * D + (int64_t)12 * B * B;
+}
+
+namespace {
+bool fill_pairs(PairList& pl, int nt, int np, const int* pairs, int max_t) {
+  if (nt < 2 || nt > max_t || np < 1 || np > 6 || !pairs) return false;
+  pl.nt = nt; pl.np = np;
+  for (int p = 0; p < 6; ++p) { pl.a[p] = 0; pl.b[p] = 0; }
+  for (int p = 0; p < np; ++p) {
+    pl.a[p] = pairs[2 * p]; pl.b[p] = pairs[2 * p + 1];
+    if (pl.a[p] < 0 || pl.a[p] >= nt || pl.b[p] < 0 || pl.b[p] >= nt) return false;
+  }
+  return true;
+}
+}  // namespace
+
+extern "C" int mmda_loss_diff_pairs(const float* x, int64_t stride, int nt, int np, const int* pairs_host, int B, int D, float scale,
+                                    float* loss, float* dx, float* work, void* stream) {
+  PairList pl;
+  if (!x || !work || B <= 0 || D <= 0 || !fill_pairs(pl, nt, np, pairs_host, 6)) return MMDA_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  float* Ahat = work;                               // 6*B*D
+  float* dA = Ahat + (int64_t)6 * B * D;            // 6*B*D
+  float* invn = dA + (int64_t)6 * B * D;            // 6*B
+  float* mean = invn + 6 * B;                       // 6*D
+  float* K = mean + 6 * D;                          // 6*B*B
+  float* Ksum = K + (int64_t)6 * B * B;             // 6*B*B
+  hipLaunchKernelGGL(diff_prep_kernel, dim3(nt), dim3(256), 0, s, x, stride, B, D, Ahat, invn, mean);
+  MMDA_CHECK_LAUNCH("mmda_loss_diff/prep");
+  mmda_gemm_args g = {};
+  g.mode = MMDA_F32; g.transA = 0; g.transB = 1; g.M = B; g.N = B; g.K = D; g.batch = nt;
+  g.A = Ahat; g.lda = D; g.strideA = (int64_t)B * D;
+  g.B = Ahat; g.ldb = D; g.strideB = (int64_t)B * D;
+  g.C = K; g.ldc = B; g.strideC = (int64_t)B * B;
+  int rc = mmda_gemm(&g, stream);
+  if (rc) return rc;
+  int64_t BB = (int64_t)B * B;
+  int blocks = (int)((BB + 255) / 256); if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(diff_combine_kernel, dim3(blocks), dim3(256), 0, s, K, B, D, scale, loss, Ksum, pl);
+  MMDA_CHECK_LAUNCH("mmda_loss_diff/combine");
+  if (!dx) return MMDA_OK;
+  mmda_gemm_args h = {};
+  h.mode = MMDA_F32; h.transA = 0; h.transB = 0; h.M = B; h.N = D; h.K = B; h.batch = nt;
+  h.A = Ksum; h.lda = B; h.strideA = BB;
+  h.B = Ahat; h.ldb = D; h.strideB = (int64_t)B * D;
+  h.C = dA; h.ldc = D; h.strideC = (int64_t)B * D;
+  rc = mmda_gemm(&h, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(diff_finish_kernel, dim3(nt), dim3(256), 0, s, dA, invn, B, D, stride, dx);
+  MMDA_CHECK_LAUNCH("mmda_loss_diff/finish");
+  return MMDA_OK;
+}
+
+extern "C" int mmda_loss_diff(const float* x, int64_t stride, int B, int D, float scale, float* loss, float* dx, float* work,
+                              void* stream) {
+  // the six pairs of solver.py:432-439 over [private_t, private_v, private_a, shared_t, shared_v, shared_a]
+  static const int pairs[12] = {0, 3, 1, 4, 2, 5, 2, 0, 2, 1, 0, 1};
+  return mmda_loss_diff_pairs(x, stride, 6, 6, pairs, B, D, scale, loss, dx, work, stream);
+}
+
+extern "C" int mmda_loss_cmd_pairs(const float* x, int64_t stride, int nt, int np, const int* pairs_host, int n_moments, int B, int D,
+                                   float scale, float value_scale, float* loss, float* dx, void* stream) {
+  PairList pl;
+  if (!x || B <= 0 || D <= 0 || n_moments < 1 || n_moments > 5 || !fill_pairs(pl, nt, np, pairs_host, 3)) return MMDA_EINVAL;
+  size_t lds = sizeof(float) * 30 * D;
+  if (lds > 60 * 1024) return MMDA_EINVAL;
+  hipLaunchKernelGGL(cmd_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, x, stride, B, D, scale, value_scale, loss, dx, pl,
+                     n_moments);
+  MMDA_CHECK_LAUNCH("mmda_loss_cmd");
+  return MMDA_OK;
+}
+
+extern "C" int mmda_loss_cmd(const float* x, int64_t stride, int B, int D, float scale, float* loss, float* dx, void* stream) {
+  static const int pairs[6] = {0, 1, 0, 2, 2, 1};        // (t,v), (t,a), (a,v)   solver.py:415-417, then /3
+  return mmda_loss_cmd_pairs(x, stride, 3, 3, pairs, 5, B, D, scale, 1.0f / 3.0f, loss, dx, stream);
+}
+
+extern "C" int mmda_loss_recon(const float* recon, const float* orig, int64_t stride, int B, int D, float scale, float* loss,
+                               float* drecon, float* dorig, void* stream) {
+  if (!recon || !orig || B <= 0 || D <= 0) return MMDA_EINVAL;
+  // three (B,D) tensors at +k*stride; mean over each, averaged over the three (solver.py:445-448).  All three have
+  // the same element count, so sum(d^2)/(3*B*D) over the lot is the same number: one launch when they are contiguous.
+  const int64_t n = (int64_t)B * D;
+  const int nl = (stride == n) ? 1 : 3;
+  for (int k = 0; k < nl; ++k) {
+    int64_t cnt = (nl == 1) ? 3 * n : n;
+    int blocks = (int)((cnt + 255) / 256); if (blocks > 64) blocks = 64;
+    hipLaunchKernelGGL(recon_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, recon + k * stride, orig + k * stride, cnt,
+                       1.0f / (3.0f * n), scale, loss, drecon ? drecon + k * stride : nullptr, dorig ? dorig + k * stride : nullptr);
+  }
+  MMDA_CHECK_LAUNCH("mmda_loss_recon");
+  return MMDA_OK;
+}
+
+extern "C" int mmda_loss_domain(const float* dom, int B, float scale, float* loss, float* ddom, void* stream) {
+  if (!dom || B <= 0) return MMDA_EINVAL;
+  hipLaunchKernelGGL(domain_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, dom, B, scale, loss, ddom);
+  MMDA_CHECK_LAUNCH("mmda_loss_domain");
+  return MMDA_OK;
+}

@@ -1,0 +1,417 @@
+// Bidirectional LSTM recurrence for gfx950 (reference: nn.LSTM(bidirectional=True) on packed sequences,
+// models.py:48-55 driven by extract_features models.py:163-180; PyTorch gate order i,f,g,o).
+//
+// Decomposition ("batch-parallel, time-persistent"): one workgroup owns 16 samples of one direction of one modality
+// for ALL time steps, so the serial chain never crosses a workgroup: no grid barrier, no inter-CU hand-off.  Per
+// step the workgroup computes gates(16 x 4H) = h_{t-1}(16 x H) * W_hh^T on the matrix cores:
+//   - h_{t-1} lives in LDS (bf16 or fp32), double-buffered; c_t and an fp32 copy of h_t live in registers
+//   - W_hh is streamed from L2 in pre-packed MFMA-fragment order (one contiguous 1 KiB wave-load per fragment)
+//   - a wave owns hidden tiles (16 units) and computes all four gates of its units, so the cell update is lane-local
+// The input-to-hidden products for all T are done beforehand as one time-batched GEMM (gemm.hip) into `gates`;
+// this kernel adds them, applies the nonlinearities and overwrites `gates` with the activated values (the stash
+// the backward kernel needs).  Variable lengths: sample b is updated only while t < len_b; the reverse direction
+// walks t = T-1..0 from a zero state, so it effectively starts at len_b-1 (packed-sequence semantics).
+#include "common.h"
+
+namespace {
+
+constexpr int NW = 4;          // waves per workgroup
+constexpr int MAXDESC = 4;
+
+struct LstmLaunch {
+  mmda_lstm_desc d[MAXDESC];
+  int n, B, T, nbt;            // nbt = ceil(B/16) batch tiles
+  const int32_t* lengths;
+};
+
+__device__ __forceinline__ int pad16(int h) { return (h + 15) & ~15; }
+__device__ __forceinline__ int pad32(int h) { return (h + 31) & ~31; }
+
+// ------------------------------------------------------------------------------------------------ packing
+// bf16 forward : [(ht*4+g)*KS + ks][lane][8]   k = ks*32 + 8*(lane>>4) + j, n = ht*16 + (lane&15), row = g*H+n
+// bf16 backward: [ht*KSB + ks][lane][8]        kk = ks*32 + 8*(lane>>4) + j over padded gate rows g*Hp+jj
+// f32  forward : [(ht*4+g)*KG + kg][lane][4]   k = kg*16 + 4*i + (lane>>4)
+// f32  backward: [ht*KGB + kg][lane][4]        kk = kg*16 + 4*i + (lane>>4)
+template <int MODE>
+__global__ void pack_kernel(int H, const float* __restrict__ W, void* outF, void* outB) {
+  const int Hp = pad16(H), nHT = Hp / 16;
+  const int per = (MODE == MMDA_BF16) ? 8 : 4;
+  const int kspan = (MODE == MMDA_BF16) ? 32 : 16;
+  const int KS = (MODE == MMDA_BF16) ? pad32(H) / 32 : Hp / 16;
+  const int KSB = 4 * Hp / kspan;
+  int64_t nF = (int64_t)nHT * 4 * KS * 64 * per;
+  int64_t nB = (int64_t)nHT * KSB * 64 * per;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nF + nB; i += (int64_t)gridDim.x * blockDim.x) {
+    bool bwd = i >= nF;
+    int64_t e = bwd ? i - nF : i;
+    int j = e % per;
+    int lane = (e / per) % 64;
+    int64_t frag = e / (per * 64);
+    float v = 0.f;
+    int koff = (MODE == MMDA_BF16) ? 8 * (lane >> 4) + j : 4 * j + (lane >> 4);
+    if (!bwd) {
+      int ks = frag % KS;
+      int tg = frag / KS;
+      int g = tg & 3, ht = tg >> 2;
+      int n = ht * 16 + (lane & 15), k = ks * kspan + koff;
+      if (n < H && k < H) v = W[(int64_t)(g * H + n) * H + k];
+    } else {
+      int ks = frag % KSB;
+      int ht = frag / KSB;
+      int kk = ks * kspan + koff;
+      int g = kk / Hp, jj = kk % Hp;
+      int n = ht * 16 + (lane & 15);
+      if (jj < H && n < H) v = W[(int64_t)(g * H + jj) * H + n];
+    }
+    if (MODE == MMDA_BF16) {
+      unsigned short* o = reinterpret_cast<unsigned short*>(bwd ? outB : outF);
+      if (o) o[e] = f2bf(v);
+    } else {
+      float* o = reinterpret_cast<float*>(bwd ? outB : outF);
+      if (o) o[e] = v;
+    }
+  }
+}
+
+template <int MODE> __device__ __forceinline__ float sig_(float x) { return MODE == MMDA_BF16 ? sigmoid_fast(x) : sigmoidf_(x); }
+template <int MODE> __device__ __forceinline__ float tanh_(float x) { return MODE == MMDA_BF16 ? tanh_fast(x) : tanhf_(x); }
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int MODE, int MAXT>
+__global__ __launch_bounds__(NW * 64) void lstm_fwd_kernel(LstmLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int per_mod = 2 * L.nbt;
+  const int mod = blockIdx.x / per_mod;
+  const int rem = blockIdx.x % per_mod;
+  const int dir = rem / L.nbt, bt = rem % L.nbt;
+  const mmda_lstm_desc& D = L.d[mod];
+  const int H = D.H, Hp = pad16(H), nHT = Hp / 16, Kp = pad32(H);
+  const int B = L.B, T = L.T;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  // LDS h buffers
+  const int ld = (MODE == MMDA_BF16) ? Kp + 8 : Kp + 2;
+  unsigned short* hb16 = reinterpret_cast<unsigned short*>(smem);
+  float* hb32 = reinterpret_cast<float*>(smem);
+  {
+    int total = 2 * 16 * ld;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+      if (MODE == MMDA_BF16) hb16[i] = 0; else hb32[i] = 0.f;
+    }
+  }
+  float c_reg[MAXT][4], h_reg[MAXT][4];
+  int len_r[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    int b = bt * 16 + fq * 4 + r;
+    len_r[r] = b < B ? L.lengths[b] : 0;
+  }
+#pragma unroll
+  for (int ti = 0; ti < MAXT; ++ti)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { c_reg[ti][r] = 0.f; h_reg[ti][r] = 0.f; }
+  __syncthreads();
+
+  const int KS = (MODE == MMDA_BF16) ? Kp / 32 : Hp / 16;
+  const int G4 = 4 * H;
+  int cur = 0;
+  for (int step = 0; step < T; ++step) {
+    const int t = dir ? T - 1 - step : step;
+#pragma unroll
+    for (int ti = 0; ti < MAXT; ++ti) {
+      const int ht = wave + NW * ti;
+      if (ht >= nHT) continue;
+      const int j = ht * 16 + fr;
+      // prefetch this step's input-to-hidden pre-activations (independent of h, so issued before the MFMAs)
+      float pre[4][4];
+      int64_t gbase[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int b = bt * 16 + fq * 4 + r;
+        bool act = (j < H) && (t < len_r[r]);
+        gbase[r] = (((int64_t)t * B + b) * 2 + dir) * G4 + j;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pre[g][r] = act ? D.gates[gbase[r] + g * H] : 0.f;
+      }
+      f32x4 acc[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (MODE == MMDA_BF16) {
+        const bf16x8* wp = reinterpret_cast<const bf16x8*>(D.wpack[dir]) + (int64_t)(ht * 4) * KS * 64 + lane;
+        const unsigned short* hrow = hb16 + (cur * 16 + fr) * ld + fq * 8;
+#pragma unroll 2
+        for (int ks = 0; ks < KS; ++ks) {
+          bf16x8 a = *reinterpret_cast<const bf16x8*>(hrow + ks * 32);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            bf16x8 bw = wp[(int64_t)(g * KS + ks) * 64];
+            acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bw, acc[g], 0, 0, 0);
+          }
+        }
+      } else {
+        const float4* wp = reinterpret_cast<const float4*>(D.wpack[dir]) + (int64_t)(ht * 4) * KS * 64 + lane;
+        const float* hrow = hb32 + (cur * 16 + fr) * ld + fq;
+#pragma unroll 2
+        for (int kg = 0; kg < KS; ++kg) {
+          float a0 = hrow[kg * 16 + 0], a1 = hrow[kg * 16 + 4], a2 = hrow[kg * 16 + 8], a3 = hrow[kg * 16 + 12];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float4 bw = wp[(int64_t)(g * KS + kg) * 64];
+            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bw.x, acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bw.y, acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, bw.z, acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, bw.w, acc[g], 0, 0, 0);
+          }
+        }
+      }
+      // lane-local cell update: accumulator element r is sample fq*4+r, hidden unit j
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int b = bt * 16 + fq * 4 + r;
+        bool inb = (b < B) && (j < H);
+        bool act = inb && (t < len_r[r]);
+        if (act) {
+          float gi = sig_<MODE>(acc[0][r] + pre[0][r]);
+          float gf = sig_<MODE>(acc[1][r] + pre[1][r]);
+          float gg = tanh_<MODE>(acc[2][r] + pre[2][r]);
+          float go = sig_<MODE>(acc[3][r] + pre[3][r]);
+          float cn = gf * c_reg[ti][r] + gi * gg;
+          float hn = go * tanh_<MODE>(cn);
+          c_reg[ti][r] = cn;
+          h_reg[ti][r] = hn;
+          D.gates[gbase[r]] = gi;
+          D.gates[gbase[r] + H] = gf;
+          D.gates[gbase[r] + 2 * H] = gg;
+          D.gates[gbase[r] + 3 * H] = go;
+          D.cstash[(((int64_t)t * B + b) * 2 + dir) * H + j] = cn;
+          D.hseq[((int64_t)t * B + b) * 2 * H + dir * H + j] = hn;
+        } else if (inb) {
+          D.hseq[((int64_t)t * B + b) * 2 * H + dir * H + j] = 0.f;   // pad_packed_sequence zero fill
+        }
+        int s = fq * 4 + r;
+        if (MODE == MMDA_BF16) hb16[((cur ^ 1) * 16 + s) * ld + j] = f2bf(h_reg[ti][r]);
+        else hb32[((cur ^ 1) * 16 + s) * ld + j] = h_reg[ti][r];
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  // final hidden state straight into the utterance layout [h1_fwd, h2_fwd, h1_bwd, h2_bwd] (models.py:203)
+#pragma unroll
+  for (int ti = 0; ti < MAXT; ++ti) {
+    const int ht = wave + NW * ti;
+    if (ht >= nHT) continue;
+    const int j = ht * 16 + fr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int b = bt * 16 + fq * 4 + r;
+      if (b < B && j < H) D.utt[(int64_t)b * 4 * H + (dir * 2 + D.layer) * H + j] = h_reg[ti][r];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// Walks time in the reverse of the forward order.  Per step: (1) lane-local gate gradients from dh, dc and the
+// stash, written in place over `gates` (fp32, for the weight/input gradient GEMMs) and to LDS as the MFMA A operand;
+// (2) dh_{t-1}(16 x H) = dG(16 x 4H) * W_hh on the matrix cores with W_hh streamed in the backward packing.
+template <int MODE, int MAXT>
+__global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int per_mod = 2 * L.nbt;
+  const int mod = blockIdx.x / per_mod;
+  const int rem = blockIdx.x % per_mod;
+  const int dir = rem / L.nbt, bt = rem % L.nbt;
+  const mmda_lstm_desc& D = L.d[mod];
+  const int H = D.H, Hp = pad16(H), nHT = Hp / 16;
+  const int B = L.B, T = L.T;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int KW = 4 * Hp;                                     // padded contraction length (gate rows)
+  const int ld = (MODE == MMDA_BF16) ? KW + 8 : KW + 2;
+  unsigned short* g16 = reinterpret_cast<unsigned short*>(smem);
+  float* g32 = reinterpret_cast<float*>(smem);
+  const int KSB = (MODE == MMDA_BF16) ? KW / 32 : KW / 16;
+  const int G4 = 4 * H;
+
+  float dh_rec[MAXT][4], dc[MAXT][4];
+  int len_r[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    int b = bt * 16 + fq * 4 + r;
+    len_r[r] = b < B ? L.lengths[b] : 0;
+  }
+#pragma unroll
+  for (int ti = 0; ti < MAXT; ++ti)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { dh_rec[ti][r] = 0.f; dc[ti][r] = 0.f; }
+
+  for (int step = 0; step < T; ++step) {
+    const int t = dir ? step : T - 1 - step;
+#pragma unroll
+    for (int ti = 0; ti < MAXT; ++ti) {
+      const int ht = wave + NW * ti;
+      if (ht >= nHT) continue;
+      const int j = ht * 16 + fr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int b = bt * 16 + fq * 4 + r;
+        bool inb = (b < B) && (j < H);
+        bool act = inb && (t < len_r[r]);
+        float dp[4] = {0.f, 0.f, 0.f, 0.f};
+        int64_t gb = (((int64_t)t * B + b) * 2 + dir) * G4 + j;
+        if (act) {
+          float gi = D.gates[gb], gf = D.gates[gb + H], gg = D.gates[gb + 2 * H], go = D.gates[gb + 3 * H];
+          float ct = D.cstash[(((int64_t)t * B + b) * 2 + dir) * H + j];
+          int tp = dir ? t + 1 : t - 1;
+          float cp = (tp >= 0 && tp < len_r[r]) ? D.cstash[(((int64_t)tp * B + b) * 2 + dir) * H + j] : 0.f;
+          float dh = dh_rec[ti][r];
+          if (D.d_hseq) dh += D.d_hseq[((int64_t)t * B + b) * 2 * H + dir * H + j];
+          bool fin = dir ? (t == 0) : (t == len_r[r] - 1);
+          if (fin) dh += D.utt[(int64_t)b * 4 * H + (dir * 2 + D.layer) * H + j];
+          float tc = tanh_<MODE>(ct);
+          float dct = dc[ti][r] + dh * go * (1.f - tc * tc);
+          dp[0] = dct * gg * gi * (1.f - gi);
+          dp[1] = dct * cp * gf * (1.f - gf);
+          dp[2] = dct * gi * (1.f - gg * gg);
+          dp[3] = dh * tc * go * (1.f - go);
+          dc[ti][r] = dct * gf;
+        }
+        if (inb) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) D.gates[gb + g * H] = dp[g];
+        }
+        int s = fq * 4 + r;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if (MODE == MMDA_BF16) g16[s * ld + g * Hp + j] = f2bf(dp[g]);
+          else g32[s * ld + g * Hp + j] = dp[g];
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ti = 0; ti < MAXT; ++ti) {
+      const int ht = wave + NW * ti;
+      if (ht >= nHT) continue;
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (MODE == MMDA_BF16) {
+        const bf16x8* wp = reinterpret_cast<const bf16x8*>(D.wpack[dir]) + (int64_t)ht * KSB * 64 + lane;
+        const unsigned short* arow = g16 + fr * ld + fq * 8;
+#pragma unroll 4
+        for (int ks = 0; ks < KSB; ++ks) {
+          bf16x8 a = *reinterpret_cast<const bf16x8*>(arow + ks * 32);
+          bf16x8 bw = wp[(int64_t)ks * 64];
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bw, acc, 0, 0, 0);
+        }
+      } else {
+        const float4* wp = reinterpret_cast<const float4*>(D.wpack[dir]) + (int64_t)ht * KSB * 64 + lane;
+        const float* arow = g32 + fr * ld + fq;
+#pragma unroll 2
+        for (int kg = 0; kg < KSB; ++kg) {
+          float4 bw = wp[(int64_t)kg * 64];
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[kg * 16 + 0], bw.x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[kg * 16 + 4], bw.y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[kg * 16 + 8], bw.z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[kg * 16 + 12], bw.w, acc, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dh_rec[ti][r] = acc[r];
+    }
+    __syncthreads();
+  }
+}
+
+int pick_maxt(int n, const mmda_lstm_desc* d) {
+  int mx = 0;
+  for (int i = 0; i < n; ++i) mx = d[i].H > mx ? d[i].H : mx;
+  int nht = round_up(mx, 16) / 16;
+  return ceil_div(nht, NW);
+}
+
+template <int MODE, bool BWD>
+int launch(int maxt, const LstmLaunch& L, size_t lds, hipStream_t s) {
+  dim3 grid(L.n * 2 * L.nbt), block(NW * 64);
+#define LAUNCH_T(MT)                                                                                      \
+  do {                                                                                                    \
+    auto kfn = BWD ? lstm_bwd_kernel<MODE, MT> : lstm_fwd_kernel<MODE, MT>;                               \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            (int)lds) != hipSuccess) { (void)hipGetLastError(); }                         \
+    hipLaunchKernelGGL(kfn, grid, block, lds, s, L);                                                      \
+  } while (0)
+  if (maxt <= 1) LAUNCH_T(1);
+  else if (maxt <= 2) LAUNCH_T(2);
+  else if (maxt <= 3) LAUNCH_T(3);
+  else if (maxt <= 5) LAUNCH_T(5);
+  else if (maxt <= 8) LAUNCH_T(8);
+  else return MMDA_EINVAL;
+#undef LAUNCH_T
+  return MMDA_OK;
+}
+
+int lstm_common(int mode, int n, const mmda_lstm_desc* descs, int B, int T, const int32_t* lengths, void* stream, bool bwd) {
+  if (n <= 0 || n > MAXDESC || !descs || B <= 0 || T < 0 || !lengths) return MMDA_EINVAL;
+  if (mode != MMDA_F32 && mode != MMDA_BF16) return MMDA_EINVAL;
+  if (T == 0) return MMDA_OK;
+  LstmLaunch L;
+  L.n = n; L.B = B; L.T = T; L.nbt = ceil_div(B, 16); L.lengths = lengths;
+  int maxH = 0;
+  for (int i = 0; i < n; ++i) {
+    const mmda_lstm_desc& d = descs[i];
+    if (d.H <= 0 || d.H > 512 || !d.gates || !d.cstash || !d.wpack[0] || !d.wpack[1] || !d.utt) return MMDA_EINVAL;
+    if (!bwd && !d.hseq) return MMDA_EINVAL;
+    if (d.layer != 0 && d.layer != 1) return MMDA_EINVAL;
+    L.d[i] = d;
+    maxH = d.H > maxH ? d.H : maxH;
+  }
+  for (int i = n; i < MAXDESC; ++i) L.d[i] = descs[0];
+  int Hp = round_up(maxH, 16), Kp = round_up(maxH, 32);
+  size_t lds;
+  if (!bwd) lds = (mode == MMDA_BF16) ? (size_t)2 * 16 * (Kp + 8) * 2 : (size_t)2 * 16 * (Kp + 2) * 4;
+  else lds = (mode == MMDA_BF16) ? (size_t)16 * (4 * Hp + 8) * 2 : (size_t)16 * (4 * Hp + 2) * 4;
+  if (lds > 160 * 1024) return MMDA_EINVAL;
+  int maxt = pick_maxt(n, descs);
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if (mode == MMDA_BF16) rc = bwd ? launch<MMDA_BF16, true>(maxt, L, lds, s) : launch<MMDA_BF16, false>(maxt, L, lds, s);
+  else rc = bwd ? launch<MMDA_F32, true>(maxt, L, lds, s) : launch<MMDA_F32, false>(maxt, L, lds, s);
+  if (rc != MMDA_OK) return rc;
+  MMDA_CHECK_LAUNCH(bwd ? "mmda_lstm_bwd" : "mmda_lstm_fwd");
+  return MMDA_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t mmda_lstm_packed_bytes(int mode, int H, int backward) {
+  if (H <= 0 || H > 512) return MMDA_EINVAL;
+  int Hp = round_up(H, 16), nHT = Hp / 16;
+  if (mode == MMDA_BF16) {
+    int KS = round_up(H, 32) / 32, KSB = 4 * Hp / 32;
+    return backward ? (int64_t)nHT * KSB * 64 * 8 * 2 : (int64_t)nHT * 4 * KS * 64 * 8 * 2;
+  } else if (mode == MMDA_F32) {
+    int KG = Hp / 16, KGB = 4 * Hp / 16;
+    return backward ? (int64_t)nHT * KGB * 64 * 4 * 4 : (int64_t)nHT * 4 * KG * 64 * 4 * 4;
+  }
+  return MMDA_EINVAL;
+}
+
+extern "C" int mmda_lstm_pack_whh(int mode, int H, const float* whh, void* packed_fwd, void* packed_bwd, void* stream) {
+  if (!whh || H <= 0 || H > 512 || (!packed_fwd && !packed_bwd)) return MMDA_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  int64_t total = (mmda_lstm_packed_bytes(mode, H, 0) + mmda_lstm_packed_bytes(mode, H, 1)) / (mode == MMDA_BF16 ? 2 : 4);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (mode == MMDA_BF16) hipLaunchKernelGGL(pack_kernel<MMDA_BF16>, dim3(blocks), dim3(256), 0, s, H, whh, packed_fwd, packed_bwd);
+  else if (mode == MMDA_F32) hipLaunchKernelGGL(pack_kernel<MMDA_F32>, dim3(blocks), dim3(256), 0, s, H, whh, packed_fwd, packed_bwd);
+  else return MMDA_EINVAL;
+  MMDA_CHECK_LAUNCH("mmda_lstm_pack_whh");
+  return MMDA_OK;
+}
+
+extern "C" int mmda_lstm_fwd(int mode, int n, const mmda_lstm_desc* descs, int B, int T, const int32_t* lengths, void* stream) {
+  return lstm_common(mode, n, descs, B, T, lengths, stream, false);
+}
+extern "C" int mmda_lstm_bwd(int mode, int n, const mmda_lstm_desc* descs, int B, int T, const int32_t* lengths, void* stream) {
+  return lstm_common(mode, n, descs, B, T, lengths, stream, true);
+}

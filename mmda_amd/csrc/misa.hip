@@ -1,0 +1,671 @@
+// Native runtime for one MISA training iteration (reference loop body solver.py:139-186 over models.py:163-285).
+// Host-side C++ only: lays the parameters out in one flat bucket, carves the workspace, and issues the HIP kernels of
+// gemm.hip / lstm.hip / norm.hip / attn.hip / losses.hip / optim.hip in dependency order on one stream.  No device
+// memory is owned here; no torch types; no host<->device synchronisation anywhere in a step.
+#include "common.h"
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct ParamInfo { std::string name; int64_t off; int rows, cols; };
+
+struct Rnn {           // one bidirectional LSTM layer
+  int D, H;
+  int64_t w_ih, w_hh[2], b_ih, b_hh;     // w_ih: (8H,D) = [fwd;rev]; b_*: (8H) = [fwd;rev]
+  int64_t pack_f[2], pack_b[2];          // workspace float offsets of the packed W_hh (per direction)
+};
+
+struct Mod {           // one modality: two stacked biLSTMs with a LayerNorm between, then a projection
+  int D, H;
+  Rnn rnn[2];
+  int64_t ln_w, ln_b;                    // {t,v,a}layer_norm
+  int64_t pw, pb, plw, plb;              // project_*: Linear + LayerNorm
+  // workspace
+  int64_t x, gates[2], c[2], hseq[2], normed, ln_mean, ln_rstd, utt, d_utt, d_hseq1, d_normed, d_x;
+};
+
+enum { SITE_ATTN = 1, SITE_DROP1 = 2, SITE_FFN = 3, SITE_DROP2 = 4, SITE_CLS = 5, SITE_DISC = 6 };
+constexpr int FFN = 2048, NHEAD = 2, S6 = 6;
+
+}  // namespace
+
+struct mmda_misa {
+  mmda_misa_config cfg;
+  std::vector<ParamInfo> params;
+  std::map<std::string, int> index;
+  int64_t dense = 0, flat = 0;
+  Mod mod[3];
+  // fusion parameter offsets
+  int64_t priv_w, priv_b, sh_w, sh_b, rec_w, rec_b, d1_w = -1, d1_b = -1, d2_w = -1, d2_b = -1, sp_w, sp_b;
+  int64_t head_w, head_b, embed;
+  int64_t in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w, l2_b, n1_w, n1_b, n2_w, n2_b;
+  float *P = nullptr, *G = nullptr, *M1 = nullptr, *V1 = nullptr;
+  // workspace
+  float* ws = nullptr; int64_t ws_floats = 0; int B = 0, T = 0;
+  std::map<std::string, int64_t> tens;
+  int64_t zero_begin = 0, zero_end = 0;      // activation-gradient region that is zeroed per step
+  int64_t z, pmean, prstd, orig, x6, rsum, recon, dom_z, dom_h, dom, qkv, probs, ctx, attn_out, ln1_mean, ln1_rstd, x1, f1, f2,
+      ln2_mean, ln2_rstd, hfused, logits, tcp, scores, labels, losses, diff_work;
+  int64_t d_scores, d_tcp, d_x6, d_orig, d_recon, d_dom, d_logits, d_hfused, d_x1, d_f2, d_f1, d_attn_out, d_ctx, d_qkv, d_z,
+      d_dom_h, d_dom_z;
+  // state of the last forward (dropout replay in backward)
+  int training = 0; uint64_t seed = 0;
+  // optional per-launch timing of the four recurrent kernels (bench.py roofline leg)
+  std::vector<hipEvent_t> ev;      // [step][slot][start/stop]
+  int ev_steps = 0, ev_fwd = 0, ev_bwd = 0;
+};
+
+namespace {
+
+int64_t add_param(mmda_misa* m, const std::string& name, int rows, int cols) {
+  ParamInfo p{name, m->flat, rows, cols};
+  m->index[name] = (int)m->params.size();
+  m->params.push_back(p);
+  m->flat += (int64_t)rows * (cols > 0 ? cols : 1);
+  return p.off;
+}
+
+void build_params(mmda_misa* m) {
+  const mmda_misa_config& c = m->cfg;
+  const int dims[3] = {c.d_t, c.d_v, c.d_a};
+  const char* mn[3] = {"t", "v", "a"};
+  const int hs = c.hidden;
+  for (int i = 0; i < 3; ++i) {
+    Mod& md = m->mod[i];
+    md.D = md.H = dims[i];
+    for (int l = 0; l < 2; ++l) {
+      Rnn& r = md.rnn[l];
+      r.H = md.H; r.D = l == 0 ? md.D : 2 * md.H;
+      std::string pre = std::string(mn[i]) + "rnn" + (l == 0 ? "1" : "2") + ".";
+      r.w_ih = add_param(m, pre + "weight_ih_l0", 4 * r.H, r.D);
+      add_param(m, pre + "weight_ih_l0_reverse", 4 * r.H, r.D);
+      r.w_hh[0] = add_param(m, pre + "weight_hh_l0", 4 * r.H, r.H);
+      r.w_hh[1] = add_param(m, pre + "weight_hh_l0_reverse", 4 * r.H, r.H);
+      r.b_ih = add_param(m, pre + "bias_ih_l0", 4 * r.H, 0);
+      add_param(m, pre + "bias_ih_l0_reverse", 4 * r.H, 0);
+      r.b_hh = add_param(m, pre + "bias_hh_l0", 4 * r.H, 0);
+      add_param(m, pre + "bias_hh_l0_reverse", 4 * r.H, 0);
+    }
+  }
+  for (int i = 0; i < 3; ++i) {
+    Mod& md = m->mod[i];
+    std::string p = std::string("project_") + mn[i] + ".project_" + mn[i];
+    md.pw = add_param(m, p + ".weight", hs, 4 * md.H);
+    md.pb = add_param(m, p + ".bias", hs, 0);
+    md.plw = add_param(m, p + "_layer_norm.weight", hs, 0);
+    md.plb = add_param(m, p + "_layer_norm.bias", hs, 0);
+  }
+  // batched groups: three (hs,hs) weights back to back, then their three biases (uniform strides for batched GEMMs)
+  m->priv_w = add_param(m, "private_t.private_t_1.weight", hs, hs);
+  add_param(m, "private_v.private_v_1.weight", hs, hs);
+  add_param(m, "private_a.private_a_3.weight", hs, hs);          // sic: reference models.py:95
+  m->priv_b = add_param(m, "private_t.private_t_1.bias", hs, 0);
+  add_param(m, "private_v.private_v_1.bias", hs, 0);
+  add_param(m, "private_a.private_a_3.bias", hs, 0);
+  m->sh_w = add_param(m, "shared.shared_1.weight", hs, hs);
+  m->sh_b = add_param(m, "shared.shared_1.bias", hs, 0);
+  m->rec_w = add_param(m, "recon_t.recon_t_1.weight", hs, hs);
+  add_param(m, "recon_v.recon_v_1.weight", hs, hs);
+  add_param(m, "recon_a.recon_a_1.weight", hs, hs);
+  m->rec_b = add_param(m, "recon_t.recon_t_1.bias", hs, 0);
+  add_param(m, "recon_v.recon_v_1.bias", hs, 0);
+  add_param(m, "recon_a.recon_a_1.bias", hs, 0);
+  if (!c.use_cmd_sim) {
+    m->d1_w = add_param(m, "discriminator.discriminator_layer_1.weight", hs, hs);
+    m->d1_b = add_param(m, "discriminator.discriminator_layer_1.bias", hs, 0);
+    m->d2_w = add_param(m, "discriminator.discriminator_layer_2.weight", 3, hs);
+    m->d2_b = add_param(m, "discriminator.discriminator_layer_2.bias", 3, 0);
+  }
+  m->sp_w = add_param(m, "sp_discriminator.sp_discriminator_layer_1.weight", 4, hs);
+  m->sp_b = add_param(m, "sp_discriminator.sp_discriminator_layer_1.bias", 4, 0);
+  // [confidence; classifier] adjacent -> one (6+ncls, 6hs) head GEMM
+  m->head_w = add_param(m, "confidence.confidence_layer_1.weight", 6, 6 * hs);
+  add_param(m, "classifier.classifier_layer.weight", c.ncls, 6 * hs);
+  m->head_b = add_param(m, "confidence.confidence_layer_1.bias", 6, 0);
+  add_param(m, "classifier.classifier_layer.bias", c.ncls, 0);
+  for (int i = 0; i < 3; ++i) {
+    m->mod[i].ln_w = add_param(m, std::string(mn[i]) + "layer_norm.weight", 2 * m->mod[i].H, 0);
+    m->mod[i].ln_b = add_param(m, std::string(mn[i]) + "layer_norm.bias", 2 * m->mod[i].H, 0);
+  }
+  const std::string te = "transformer_encoder.layers.0.";
+  m->in_w = add_param(m, te + "self_attn.in_proj_weight", 3 * hs, hs);
+  m->in_b = add_param(m, te + "self_attn.in_proj_bias", 3 * hs, 0);
+  m->out_w = add_param(m, te + "self_attn.out_proj.weight", hs, hs);
+  m->out_b = add_param(m, te + "self_attn.out_proj.bias", hs, 0);
+  m->l1_w = add_param(m, te + "linear1.weight", FFN, hs);
+  m->l1_b = add_param(m, te + "linear1.bias", FFN, 0);
+  m->l2_w = add_param(m, te + "linear2.weight", hs, FFN);
+  m->l2_b = add_param(m, te + "linear2.bias", hs, 0);
+  m->n1_w = add_param(m, te + "norm1.weight", hs, 0);
+  m->n1_b = add_param(m, te + "norm1.bias", hs, 0);
+  m->n2_w = add_param(m, te + "norm2.weight", hs, 0);
+  m->n2_b = add_param(m, te + "norm2.bias", hs, 0);
+  m->flat = (m->flat + 3) & ~(int64_t)3;
+  m->dense = m->flat;
+  m->embed = add_param(m, "embed.weight", c.vocab, c.d_t);
+  m->flat = (m->flat + 3) & ~(int64_t)3;
+}
+
+struct Carver {
+  int64_t cur = 0;
+  int64_t take(int64_t n) { int64_t o = cur; cur += (n + 3) & ~(int64_t)3; return o; }   // 16-B aligned
+};
+
+// lays out the workspace for (B,T); returns total floats.  With m == nullptr-like dry run when commit == false.
+int64_t layout(mmda_misa* m, int B, int T, bool commit) {
+  const mmda_misa_config& c = m->cfg;
+  const int hs = c.hidden, NC = 6 + c.ncls;
+  const int64_t R = (int64_t)T * B;
+  Carver k;
+  mmda_misa tmp_store;               // only used to keep the code path identical in dry runs
+  mmda_misa* o = commit ? m : &tmp_store;
+  if (!commit) { o->cfg = m->cfg; for (int i = 0; i < 3; ++i) o->mod[i] = m->mod[i]; }
+  for (int i = 0; i < 3; ++i) {
+    Mod& md = o->mod[i];
+    for (int l = 0; l < 2; ++l) {
+      Rnn& r = md.rnn[l];
+      for (int d = 0; d < 2; ++d) {     // sized for the larger (fp32) packing so the mode can be switched in place
+        r.pack_f[d] = k.take(mmda_lstm_packed_bytes(MMDA_F32, r.H, 0) / 4);
+        r.pack_b[d] = k.take(mmda_lstm_packed_bytes(MMDA_F32, r.H, 1) / 4);
+      }
+    }
+    md.x = (i == 0) ? k.take(R * md.D) : -1;
+    for (int l = 0; l < 2; ++l) {
+      md.gates[l] = k.take(R * 8 * md.H);
+      md.c[l] = k.take(R * 2 * md.H);
+      md.hseq[l] = k.take(R * 2 * md.H);
+    }
+    md.normed = k.take(R * 2 * md.H);
+    md.ln_mean = k.take(R);
+    md.ln_rstd = k.take(R);
+    md.utt = k.take((int64_t)B * 4 * md.H);
+    md.d_utt = k.take((int64_t)B * 4 * md.H);
+    md.d_hseq1 = k.take(R * 2 * md.H);
+    md.d_normed = k.take(R * 2 * md.H);
+    md.d_x = (i == 0) ? k.take(R * md.D) : -1;
+  }
+  const int64_t BH = (int64_t)B * hs;
+  o->z = k.take(3 * BH); o->pmean = k.take(3 * B); o->prstd = k.take(3 * B);
+  // public outputs (what the reference's solver reads off the module) are contiguous so the host can snapshot them at once
+  const int64_t pub_begin = k.cur;
+  o->orig = k.take(3 * BH); o->x6 = k.take(6 * BH); o->recon = k.take(3 * BH); o->dom = k.take((int64_t)3 * B * 3);
+  o->tcp = k.take((int64_t)B * 6); o->scores = k.take((int64_t)B * c.ncls); o->labels = k.take((int64_t)B * c.ncls);
+  const int64_t pub_end = k.cur;
+  o->rsum = k.take(3 * BH); o->dom_z = k.take(3 * BH); o->dom_h = k.take(3 * BH);
+  o->qkv = k.take(6 * BH * 3); o->probs = k.take((int64_t)B * NHEAD * S6 * S6); o->ctx = k.take(6 * BH);
+  o->attn_out = k.take(6 * BH); o->ln1_mean = k.take(6 * B); o->ln1_rstd = k.take(6 * B); o->x1 = k.take(6 * BH);
+  o->f1 = k.take((int64_t)6 * B * FFN); o->f2 = k.take(6 * BH); o->ln2_mean = k.take(6 * B); o->ln2_rstd = k.take(6 * B);
+  o->hfused = k.take(6 * BH); o->logits = k.take((int64_t)B * NC); o->losses = k.take(8);
+  o->diff_work = k.take(mmda_loss_diff_work_floats(B, hs));
+  // ---- activation gradients seeded by the losses (zeroed every step, contiguous)
+  o->zero_begin = k.cur;
+  o->d_scores = k.take((int64_t)B * c.ncls); o->d_tcp = k.take((int64_t)B * 6); o->d_x6 = k.take(6 * BH);
+  o->d_orig = k.take(3 * BH); o->d_recon = k.take(3 * BH); o->d_dom = k.take((int64_t)3 * B * 3);
+  o->zero_end = k.cur;
+  // ---- fully overwritten gradients
+  o->d_logits = k.take((int64_t)B * NC); o->d_hfused = k.take(6 * BH); o->d_x1 = k.take(6 * BH); o->d_f2 = k.take(6 * BH);
+  o->d_f1 = k.take((int64_t)6 * B * FFN); o->d_attn_out = k.take(6 * BH); o->d_ctx = k.take(6 * BH);
+  o->d_qkv = k.take(6 * BH * 3); o->d_z = k.take(3 * BH); o->d_dom_h = k.take(3 * BH); o->d_dom_z = k.take(3 * BH);
+  if (commit) {
+    std::map<std::string, int64_t>& t = m->tens;
+    t.clear();
+    t["scores"] = m->scores; t["labels"] = m->labels; t["tcp"] = m->tcp; t["logits"] = m->logits; t["hfused"] = m->hfused;
+    t["x6"] = m->x6; t["orig"] = m->orig; t["recon"] = m->recon; t["dom"] = m->dom; t["losses"] = m->losses;
+    t["utt_t"] = m->mod[0].utt; t["utt_v"] = m->mod[1].utt; t["utt_a"] = m->mod[2].utt;
+    t["d_scores"] = m->d_scores; t["d_tcp"] = m->d_tcp; t["d_x6"] = m->d_x6; t["d_orig"] = m->d_orig;
+    t["d_recon"] = m->d_recon; t["d_dom"] = m->d_dom;
+    t["pub_begin"] = pub_begin; t["pub_end"] = pub_end; t["zero_begin"] = m->zero_begin; t["zero_end"] = m->zero_end;
+    t["hseq1_t"] = m->mod[0].hseq[0]; t["hseq1_v"] = m->mod[1].hseq[0]; t["hseq1_a"] = m->mod[2].hseq[0];
+  }
+  return k.cur;
+}
+
+// ---------------------------------------------------------------------------------------------- GEMM shorthands
+struct Ctx { mmda_misa* m; void* s; int rc = 0; };
+
+void gemm(Ctx& c, int mode, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* Bp, int ldb, float* C,
+          int ldc, const float* bias = nullptr, const float* bias2 = nullptr, int acc = 0, int act = 0, int batch = 1,
+          int64_t sA = 0, int64_t sB = 0, int64_t sC = 0, int64_t sBias = 0, mmda_gemm_args* extra = nullptr) {
+  if (c.rc) return;
+  mmda_gemm_args g = {};
+  if (extra) g = *extra;
+  g.mode = mode; g.transA = tA; g.transB = tB; g.M = M; g.N = N; g.K = K; g.batch = batch;
+  g.A = A; g.lda = lda; g.strideA = sA; g.B = Bp; g.ldb = ldb; g.strideB = sB; g.C = C; g.ldc = ldc; g.strideC = sC;
+  g.bias = bias; g.bias2 = bias2; g.strideBias = sBias; g.accumulate = acc; g.act = act;
+  c.rc = mmda_gemm(&g, c.s);
+}
+// y(M,N) = x(M,K) W(N,K)^T + b
+void lin_fwd(Ctx& c, int mode, int M, int N, int K, const float* x, const float* W, const float* b, float* y, int act = 0) {
+  gemm(c, mode, 0, 1, M, N, K, x, K, W, K, y, N, b, nullptr, 0, act);
+}
+// dx(M,K) (+)= dy(M,N) W(N,K)
+void lin_dx(Ctx& c, int mode, int M, int N, int K, const float* dy, const float* W, float* dx, int acc) {
+  gemm(c, mode, 0, 0, M, K, N, dy, N, W, K, dx, K, nullptr, nullptr, acc);
+}
+// dW(N,K) += dy(M,N)^T x(M,K);  db(N) += colsum(dy)
+void lin_dw(Ctx& c, int mode, int M, int N, int K, const float* dy, const float* x, float* dW, float* db) {
+  gemm(c, mode, 1, 0, N, K, M, dy, N, x, K, dW, K, nullptr, nullptr, 1);
+  if (!c.rc && db) c.rc = mmda_colsum(dy, N, M, N, db, nullptr, c.s);
+}
+
+__global__ void total_loss_kernel(float* L, float dw, float sw, float rw, float cw, int use_conf) {
+  // L: cls, diff, sim, recon, conf, total   (solver.py:175-181)
+  float t = L[0] + dw * L[1] + sw * L[2] + rw * L[3];
+  if (use_conf) t += cw * L[4];
+  L[5] = t;
+}
+
+void ev_rec(mmda_misa* m, int step, int slot, int which, void* stream) {
+  if (m->ev.empty() || step >= m->ev_steps) return;
+  (void)hipEventRecord(m->ev[(step * 4 + slot) * 2 + which], (hipStream_t)stream);
+}
+
+#define WS(off) (m->ws + (off))
+#define PP(off) (m->P + (off))
+#define GG(off) (m->G + (off))
+
+int check_ready(const mmda_misa* m) {
+  if (!m || !m->P || !m->ws) return MMDA_EINVAL;
+  return MMDA_OK;
+}
+
+}  // namespace
+
+// =============================================================================================== lifecycle
+extern "C" int mmda_misa_create(const mmda_misa_config* cfg, mmda_misa** out) {
+  if (!cfg || !out) return MMDA_EINVAL;
+  if (cfg->vocab <= 0 || cfg->d_t <= 0 || cfg->d_v <= 0 || cfg->d_a <= 0 || cfg->hidden <= 0 || cfg->ncls <= 0) return MMDA_EINVAL;
+  if (cfg->d_t > 512 || cfg->d_v > 512 || cfg->d_a > 512 || cfg->hidden % NHEAD || cfg->hidden > 1024) return MMDA_EINVAL;
+  if (cfg->mode != MMDA_F32 && cfg->mode != MMDA_BF16) return MMDA_EINVAL;
+  mmda_misa* m = new mmda_misa();
+  m->cfg = *cfg;
+  build_params(m);
+  *out = m;
+  return MMDA_OK;
+}
+extern "C" void mmda_misa_destroy(mmda_misa* m) { delete m; }
+extern "C" int mmda_misa_num_params(const mmda_misa* m) { return m ? (int)m->params.size() : MMDA_EINVAL; }
+extern "C" int mmda_misa_param_info(const mmda_misa* m, int i, const char** name, int64_t* offset, int* rows, int* cols) {
+  if (!m || i < 0 || i >= (int)m->params.size()) return MMDA_EINVAL;
+  const ParamInfo& p = m->params[i];
+  if (name) *name = p.name.c_str();
+  if (offset) *offset = p.off;
+  if (rows) *rows = p.rows;
+  if (cols) *cols = p.cols;
+  return MMDA_OK;
+}
+extern "C" int64_t mmda_misa_flat_floats(const mmda_misa* m) { return m ? m->flat : MMDA_EINVAL; }
+extern "C" int64_t mmda_misa_dense_floats(const mmda_misa* m) { return m ? m->dense : MMDA_EINVAL; }
+extern "C" int mmda_misa_bind(mmda_misa* m, float* params, float* grads, float* adam_m, float* adam_v) {
+  if (!m || !params) return MMDA_EINVAL;
+  if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)adam_m | (uintptr_t)adam_v) & 15) return MMDA_EINVAL;
+  m->P = params; m->G = grads; m->M1 = adam_m; m->V1 = adam_v;
+  return MMDA_OK;
+}
+extern "C" int64_t mmda_misa_workspace_floats(const mmda_misa* m, int B, int T) {
+  if (!m || B <= 0 || T <= 0) return MMDA_EINVAL;
+  return layout(const_cast<mmda_misa*>(m), B, T, false);
+}
+extern "C" int mmda_misa_set_workspace(mmda_misa* m, float* ws, int64_t floats, int B, int T) {
+  if (!m || !ws || B <= 0 || T <= 0 || ((uintptr_t)ws & 15)) return MMDA_EINVAL;
+  int64_t need = layout(m, B, T, false);
+  if (floats < need) return MMDA_EINVAL;
+  layout(m, B, T, true);
+  m->ws = ws; m->ws_floats = floats; m->B = B; m->T = T;
+  return MMDA_OK;
+}
+extern "C" int64_t mmda_misa_tensor_offset(const mmda_misa* m, const char* name) {
+  if (!m || !name) return -1;
+  auto it = m->tens.find(name);
+  return it == m->tens.end() ? -1 : it->second;
+}
+extern "C" int mmda_misa_set_mode(mmda_misa* m, int mode) {
+  if (!m || (mode != MMDA_F32 && mode != MMDA_BF16)) return MMDA_EINVAL;
+  m->cfg.mode = mode;
+  return MMDA_OK;
+}
+
+// =============================================================================================== forward
+extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float* v, const float* a, const int32_t* lengths,
+                                 int training, uint64_t seed, void* stream) {
+  if (check_ready(m) || !t_ids || !v || !a || !lengths) return MMDA_EINVAL;
+  const mmda_misa_config& c = m->cfg;
+  const int B = m->B, T = m->T, hs = c.hidden, mode = c.mode, NC = 6 + c.ncls;
+  const int R = T * B;
+  Ctx x{m, stream};
+  m->training = training; m->seed = seed;
+  const float p_tf = training ? c.fusion_dropout : 0.f, p_cls = training ? c.dropout : 0.f;
+
+  // W_hh -> MFMA fragment order (weights changed since the last step)
+  for (int i = 0; i < 3 && !x.rc; ++i)
+    for (int l = 0; l < 2 && !x.rc; ++l)
+      for (int d = 0; d < 2 && !x.rc; ++d) {
+        Rnn& r = m->mod[i].rnn[l];
+        x.rc = mmda_lstm_pack_whh(mode, r.H, PP(r.w_hh[d]), WS(r.pack_f[d]), WS(r.pack_b[d]), stream);
+      }
+  if (x.rc) return x.rc;
+  // embedding rows (models.py:201)
+  x.rc = mmda_embed_gather(PP(m->embed), t_ids, R, c.d_t, WS(m->mod[0].x), stream);
+  const float* xin[3] = {WS(m->mod[0].x), v, a};
+  for (int l = 0; l < 2; ++l) {
+    mmda_lstm_desc desc[3];
+    for (int i = 0; i < 3; ++i) {
+      Mod& md = m->mod[i]; Rnn& r = md.rnn[l];
+      const float* in = l == 0 ? xin[i] : WS(md.normed);
+      // time-batched input-to-hidden GEMM for both directions: (R, D) x (8H, D)^T + b_ih + b_hh
+      gemm(x, mode, 0, 1, R, 8 * r.H, r.D, in, r.D, PP(r.w_ih), r.D, WS(md.gates[l]), 8 * r.H, PP(r.b_ih), PP(r.b_hh));
+      desc[i] = mmda_lstm_desc{};
+      desc[i].H = r.H; desc[i].gates = WS(md.gates[l]); desc[i].cstash = WS(md.c[l]); desc[i].hseq = WS(md.hseq[l]);
+      desc[i].wpack[0] = WS(r.pack_f[0]); desc[i].wpack[1] = WS(r.pack_f[1]);
+      desc[i].utt = WS(md.utt); desc[i].layer = l; desc[i].d_hseq = nullptr;
+    }
+    if (x.rc) return x.rc;
+    ev_rec(m, m->ev_fwd, l, 0, stream);
+    x.rc = mmda_lstm_fwd(mode, 3, desc, B, T, lengths, stream);
+    ev_rec(m, m->ev_fwd, l, 1, stream);
+    if (x.rc) return x.rc;
+    if (l == 0)
+      for (int i = 0; i < 3 && !x.rc; ++i) {
+        Mod& md = m->mod[i];
+        mmda_ln_args ln = {};
+        ln.rows = R; ln.n = 2 * md.H; ln.x = WS(md.hseq[0]); ln.gamma = PP(md.ln_w); ln.beta = PP(md.ln_b);
+        ln.y = WS(md.normed); ln.mean = WS(md.ln_mean); ln.rstd = WS(md.ln_rstd); ln.eps = 1e-5f;
+        x.rc = mmda_layernorm_fwd(&ln, stream);
+      }
+  }
+  if (x.rc) return x.rc;
+  // shared_private (models.py:265-279)
+  const int64_t BH = (int64_t)B * hs;
+  for (int i = 0; i < 3 && !x.rc; ++i) {
+    Mod& md = m->mod[i];
+    lin_fwd(x, mode, B, hs, 4 * md.H, WS(md.utt), PP(md.pw), PP(md.pb), WS(m->z + i * BH));
+    if (x.rc) break;
+    mmda_ln_args ln = {};
+    ln.rows = B; ln.n = hs; ln.x = WS(m->z + i * BH); ln.gamma = PP(md.plw); ln.beta = PP(md.plb); ln.y = WS(m->orig + i * BH);
+    ln.mean = WS(m->pmean + i * B); ln.rstd = WS(m->prstd + i * B); ln.act = c.act; ln.eps = 1e-5f;
+    x.rc = mmda_layernorm_fwd(&ln, stream);
+  }
+  // private (three weights, batched) and shared (one weight over the stacked 3B rows), sigmoid epilogue
+  gemm(x, mode, 0, 1, B, hs, hs, WS(m->orig), hs, PP(m->priv_w), hs, WS(m->x6), hs, PP(m->priv_b), nullptr, 0, MMDA_ACT_SIGMOID, 3,
+       BH, (int64_t)hs * hs, BH, hs);
+  gemm(x, mode, 0, 1, 3 * B, hs, hs, WS(m->orig), hs, PP(m->sh_w), hs, WS(m->x6 + 3 * BH), hs, PP(m->sh_b), nullptr, 0,
+       MMDA_ACT_SIGMOID);
+  // reconstruct (models.py:254-262)
+  if (!x.rc) x.rc = mmda_add(WS(m->x6), WS(m->x6 + 3 * BH), WS(m->rsum), 3 * BH, stream);
+  gemm(x, mode, 0, 1, B, hs, hs, WS(m->rsum), hs, PP(m->rec_w), hs, WS(m->recon), hs, PP(m->rec_b), nullptr, 0, 0, 3, BH,
+       (int64_t)hs * hs, BH, hs);
+  // adversarial discriminator behind the gradient-reversal layer (models.py:219-227); identity in forward
+  if (!c.use_cmd_sim) {
+    lin_fwd(x, mode, 3 * B, hs, hs, WS(m->x6 + 3 * BH), PP(m->d1_w), PP(m->d1_b), WS(m->dom_z));
+    if (!x.rc) x.rc = mmda_act_dropout_fwd(WS(m->dom_z), WS(m->dom_h), 3 * BH, c.act, p_cls, seed, SITE_DISC, stream);
+    lin_fwd(x, mode, 3 * B, 3, hs, WS(m->dom_h), PP(m->d2_w), PP(m->d2_b), WS(m->dom));
+  }
+  // 1-layer transformer fusion over the six tokens (models.py:243-245; torch post-norm encoder layer)
+  lin_fwd(x, mode, 6 * B, 3 * hs, hs, WS(m->x6), PP(m->in_w), PP(m->in_b), WS(m->qkv));
+  if (!x.rc) x.rc = mmda_attn_fwd(WS(m->qkv), S6, B, hs, NHEAD, WS(m->ctx), WS(m->probs), p_tf, seed, SITE_ATTN, stream);
+  lin_fwd(x, mode, 6 * B, hs, hs, WS(m->ctx), PP(m->out_w), PP(m->out_b), WS(m->attn_out));
+  if (!x.rc) {
+    mmda_ln_args ln = {};
+    ln.rows = 6 * B; ln.n = hs; ln.x = WS(m->x6); ln.res = WS(m->attn_out); ln.gamma = PP(m->n1_w); ln.beta = PP(m->n1_b);
+    ln.y = WS(m->x1); ln.mean = WS(m->ln1_mean); ln.rstd = WS(m->ln1_rstd); ln.drop_p = p_tf; ln.drop_seed = seed;
+    ln.drop_site = SITE_DROP1; ln.eps = 1e-5f;
+    x.rc = mmda_layernorm_fwd(&ln, stream);
+  }
+  {
+    mmda_gemm_args e = {};
+    e.drop_p = p_tf; e.drop_seed = seed; e.drop_site = SITE_FFN;
+    gemm(x, mode, 0, 1, 6 * B, FFN, hs, WS(m->x1), hs, PP(m->l1_w), hs, WS(m->f1), FFN, PP(m->l1_b), nullptr, 0, MMDA_ACT_RELU, 1, 0,
+         0, 0, 0, &e);
+  }
+  lin_fwd(x, mode, 6 * B, hs, FFN, WS(m->f1), PP(m->l2_w), PP(m->l2_b), WS(m->f2));
+  if (!x.rc) {
+    mmda_ln_args ln = {};
+    ln.rows = 6 * B; ln.n = hs; ln.x = WS(m->x1); ln.res = WS(m->f2); ln.gamma = PP(m->n2_w); ln.beta = PP(m->n2_b);
+    ln.y = WS(m->hfused); ln.mean = WS(m->ln2_mean); ln.rstd = WS(m->ln2_rstd); ln.drop_p = p_tf; ln.drop_seed = seed;
+    ln.drop_site = SITE_DROP2; ln.permute_S = S6; ln.permute_B = B; ln.eps = 1e-5f;   // emits h = cat(h[0..5], dim=1)
+    x.rc = mmda_layernorm_fwd(&ln, stream);
+  }
+  // heads (models.py:247-249)
+  lin_fwd(x, mode, B, NC, 6 * hs, WS(m->hfused), PP(m->head_w), PP(m->head_b), WS(m->logits));
+  if (!x.rc)
+    x.rc = mmda_heads_fwd(WS(m->logits), B, c.ncls, c.threshold, WS(m->tcp), WS(m->scores), WS(m->labels), p_cls, seed, SITE_CLS,
+                          stream);
+  if (!m->ev.empty()) m->ev_fwd++;
+  return x.rc;
+}
+
+// =============================================================================================== losses
+extern "C" int mmda_misa_zero_act_grads(mmda_misa* m, void* stream) {
+  if (check_ready(m)) return MMDA_EINVAL;
+  if (hipMemsetAsync(WS(m->zero_begin), 0, sizeof(float) * (m->zero_end - m->zero_begin), (hipStream_t)stream) != hipSuccess)
+    return MMDA_ELAUNCH;
+  return MMDA_OK;
+}
+
+extern "C" int mmda_misa_losses(mmda_misa* m, const float* emo, int with_grads, void* stream) {
+  if (check_ready(m) || !emo) return MMDA_EINVAL;
+  const mmda_misa_config& c = m->cfg;
+  const int B = m->B, hs = c.hidden;
+  const int64_t BH = (int64_t)B * hs;
+  hipStream_t s = (hipStream_t)stream;
+  int rc = MMDA_OK;
+  if (hipMemsetAsync(WS(m->losses), 0, sizeof(float) * 8, s) != hipSuccess) return MMDA_ELAUNCH;
+  if (with_grads) { rc = mmda_misa_zero_act_grads(m, stream); if (rc) return rc; }
+  float* L = WS(m->losses);
+  float* g_sc = with_grads ? WS(m->d_scores) : nullptr;
+  rc = mmda_loss_cls(WS(m->scores), emo, B, c.ncls, 1.f, L + 0, g_sc, stream);
+  if (rc) return rc;
+  rc = mmda_loss_diff(WS(m->x6), BH, B, hs, c.diff_weight, L + 1, with_grads ? WS(m->d_x6) : nullptr, WS(m->diff_work), stream);
+  if (rc) return rc;
+  if (c.use_cmd_sim) rc = mmda_loss_cmd(WS(m->x6 + 3 * BH), BH, B, hs, c.sim_weight, L + 2, with_grads ? WS(m->d_x6 + 3 * BH) : nullptr, stream);
+  else rc = mmda_loss_domain(WS(m->dom), B, c.sim_weight, L + 2, with_grads ? WS(m->d_dom) : nullptr, stream);
+  if (rc) return rc;
+  rc = mmda_loss_recon(WS(m->recon), WS(m->orig), BH, B, hs, c.recon_weight, L + 3, with_grads ? WS(m->d_recon) : nullptr,
+                       with_grads ? WS(m->d_orig) : nullptr, stream);
+  if (rc) return rc;
+  if (c.ncls == 6) {   // computed every step like solver.py:168; only seeds gradients when use_confidNet (solver.py:180-181)
+    bool cg = with_grads && c.use_confidNet;
+    rc = mmda_loss_conf(WS(m->scores), WS(m->tcp), emo, B, c.ncls, c.conf_weight, L + 4, cg ? WS(m->d_scores) : nullptr,
+                        cg ? WS(m->d_tcp) : nullptr, stream);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(1), 0, s, L, c.diff_weight, c.sim_weight, c.recon_weight, c.conf_weight,
+                     c.use_confidNet);
+  MMDA_CHECK_LAUNCH("mmda_misa_losses/total");
+  return MMDA_OK;
+}
+
+// =============================================================================================== backward
+extern "C" int mmda_misa_zero_grad(mmda_misa* m, void* stream) {
+  if (!m || !m->G) return MMDA_EINVAL;
+  if (hipMemsetAsync(m->G, 0, sizeof(float) * m->flat, (hipStream_t)stream) != hipSuccess) return MMDA_ELAUNCH;
+  return MMDA_OK;
+}
+
+extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const float* v, const float* a, const int32_t* lengths,
+                                  void* stream) {
+  if (check_ready(m) || !m->G || !t_ids || !v || !a || !lengths) return MMDA_EINVAL;
+  const mmda_misa_config& c = m->cfg;
+  const int B = m->B, T = m->T, hs = c.hidden, mode = c.mode, NC = 6 + c.ncls;
+  const int R = T * B;
+  const int64_t BH = (int64_t)B * hs;
+  Ctx x{m, stream};
+  const int training = m->training; const uint64_t seed = m->seed;
+  const float p_tf = training ? c.fusion_dropout : 0.f, p_cls = training ? c.dropout : 0.f;
+
+  // heads
+  x.rc = mmda_heads_bwd(WS(m->tcp), WS(m->scores), WS(m->d_tcp), WS(m->d_scores), B, c.ncls, WS(m->d_logits), p_cls, seed, SITE_CLS,
+                        stream);
+  lin_dx(x, mode, B, NC, 6 * hs, WS(m->d_logits), PP(m->head_w), WS(m->d_hfused), 0);
+  lin_dw(x, mode, B, NC, 6 * hs, WS(m->d_logits), WS(m->hfused), GG(m->head_w), GG(m->head_b));
+  // norm2 + FFN
+  if (!x.rc) {
+    mmda_ln_bwd_args l = {};
+    l.rows = 6 * B; l.n = hs; l.dy = WS(m->d_hfused); l.x = WS(m->x1); l.res = WS(m->f2); l.gamma = PP(m->n2_w);
+    l.mean = WS(m->ln2_mean); l.rstd = WS(m->ln2_rstd); l.d_x = WS(m->d_x1); l.d_res = WS(m->d_f2);
+    l.dgamma = GG(m->n2_w); l.dbeta = GG(m->n2_b); l.drop_p = p_tf; l.drop_seed = seed; l.drop_site = SITE_DROP2;
+    l.permute_S = S6; l.permute_B = B;
+    x.rc = mmda_layernorm_bwd(&l, stream);
+  }
+  {
+    // d f1 = (d f2 W2) * [f1 > 0] / (1-p): f1 is stored post-relu, post-dropout, so f1 > 0 <=> kept and pre-activation > 0
+    mmda_gemm_args e = {};
+    e.gate = WS(m->f1); e.ldgate = FFN; e.gate_scale = p_tf > 0.f ? 1.f / (1.f - p_tf) : 1.f;
+    gemm(x, mode, 0, 0, 6 * B, FFN, hs, WS(m->d_f2), hs, PP(m->l2_w), FFN, WS(m->d_f1), FFN, nullptr, nullptr, 0, 0, 1, 0, 0, 0, 0, &e);
+  }
+  lin_dw(x, mode, 6 * B, hs, FFN, WS(m->d_f2), WS(m->f1), GG(m->l2_w), GG(m->l2_b));
+  lin_dx(x, mode, 6 * B, FFN, hs, WS(m->d_f1), PP(m->l1_w), WS(m->d_x1), 1);
+  lin_dw(x, mode, 6 * B, FFN, hs, WS(m->d_f1), WS(m->x1), GG(m->l1_w), GG(m->l1_b));
+  // norm1 + self-attention
+  if (!x.rc) {
+    mmda_ln_bwd_args l = {};
+    l.rows = 6 * B; l.n = hs; l.dy = WS(m->d_x1); l.x = WS(m->x6); l.res = WS(m->attn_out); l.gamma = PP(m->n1_w);
+    l.mean = WS(m->ln1_mean); l.rstd = WS(m->ln1_rstd); l.d_x = WS(m->d_x6); l.accumulate_dx = 1; l.d_res = WS(m->d_attn_out);
+    l.dgamma = GG(m->n1_w); l.dbeta = GG(m->n1_b); l.drop_p = p_tf; l.drop_seed = seed; l.drop_site = SITE_DROP1;
+    x.rc = mmda_layernorm_bwd(&l, stream);
+  }
+  lin_dx(x, mode, 6 * B, hs, hs, WS(m->d_attn_out), PP(m->out_w), WS(m->d_ctx), 0);
+  lin_dw(x, mode, 6 * B, hs, hs, WS(m->d_attn_out), WS(m->ctx), GG(m->out_w), GG(m->out_b));
+  if (!x.rc) x.rc = mmda_attn_bwd(WS(m->qkv), WS(m->probs), WS(m->d_ctx), S6, B, hs, NHEAD, WS(m->d_qkv), p_tf, seed, SITE_ATTN, stream);
+  lin_dx(x, mode, 6 * B, 3 * hs, hs, WS(m->d_qkv), PP(m->in_w), WS(m->d_x6), 1);
+  lin_dw(x, mode, 6 * B, 3 * hs, hs, WS(m->d_qkv), WS(m->x6), GG(m->in_w), GG(m->in_b));
+  // adversarial branch: discriminator grads, then the REVERSED gradient into the shared codes (functions.py:17-21)
+  if (!c.use_cmd_sim) {
+    lin_dx(x, mode, 3 * B, 3, hs, WS(m->d_dom), PP(m->d2_w), WS(m->d_dom_h), 0);
+    lin_dw(x, mode, 3 * B, 3, hs, WS(m->d_dom), WS(m->dom_h), GG(m->d2_w), GG(m->d2_b));
+    if (!x.rc) x.rc = mmda_act_dropout_bwd(WS(m->d_dom_h), WS(m->dom_z), WS(m->d_dom_z), 3 * BH, c.act, p_cls, seed, SITE_DISC, stream);
+    lin_dw(x, mode, 3 * B, hs, hs, WS(m->d_dom_z), WS(m->x6 + 3 * BH), GG(m->d1_w), GG(m->d1_b));
+    mmda_gemm_args e = {};
+    e.alpha = -c.reverse_grad_weight;
+    gemm(x, mode, 0, 0, 3 * B, hs, hs, WS(m->d_dom_z), hs, PP(m->d1_w), hs, WS(m->d_x6 + 3 * BH), hs, nullptr, nullptr, 1, 0, 1, 0, 0, 0, 0, &e);
+  }
+  // reconstruct: d(private+shared) goes to both halves of d_x6
+  gemm(x, mode, 0, 0, B, hs, hs, WS(m->d_recon), hs, PP(m->rec_w), hs, WS(m->d_x6), hs, nullptr, nullptr, 1, 0, 3, BH, (int64_t)hs * hs, BH);
+  gemm(x, mode, 0, 0, B, hs, hs, WS(m->d_recon), hs, PP(m->rec_w), hs, WS(m->d_x6 + 3 * BH), hs, nullptr, nullptr, 1, 0, 3, BH,
+       (int64_t)hs * hs, BH);
+  gemm(x, mode, 1, 0, hs, hs, B, WS(m->d_recon), hs, WS(m->rsum), hs, GG(m->rec_w), hs, nullptr, nullptr, 1, 0, 3, BH, BH, (int64_t)hs * hs);
+  for (int i = 0; i < 3 && !x.rc; ++i) x.rc = mmda_colsum(WS(m->d_recon + i * BH), hs, B, hs, GG(m->rec_b + i * hs), nullptr, stream);
+  // sigmoid of private/shared
+  if (!x.rc) x.rc = mmda_sigmoid_bwd_inplace(WS(m->d_x6), WS(m->x6), 6 * BH, stream);
+  gemm(x, mode, 0, 0, B, hs, hs, WS(m->d_x6), hs, PP(m->priv_w), hs, WS(m->d_orig), hs, nullptr, nullptr, 1, 0, 3, BH, (int64_t)hs * hs, BH);
+  gemm(x, mode, 1, 0, hs, hs, B, WS(m->d_x6), hs, WS(m->orig), hs, GG(m->priv_w), hs, nullptr, nullptr, 1, 0, 3, BH, BH, (int64_t)hs * hs);
+  for (int i = 0; i < 3 && !x.rc; ++i) x.rc = mmda_colsum(WS(m->d_x6 + i * BH), hs, B, hs, GG(m->priv_b + i * hs), nullptr, stream);
+  lin_dx(x, mode, 3 * B, hs, hs, WS(m->d_x6 + 3 * BH), PP(m->sh_w), WS(m->d_orig), 1);
+  lin_dw(x, mode, 3 * B, hs, hs, WS(m->d_x6 + 3 * BH), WS(m->orig), GG(m->sh_w), GG(m->sh_b));
+  // projections
+  for (int i = 0; i < 3 && !x.rc; ++i) {
+    Mod& md = m->mod[i];
+    mmda_ln_bwd_args l = {};
+    l.rows = B; l.n = hs; l.dy = WS(m->d_orig + i * BH); l.x = WS(m->z + i * BH); l.gamma = PP(md.plw);
+    l.mean = WS(m->pmean + i * B); l.rstd = WS(m->prstd + i * B); l.d_x = WS(m->d_z + i * BH);
+    l.dgamma = GG(md.plw); l.dbeta = GG(md.plb); l.act = c.act;
+    x.rc = mmda_layernorm_bwd(&l, stream);
+    lin_dx(x, mode, B, hs, 4 * md.H, WS(m->d_z + i * BH), PP(md.pw), WS(md.d_utt), 0);
+    lin_dw(x, mode, B, hs, 4 * md.H, WS(m->d_z + i * BH), WS(md.utt), GG(md.pw), GG(md.pb));
+  }
+  if (x.rc) return x.rc;
+  // encoders, top layer first
+  const float* xin[3] = {WS(m->mod[0].x), v, a};
+  for (int l = 1; l >= 0; --l) {
+    mmda_lstm_desc desc[3];
+    for (int i = 0; i < 3; ++i) {
+      Mod& md = m->mod[i]; Rnn& r = md.rnn[l];
+      desc[i] = mmda_lstm_desc{};
+      desc[i].H = r.H; desc[i].gates = WS(md.gates[l]); desc[i].cstash = WS(md.c[l]); desc[i].hseq = WS(md.hseq[l]);
+      desc[i].wpack[0] = WS(r.pack_b[0]); desc[i].wpack[1] = WS(r.pack_b[1]);
+      desc[i].utt = WS(md.d_utt); desc[i].layer = l; desc[i].d_hseq = l == 0 ? WS(md.d_hseq1) : nullptr;
+    }
+    ev_rec(m, m->ev_bwd, l == 1 ? 2 : 3, 0, stream);
+    x.rc = mmda_lstm_bwd(mode, 3, desc, B, T, lengths, stream);
+    ev_rec(m, m->ev_bwd, l == 1 ? 2 : 3, 1, stream);
+    if (x.rc) return x.rc;
+    for (int i = 0; i < 3 && !x.rc; ++i) {
+      Mod& md = m->mod[i]; Rnn& r = md.rnn[l];
+      const int H = r.H, G8 = 8 * H;
+      const float* dG = WS(md.gates[l]);
+      const float* in = l == 0 ? xin[i] : WS(md.normed);
+      // dW_ih (both directions stacked), biases
+      gemm(x, mode, 1, 0, G8, r.D, R, dG, G8, in, r.D, GG(r.w_ih), r.D, nullptr, nullptr, 1);
+      if (!x.rc) x.rc = mmda_colsum(dG, G8, R, G8, GG(r.b_ih), GG(r.b_hh), stream);
+      // dW_hh: forward direction pairs dG[t] with h[t-1]; reverse direction pairs dG[t] with h[t+1] (zero past len)
+      if (T > 1) {
+        const float* hs_ = WS(md.hseq[l]);
+        gemm(x, mode, 1, 0, 4 * H, H, (T - 1) * B, dG + (int64_t)B * G8, G8, hs_, 2 * H, GG(r.w_hh[0]), H, nullptr, nullptr, 1);
+        gemm(x, mode, 1, 0, 4 * H, H, (T - 1) * B, dG + 4 * H, G8, hs_ + (int64_t)B * 2 * H + H, 2 * H, GG(r.w_hh[1]), H, nullptr,
+             nullptr, 1);
+      }
+      if (l == 1) {
+        // d(normed) = dG W_ih ; then the inter-layer LayerNorm backward gives d(hseq of layer 1)
+        gemm(x, mode, 0, 0, R, r.D, G8, dG, G8, PP(r.w_ih), r.D, WS(md.d_normed), r.D);
+        if (!x.rc) {
+          mmda_ln_bwd_args lb = {};
+          lb.rows = R; lb.n = 2 * H; lb.dy = WS(md.d_normed); lb.x = WS(md.hseq[0]); lb.gamma = PP(md.ln_w);
+          lb.mean = WS(md.ln_mean); lb.rstd = WS(md.ln_rstd); lb.d_x = WS(md.d_hseq1); lb.dgamma = GG(md.ln_w); lb.dbeta = GG(md.ln_b);
+          x.rc = mmda_layernorm_bwd(&lb, stream);
+        }
+      } else if (i == 0) {
+        // text: gradient w.r.t. the embedding rows, scattered densely into embed.weight.grad (sparse=False)
+        gemm(x, mode, 0, 0, R, r.D, G8, dG, G8, PP(r.w_ih), r.D, WS(md.d_x), r.D);
+        if (!x.rc) x.rc = mmda_embed_scatter_add(GG(m->embed), t_ids, R, c.d_t, WS(md.d_x), stream);
+      }
+    }
+    if (x.rc) return x.rc;
+  }
+  if (!m->ev.empty()) m->ev_bwd++;
+  return x.rc;
+}
+
+extern "C" int mmda_misa_timing_end(mmda_misa* m) {
+  if (!m) return MMDA_EINVAL;
+  for (hipEvent_t e : m->ev) (void)hipEventDestroy(e);
+  m->ev.clear(); m->ev_steps = m->ev_fwd = m->ev_bwd = 0;
+  return MMDA_OK;
+}
+extern "C" int mmda_misa_timing_begin(mmda_misa* m, int max_steps) {
+  if (!m || max_steps <= 0 || max_steps > 4096) return MMDA_EINVAL;
+  mmda_misa_timing_end(m);
+  m->ev.resize((size_t)max_steps * 8);
+  for (auto& e : m->ev)
+    if (hipEventCreate(&e) != hipSuccess) return MMDA_ELAUNCH;
+  m->ev_steps = max_steps;
+  return MMDA_OK;
+}
+extern "C" int mmda_misa_timing_collect(mmda_misa* m, float mean_ms[4], int* steps) {
+  if (!m || !mean_ms || m->ev.empty()) return MMDA_EINVAL;
+  int n = m->ev_fwd < m->ev_bwd ? m->ev_fwd : m->ev_bwd;
+  if (n > m->ev_steps) n = m->ev_steps;
+  double acc[4] = {0, 0, 0, 0};
+  for (int s = 0; s < n; ++s)
+    for (int k = 0; k < 4; ++k) {
+      float ms = 0.f;
+      if (hipEventSynchronize(m->ev[(s * 4 + k) * 2 + 1]) != hipSuccess) return MMDA_ELAUNCH;
+      if (hipEventElapsedTime(&ms, m->ev[(s * 4 + k) * 2], m->ev[(s * 4 + k) * 2 + 1]) != hipSuccess) return MMDA_ELAUNCH;
+      acc[k] += ms;
+    }
+  for (int k = 0; k < 4; ++k) mean_ms[k] = n > 0 ? (float)(acc[k] / n) : 0.f;
+  if (steps) *steps = n;
+  return MMDA_OK;
+}
+
+// =============================================================================================== optimizer / step
+extern "C" int mmda_misa_adam_step(mmda_misa* m, float lr, float clip, float grad_scale, int step, void* stream) {
+  if (!m || !m->P || !m->G || !m->M1 || !m->V1) return MMDA_EINVAL;
+  return mmda_clamp_adam(m->P, m->G, m->M1, m->V1, m->flat, lr, 0.9f, 0.999f, 1e-8f, clip, grad_scale, step, stream);
+}
+
+extern "C" int mmda_misa_train_step(mmda_misa* m, const int64_t* t_ids, const float* v, const float* a, const int32_t* lengths,
+                                    const float* emo, int training, uint64_t seed, int do_adam, float lr, float clip, int step,
+                                    void* stream) {
+  int rc = mmda_misa_zero_grad(m, stream);
+  if (rc) return rc;
+  rc = mmda_misa_forward(m, t_ids, v, a, lengths, training, seed, stream);
+  if (rc) return rc;
+  rc = mmda_misa_losses(m, emo, 1, stream);
+  if (rc) return rc;
+  rc = mmda_misa_backward(m, t_ids, v, a, lengths, stream);
+  if (rc) return rc;
+  if (do_adam) rc = mmda_misa_adam_step(m, lr, clip, 1.0f, step, stream);
+  return rc;
+}

@@ -1,0 +1,204 @@
+"""Thin per-operator wrappers over the C ABI (one function per entry point of include/mmda_hip.h).
+
+These take/return torch CUDA tensors purely as device-memory handles; all arithmetic is in libmmda_hip.so.
+Used by the parity tests (tests/test_gpu_ops.py) and available to callers who want single kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ACT, BF16, F32, check, load, ptr, stream_ptr
+
+MODE = {"fp32": F32, "bf16": BF16, F32: F32, BF16: BF16}
+
+
+def _f(t):
+    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), "expect contiguous fp32 CUDA tensors"
+    return t
+
+
+def gemm(A, B, *, mode="fp32", transA=False, transB=True, bias=None, bias2=None, out=None, accumulate=False, act="none",
+         A2=None, gather=None, alpha=1.0, drop_p=0.0, seed=0, site=0, gate=None, gate_scale=1.0):
+    """C = act(alpha * opA(A (+A2)) @ opB(B) + bias + bias2 (+C)).  A,B 2-D or 3-D (batched, uniform strides)."""
+    lib = load()
+    batched = A.dim() == 3
+    Ab = A if batched else A.unsqueeze(0)
+    Bb = B if B.dim() == 3 else B.unsqueeze(0)
+    nb = max(Ab.shape[0], Bb.shape[0])
+    if gather is not None:
+        M = gather.numel(); K = Ab.shape[2]
+    elif transA:
+        K, M = Ab.shape[1], Ab.shape[2]
+    else:
+        M, K = Ab.shape[1], Ab.shape[2]
+    N = Bb.shape[1] if transB else Bb.shape[2]
+    if out is None:
+        out = torch.zeros((nb, M, N), device=A.device, dtype=torch.float32)
+        if not batched and B.dim() == 2:
+            out = out[0]
+    Cb = out if out.dim() == 3 else out.unsqueeze(0)
+    g = _lib.GemmArgs()
+    g.mode = MODE[mode]; g.transA = int(transA); g.transB = int(transB); g.M = M; g.N = N; g.K = K; g.batch = nb
+    g.A = ptr(_f(Ab)); g.lda = Ab.shape[2]; g.strideA = Ab.stride(0) if Ab.shape[0] > 1 else 0
+    g.A2 = ptr(A2); g.gather = ptr(gather)
+    g.B = ptr(_f(Bb)); g.ldb = Bb.shape[2]; g.strideB = Bb.stride(0) if Bb.shape[0] > 1 else 0
+    g.C = ptr(_f(Cb)); g.ldc = N; g.strideC = Cb.stride(0) if Cb.shape[0] > 1 else 0
+    g.bias = ptr(bias); g.bias2 = ptr(bias2)
+    g.strideBias = (bias.stride(0) if (bias is not None and bias.dim() == 2) else 0)
+    g.accumulate = int(accumulate); g.act = ACT[act]
+    g.drop_p = drop_p; g.drop_seed = seed; g.drop_site = site
+    g.gate = ptr(gate); g.ldgate = N; g.gate_scale = gate_scale; g.alpha = alpha
+    check(lib.mmda_gemm(C.byref(g), stream_ptr()), "mmda_gemm")
+    return out
+
+
+def colsum(X, out=None, out2=None):
+    lib = load()
+    M, N = X.shape
+    if out is None:
+        out = torch.zeros(N, device=X.device)
+    check(lib.mmda_colsum(ptr(_f(X)), N, M, N, ptr(out), ptr(out2), stream_ptr()), "mmda_colsum")
+    return out
+
+
+def embed_gather(W, ids):
+    lib = load()
+    rows, dim = ids.numel(), W.shape[1]
+    out = torch.empty(tuple(ids.shape) + (dim,), device=W.device)
+    check(lib.mmda_embed_gather(ptr(_f(W)), ptr(ids.contiguous()), rows, dim, ptr(out), stream_ptr()), "embed_gather")
+    return out
+
+
+def embed_scatter_add(dW, ids, dX):
+    lib = load()
+    check(lib.mmda_embed_scatter_add(ptr(_f(dW)), ptr(ids.contiguous()), ids.numel(), dW.shape[1], ptr(_f(dX)), stream_ptr()),
+          "embed_scatter_add")
+    return dW
+
+
+def layernorm_fwd(x, gamma, beta, *, res=None, act="none", drop_p=0.0, seed=0, site=0, permute=None, eps=1e-5):
+    lib = load()
+    n = x.shape[-1]
+    rows = x.numel() // n
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, device=x.device); rstd = torch.empty(rows, device=x.device)
+    a = _lib.LnArgs()
+    a.rows = rows; a.n = n; a.x = ptr(_f(x)); a.res = ptr(res); a.gamma = ptr(gamma); a.beta = ptr(beta)
+    a.y = ptr(y); a.mean = ptr(mean); a.rstd = ptr(rstd); a.act = ACT[act]
+    a.drop_p = drop_p; a.drop_seed = seed; a.drop_site = site
+    a.permute_S, a.permute_B = permute if permute else (0, 0)
+    a.eps = eps
+    check(lib.mmda_layernorm_fwd(C.byref(a), stream_ptr()), "layernorm_fwd")
+    if permute:
+        y = y.view(permute[1], permute[0], n)
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, *, res=None, act="none", drop_p=0.0, seed=0, site=0, permute=None,
+                  want_dres=False):
+    lib = load()
+    n = x.shape[-1]
+    rows = x.numel() // n
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    dg = torch.zeros(n, device=x.device); db = torch.zeros(n, device=x.device)
+    a = _lib.LnBwdArgs()
+    a.rows = rows; a.n = n; a.dy = ptr(_f(dy)); a.x = ptr(_f(x)); a.res = ptr(res); a.gamma = ptr(gamma)
+    a.mean = ptr(mean); a.rstd = ptr(rstd); a.d_x = ptr(dx); a.accumulate_dx = 0; a.d_res = ptr(dres)
+    a.dgamma = ptr(dg); a.dbeta = ptr(db); a.act = ACT[act]
+    a.drop_p = drop_p; a.drop_seed = seed; a.drop_site = site
+    a.permute_S, a.permute_B = permute if permute else (0, 0)
+    check(lib.mmda_layernorm_bwd(C.byref(a), stream_ptr()), "layernorm_bwd")
+    return dx, dres, dg, db
+
+
+def lstm_pack(whh, mode):
+    """Returns (packed_fwd, packed_bwd) byte tensors for one direction's W_hh (4H,H)."""
+    lib = load()
+    H = whh.shape[1]
+    md = MODE[mode]
+    pf = torch.empty(lib.mmda_lstm_packed_bytes(md, H, 0), dtype=torch.uint8, device=whh.device)
+    pb = torch.empty(lib.mmda_lstm_packed_bytes(md, H, 1), dtype=torch.uint8, device=whh.device)
+    check(lib.mmda_lstm_pack_whh(md, H, ptr(_f(whh)), ptr(pf), ptr(pb), stream_ptr()), "lstm_pack")
+    return pf, pb
+
+
+def _desc(H, gates, cstash, hseq, wp0, wp1, utt, layer, d_hseq=None):
+    d = _lib.LstmDesc()
+    d.H = H; d.gates = ptr(gates); d.cstash = ptr(cstash); d.hseq = ptr(hseq)
+    d.wpack[0] = ptr(wp0); d.wpack[1] = ptr(wp1)
+    d.utt = ptr(utt); d.layer = layer; d.d_hseq = ptr(d_hseq)
+    return d
+
+
+def lstm_bidir_fwd(pre, whh_f, whh_r, lengths, *, mode="fp32", layer=0, utt=None):
+    """pre: (T,B,2,4H) = x W_ih^T + b_ih + b_hh per direction.  Returns dict(hseq, gates, cstash, utt, packs)."""
+    lib = load()
+    T, B, _, G4 = pre.shape
+    H = G4 // 4
+    gates = pre.clone().contiguous()
+    cst = torch.zeros(T, B, 2, H, device=pre.device)
+    hseq = torch.full((T, B, 2 * H), float("nan"), device=pre.device)
+    if utt is None:
+        utt = torch.zeros(B, 4 * H, device=pre.device)
+    pf0, pb0 = lstm_pack(whh_f, mode)
+    pf1, pb1 = lstm_pack(whh_r, mode)
+    len_dev = lengths.to(device=pre.device, dtype=torch.int32)
+    d = (_lib.LstmDesc * 1)(_desc(H, gates, cst, hseq, pf0, pf1, utt, layer))
+    check(lib.mmda_lstm_fwd(MODE[mode], 1, d, B, T, ptr(len_dev), stream_ptr()), "lstm_fwd")
+    return dict(hseq=hseq, gates=gates, cstash=cst, utt=utt, packs=(pf0, pb0, pf1, pb1), len_dev=len_dev)
+
+
+def lstm_bidir_bwd(fw, d_utt, d_hseq, *, mode="fp32", layer=0):
+    """Consumes the dict returned by lstm_bidir_fwd; returns dG (T,B,2,4H) (overwrites fw['gates'])."""
+    lib = load()
+    gates = fw["gates"]
+    T, B, _, G4 = gates.shape
+    H = G4 // 4
+    pf0, pb0, pf1, pb1 = fw["packs"]
+    d = (_lib.LstmDesc * 1)(_desc(H, gates, fw["cstash"], fw["hseq"], pb0, pb1, d_utt, layer, d_hseq))
+    check(lib.mmda_lstm_bwd(MODE[mode], 1, d, B, T, ptr(fw["len_dev"]), stream_ptr()), "lstm_bwd")
+    return gates
+
+
+def attn_fwd(qkv, S, B, E, nhead, drop_p=0.0, seed=0, site=0):
+    lib = load()
+    ctx = torch.empty(S * B, E, device=qkv.device)
+    probs = torch.empty(B, nhead, S, S, device=qkv.device)
+    check(lib.mmda_attn_fwd(ptr(_f(qkv)), S, B, E, nhead, ptr(ctx), ptr(probs), drop_p, seed, site, stream_ptr()), "attn_fwd")
+    return ctx, probs
+
+
+def attn_bwd(qkv, probs, dctx, S, B, E, nhead, drop_p=0.0, seed=0, site=0):
+    lib = load()
+    dqkv = torch.empty_like(qkv)
+    check(lib.mmda_attn_bwd(ptr(_f(qkv)), ptr(_f(probs)), ptr(_f(dctx)), S, B, E, nhead, ptr(dqkv), drop_p, seed, site,
+                            stream_ptr()), "attn_bwd")
+    return dqkv
+
+
+def clamp_adam(p, g, m, v, lr, step, clip=float("inf"), grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8):
+    lib = load()
+    check(lib.mmda_clamp_adam(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, betas[0], betas[1], eps, clip, grad_scale, step,
+                              stream_ptr()), "clamp_adam")
+
+
+def heads_fwd(logits, ncls, threshold=0.35, drop_p=0.0, seed=0, site=0):
+    lib = load()
+    B = logits.shape[0]
+    tcp = torch.empty(B, 6, device=logits.device); sc = torch.empty(B, ncls, device=logits.device)
+    lab = torch.empty(B, ncls, device=logits.device)
+    check(lib.mmda_heads_fwd(ptr(_f(logits)), B, ncls, threshold, ptr(tcp), ptr(sc), ptr(lab), drop_p, seed, site, stream_ptr()),
+          "heads_fwd")
+    return tcp, sc, lab
+
+
+def dropout_mask_via_act(n, p, seed, site, device):
+    """Exposes the counter-based dropout multipliers (for the statistical tests): h = dropout(identity(1))."""
+    lib = load()
+    z = torch.ones(n, device=device); h = torch.empty(n, device=device)
+    check(lib.mmda_act_dropout_fwd(ptr(z), ptr(h), n, ACT["none"], p, seed, site, stream_ptr()), "act_dropout_fwd")
+    return h

@@ -1,0 +1,2 @@
+from .convert import to_gpu, to_cpu, set_device
+from .functions import DiffLoss, CMD, ReverseLayerF, getBinaryTensor

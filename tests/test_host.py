@@ -1,0 +1,118 @@
+"""CPU: host-side logic of the drop-in surface (no kernels run): parameter table vs the reference's state_dict,
+config mirror, synthetic collate contract, accuracy metric, native workspace layout."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import misa_oracle as orc
+from mmda_amd import make_config, MISA, Model, _lib
+from mmda_amd.config import get_config, activation_name
+from mmda_amd.data import synth_batch, get_loader, PAD
+from mmda_amd.solver import Solver, get_accuracy
+
+
+@pytest.mark.parametrize("cmd", [True, False])
+def test_state_dict_keys_order_shapes_match_reference(cmd):
+    ocfg = orc.default_config(vocab_size=77, use_cmd_sim=cmd)
+    ref = orc.param_shapes(ocfg)          # pinned to the reference's state_dict by tests/golden/gen_golden.py (asserted there)
+    m = MISA(make_config(vocab_size=77, use_cmd_sim=cmd))
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    for k, v in sd.items():
+        assert tuple(v.shape) == ref[k], k
+    assert Model is MISA
+    assert sum(v.numel() for k, v in sd.items() if k != "embed.weight") == (4811676 if cmd else 4811676 + 128 * 128 + 128 + 3 * 128 + 3)
+
+
+def test_flat_layout_is_dense_disjoint_and_embedding_last():
+    m = MISA(make_config(vocab_size=50))
+    spans = sorted((off, off + int(np.prod(shape)), name) for name, (off, shape) in m._layout.items())
+    for (a0, a1, _), (b0, b1, _) in zip(spans, spans[1:]):
+        assert a1 <= b0
+    assert spans[-1][2] == "embed.weight" and spans[-1][0] >= m.dense_floats
+    assert spans[-2][1] <= m.dense_floats and m.dense_floats % 4 == 0 and m._flat_floats % 4 == 0
+    # groups that the batched GEMMs rely on are adjacent with uniform strides
+    L = m._layout
+    hs = 128
+    assert L["private_v.private_v_1.weight"][0] - L["private_t.private_t_1.weight"][0] == hs * hs
+    assert L["private_a.private_a_3.weight"][0] - L["private_v.private_v_1.weight"][0] == hs * hs
+    assert L["recon_a.recon_a_1.bias"][0] - L["recon_v.recon_v_1.bias"][0] == hs
+    assert L["trnn1.weight_ih_l0_reverse"][0] - L["trnn1.weight_ih_l0"][0] == 1200 * 300
+    assert L["classifier.classifier_layer.weight"][0] - L["confidence.confidence_layer_1.weight"][0] == 6 * 768
+
+
+def test_default_init_statistics_match_torch_modules():
+    torch.manual_seed(0)
+    m = MISA(make_config(vocab_size=200))
+    sd = m.state_dict()
+    k = 1 / np.sqrt(300)
+    w = sd["trnn1.weight_hh_l0"]
+    assert float(w.abs().max()) <= k + 1e-6 and abs(float(w.std()) - k / np.sqrt(3)) < 1e-3
+    assert torch.all(sd["tlayer_norm.weight"] == 1) and torch.all(sd["project_a.project_a_layer_norm.bias"] == 0)
+    assert torch.all(sd["transformer_encoder.layers.0.self_attn.in_proj_bias"] == 0)
+    assert abs(float(sd["embed.weight"].std()) - 1.0) < 0.02
+
+
+def test_config_mirror_defaults_and_errors(monkeypatch):
+    monkeypatch.setattr("sys.argv", ["x", "--use_confidNet", "True", "--learning_rate", "1e-5"])
+    c = get_config()
+    assert c.use_confidNet is True and c.learning_rate == 1e-5 and c.diff_weight == 0.3 and c.sim_weight == 0.7
+    assert c.recon_weight == 0.7 and c.conf_weight == 0.3 and c.clip == 1.0 and c.threshold == 0.35 and c.hidden_size == 128
+    assert c.model == "MISA" and c.activation == "leakyrelu" and c.batch_size == 64 and c.n_epoch == 40
+    assert activation_name(torch.nn.LeakyReLU) == "leakyrelu" and activation_name(torch.nn.ReLU()) == "relu"
+    with pytest.raises(NotImplementedError):
+        activation_name("prelu")
+    with pytest.raises(NotImplementedError):
+        MISA(make_config(vocab_size=10, rnncell="gru"))
+    with pytest.raises(NotImplementedError):
+        MISA(make_config(vocab_size=10, extractor="transformer"))
+
+
+def test_synthetic_collate_contract():
+    cfg = make_config(vocab_size=100)
+    t, v, a, y, emo, l, bs, bt, bm, ids = synth_batch(cfg, 9, 14, seed=3, ragged=True)
+    assert t.shape == (14, 9) and t.dtype == torch.int64 and v.shape == (14, 9, 35) and a.shape == (14, 9, 74)
+    assert l.dtype == torch.int64 and l.device.type == "cpu" and bool((l[:-1] >= l[1:]).all()) and int(l[0]) == 14
+    assert emo.shape == (9, 6) and set(emo.unique().tolist()) <= {0.0, 1.0} and bool((emo.sum(0) > 0).all())
+    for b in range(9):
+        assert bool((t[int(l[b]):, b] == PAD).all()) and float(v[int(l[b]):, b].abs().sum()) == 0.0
+    assert bs.shape == (9, 16) and len(ids) == 9
+    cfg.batch_size = 4; cfg.seq_len = 6
+    dl = get_loader(cfg, n_batches=3)
+    assert len(dl) == 3 and len(next(iter(dl))) == 10
+
+
+def test_get_accuracy_matches_reference_formula():
+    rng = np.random.default_rng(0)
+    y = (rng.random((50, 6)) > 0.6).astype(np.float32); p = (rng.random((50, 6)) > 0.5).astype(np.float32)
+    y[0] = 0; p[0] = 0
+    count = 0.0
+    for i in range(50):                   # the loop form of reference utils/eval.py:14-31
+        yt = sum(1 for j in range(6) if y[i][j] > 0 and p[i][j] > 0)
+        al = sum(1 for j in range(6) if y[i][j] > 0 or p[i][j] > 0)
+        count += yt / (al if al > 0 else 1)
+    assert get_accuracy(y, p) == round(count / 50, 4)
+
+
+def test_native_workspace_layout_monotone_and_named():
+    m = MISA(make_config(vocab_size=50))
+    lib = _lib.load()
+    n1 = lib.mmda_misa_workspace_floats(m._h, 32, 50)
+    n2 = lib.mmda_misa_workspace_floats(m._h, 64, 50)
+    n3 = lib.mmda_misa_workspace_floats(m._h, 32, 100)
+    assert 0 < n1 < n2 and n1 < n3
+    # B=32,T=50 fp32 stash: gates 8H + c 2H + hseq 2H per layer, plus LN/grad buffers: tens of MB, far below HBM
+    assert 20e6 < n1 * 4 < 400e6
+    assert lib.mmda_misa_workspace_floats(m._h, 0, 50) == -1
+    assert lib.mmda_misa_tensor_offset(m._h, b"scores") == -1      # no workspace bound yet
+
+
+def test_solver_surface_exists():
+    for name in ("build", "train", "train_epoch", "eval", "get_cls_loss", "get_domain_loss", "get_cmd_loss", "get_diff_loss",
+                 "get_recon_loss", "get_conf_loss"):
+        assert callable(getattr(Solver, name))
+    c = make_config(vocab_size=20)
+    s = Solver(c, c, c, None, None, None, is_train=True, model=None)
+    assert s.get_domain_loss() == 0.0          # python float when use_cmd_sim (solver.py:390-391)
