@@ -137,14 +137,20 @@ def main():
     # ---- CPU baseline: the oracle's stock-PyTorch port of the reference loop on this box's host cores (N=1 only)
     if world == 1 and not args.no_cpu_baseline:
         from oracle import misa_oracle as orc
-        ncores = os.cpu_count() or 1
+        # host cores this process may actually use (cgroup/affinity share, 16 on a 1-GPU box), not the machine's count:
+        # oversubscribing torch's intra-op pool makes the CPU loop orders of magnitude slower
+        try:
+            ncores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            ncores = os.cpu_count() or 1
+        ncores = max(1, min(ncores, int(os.environ.get("MMDA_CPU_THREADS", "16"))))
         torch.set_num_threads(ncores)
         ocfg = orc.default_config(vocab_size=args.vocab, use_confidNet=bool(args.confidnet))
         cb = {"t": t.cpu(), "v": v.cpu(), "a": a.cpu(), "l": lengths.cpu(), "emo": emo.cpu()}
         nsteps = args.cpu_steps
         if nsteps <= 0:
-            probe = orc.baseline_train_steps(ocfg, cb, steps=2, warmup=1) / 2
-            nsteps = int(max(3, min(60, 15.0 / max(probe, 1e-3))))
+            probe = orc.baseline_train_steps(ocfg, cb, steps=1, warmup=1)
+            nsteps = int(max(2, min(60, 15.0 / max(probe, 1e-3))))
         secs = orc.baseline_train_steps(ocfg, cb, steps=nsteps, warmup=1)
         out["cpu_baseline"] = {"value": round(args.batch * nsteps / secs, 2), "unit": "samples/s", "cores": torch.get_num_threads(),
                                "kind": "port",

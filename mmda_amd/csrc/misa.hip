@@ -333,6 +333,9 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
   if (check_ready(m) || !t_ids || !v || !a || !lengths) return MMDA_EINVAL;
   const mmda_misa_config& c = m->cfg;
   const int B = m->B, T = m->T, hs = c.hidden, mode = c.mode, NC = 6 + c.ncls;
+  // The fusion block (projections, private/shared/recon, transformer layer, heads) is 2 % of the FLOPs and feeds the
+  // batch-statistic losses: it always runs on the exact f32 MFMA path.  `mode` (bf16) covers the LSTM GEMMs + recurrences.
+  const int fmode = MMDA_F32;
   const int R = T * B;
   Ctx x{m, stream};
   m->training = training; m->seed = seed;
@@ -380,7 +383,7 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
   const int64_t BH = (int64_t)B * hs;
   for (int i = 0; i < 3 && !x.rc; ++i) {
     Mod& md = m->mod[i];
-    lin_fwd(x, mode, B, hs, 4 * md.H, WS(md.utt), PP(md.pw), PP(md.pb), WS(m->z + i * BH));
+    lin_fwd(x, fmode, B, hs, 4 * md.H, WS(md.utt), PP(md.pw), PP(md.pb), WS(m->z + i * BH));
     if (x.rc) break;
     mmda_ln_args ln = {};
     ln.rows = B; ln.n = hs; ln.x = WS(m->z + i * BH); ln.gamma = PP(md.plw); ln.beta = PP(md.plb); ln.y = WS(m->orig + i * BH);
@@ -388,24 +391,24 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
     x.rc = mmda_layernorm_fwd(&ln, stream);
   }
   // private (three weights, batched) and shared (one weight over the stacked 3B rows), sigmoid epilogue
-  gemm(x, mode, 0, 1, B, hs, hs, WS(m->orig), hs, PP(m->priv_w), hs, WS(m->x6), hs, PP(m->priv_b), nullptr, 0, MMDA_ACT_SIGMOID, 3,
+  gemm(x, fmode, 0, 1, B, hs, hs, WS(m->orig), hs, PP(m->priv_w), hs, WS(m->x6), hs, PP(m->priv_b), nullptr, 0, MMDA_ACT_SIGMOID, 3,
        BH, (int64_t)hs * hs, BH, hs);
-  gemm(x, mode, 0, 1, 3 * B, hs, hs, WS(m->orig), hs, PP(m->sh_w), hs, WS(m->x6 + 3 * BH), hs, PP(m->sh_b), nullptr, 0,
+  gemm(x, fmode, 0, 1, 3 * B, hs, hs, WS(m->orig), hs, PP(m->sh_w), hs, WS(m->x6 + 3 * BH), hs, PP(m->sh_b), nullptr, 0,
        MMDA_ACT_SIGMOID);
   // reconstruct (models.py:254-262)
   if (!x.rc) x.rc = mmda_add(WS(m->x6), WS(m->x6 + 3 * BH), WS(m->rsum), 3 * BH, stream);
-  gemm(x, mode, 0, 1, B, hs, hs, WS(m->rsum), hs, PP(m->rec_w), hs, WS(m->recon), hs, PP(m->rec_b), nullptr, 0, 0, 3, BH,
+  gemm(x, fmode, 0, 1, B, hs, hs, WS(m->rsum), hs, PP(m->rec_w), hs, WS(m->recon), hs, PP(m->rec_b), nullptr, 0, 0, 3, BH,
        (int64_t)hs * hs, BH, hs);
   // adversarial discriminator behind the gradient-reversal layer (models.py:219-227); identity in forward
   if (!c.use_cmd_sim) {
-    lin_fwd(x, mode, 3 * B, hs, hs, WS(m->x6 + 3 * BH), PP(m->d1_w), PP(m->d1_b), WS(m->dom_z));
+    lin_fwd(x, fmode, 3 * B, hs, hs, WS(m->x6 + 3 * BH), PP(m->d1_w), PP(m->d1_b), WS(m->dom_z));
     if (!x.rc) x.rc = mmda_act_dropout_fwd(WS(m->dom_z), WS(m->dom_h), 3 * BH, c.act, p_cls, seed, SITE_DISC, stream);
-    lin_fwd(x, mode, 3 * B, 3, hs, WS(m->dom_h), PP(m->d2_w), PP(m->d2_b), WS(m->dom));
+    lin_fwd(x, fmode, 3 * B, 3, hs, WS(m->dom_h), PP(m->d2_w), PP(m->d2_b), WS(m->dom));
   }
   // 1-layer transformer fusion over the six tokens (models.py:243-245; torch post-norm encoder layer)
-  lin_fwd(x, mode, 6 * B, 3 * hs, hs, WS(m->x6), PP(m->in_w), PP(m->in_b), WS(m->qkv));
+  lin_fwd(x, fmode, 6 * B, 3 * hs, hs, WS(m->x6), PP(m->in_w), PP(m->in_b), WS(m->qkv));
   if (!x.rc) x.rc = mmda_attn_fwd(WS(m->qkv), S6, B, hs, NHEAD, WS(m->ctx), WS(m->probs), p_tf, seed, SITE_ATTN, stream);
-  lin_fwd(x, mode, 6 * B, hs, hs, WS(m->ctx), PP(m->out_w), PP(m->out_b), WS(m->attn_out));
+  lin_fwd(x, fmode, 6 * B, hs, hs, WS(m->ctx), PP(m->out_w), PP(m->out_b), WS(m->attn_out));
   if (!x.rc) {
     mmda_ln_args ln = {};
     ln.rows = 6 * B; ln.n = hs; ln.x = WS(m->x6); ln.res = WS(m->attn_out); ln.gamma = PP(m->n1_w); ln.beta = PP(m->n1_b);
@@ -416,10 +419,10 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
   {
     mmda_gemm_args e = {};
     e.drop_p = p_tf; e.drop_seed = seed; e.drop_site = SITE_FFN;
-    gemm(x, mode, 0, 1, 6 * B, FFN, hs, WS(m->x1), hs, PP(m->l1_w), hs, WS(m->f1), FFN, PP(m->l1_b), nullptr, 0, MMDA_ACT_RELU, 1, 0,
+    gemm(x, fmode, 0, 1, 6 * B, FFN, hs, WS(m->x1), hs, PP(m->l1_w), hs, WS(m->f1), FFN, PP(m->l1_b), nullptr, 0, MMDA_ACT_RELU, 1, 0,
          0, 0, 0, &e);
   }
-  lin_fwd(x, mode, 6 * B, hs, FFN, WS(m->f1), PP(m->l2_w), PP(m->l2_b), WS(m->f2));
+  lin_fwd(x, fmode, 6 * B, hs, FFN, WS(m->f1), PP(m->l2_w), PP(m->l2_b), WS(m->f2));
   if (!x.rc) {
     mmda_ln_args ln = {};
     ln.rows = 6 * B; ln.n = hs; ln.x = WS(m->x1); ln.res = WS(m->f2); ln.gamma = PP(m->n2_w); ln.beta = PP(m->n2_b);
@@ -428,7 +431,7 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
     x.rc = mmda_layernorm_fwd(&ln, stream);
   }
   // heads (models.py:247-249)
-  lin_fwd(x, mode, B, NC, 6 * hs, WS(m->hfused), PP(m->head_w), PP(m->head_b), WS(m->logits));
+  lin_fwd(x, fmode, B, NC, 6 * hs, WS(m->hfused), PP(m->head_w), PP(m->head_b), WS(m->logits));
   if (!x.rc)
     x.rc = mmda_heads_fwd(WS(m->logits), B, c.ncls, c.threshold, WS(m->tcp), WS(m->scores), WS(m->labels), p_cls, seed, SITE_CLS,
                           stream);
@@ -489,6 +492,7 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
   if (check_ready(m) || !m->G || !t_ids || !v || !a || !lengths) return MMDA_EINVAL;
   const mmda_misa_config& c = m->cfg;
   const int B = m->B, T = m->T, hs = c.hidden, mode = c.mode, NC = 6 + c.ncls;
+  const int fmode = MMDA_F32;       // fusion block: exact path (see mmda_misa_forward)
   const int R = T * B;
   const int64_t BH = (int64_t)B * hs;
   Ctx x{m, stream};
@@ -498,8 +502,8 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
   // heads
   x.rc = mmda_heads_bwd(WS(m->tcp), WS(m->scores), WS(m->d_tcp), WS(m->d_scores), B, c.ncls, WS(m->d_logits), p_cls, seed, SITE_CLS,
                         stream);
-  lin_dx(x, mode, B, NC, 6 * hs, WS(m->d_logits), PP(m->head_w), WS(m->d_hfused), 0);
-  lin_dw(x, mode, B, NC, 6 * hs, WS(m->d_logits), WS(m->hfused), GG(m->head_w), GG(m->head_b));
+  lin_dx(x, fmode, B, NC, 6 * hs, WS(m->d_logits), PP(m->head_w), WS(m->d_hfused), 0);
+  lin_dw(x, fmode, B, NC, 6 * hs, WS(m->d_logits), WS(m->hfused), GG(m->head_w), GG(m->head_b));
   // norm2 + FFN
   if (!x.rc) {
     mmda_ln_bwd_args l = {};
@@ -513,11 +517,11 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
     // d f1 = (d f2 W2) * [f1 > 0] / (1-p): f1 is stored post-relu, post-dropout, so f1 > 0 <=> kept and pre-activation > 0
     mmda_gemm_args e = {};
     e.gate = WS(m->f1); e.ldgate = FFN; e.gate_scale = p_tf > 0.f ? 1.f / (1.f - p_tf) : 1.f;
-    gemm(x, mode, 0, 0, 6 * B, FFN, hs, WS(m->d_f2), hs, PP(m->l2_w), FFN, WS(m->d_f1), FFN, nullptr, nullptr, 0, 0, 1, 0, 0, 0, 0, &e);
+    gemm(x, fmode, 0, 0, 6 * B, FFN, hs, WS(m->d_f2), hs, PP(m->l2_w), FFN, WS(m->d_f1), FFN, nullptr, nullptr, 0, 0, 1, 0, 0, 0, 0, &e);
   }
-  lin_dw(x, mode, 6 * B, hs, FFN, WS(m->d_f2), WS(m->f1), GG(m->l2_w), GG(m->l2_b));
-  lin_dx(x, mode, 6 * B, FFN, hs, WS(m->d_f1), PP(m->l1_w), WS(m->d_x1), 1);
-  lin_dw(x, mode, 6 * B, FFN, hs, WS(m->d_f1), WS(m->x1), GG(m->l1_w), GG(m->l1_b));
+  lin_dw(x, fmode, 6 * B, hs, FFN, WS(m->d_f2), WS(m->f1), GG(m->l2_w), GG(m->l2_b));
+  lin_dx(x, fmode, 6 * B, FFN, hs, WS(m->d_f1), PP(m->l1_w), WS(m->d_x1), 1);
+  lin_dw(x, fmode, 6 * B, FFN, hs, WS(m->d_f1), WS(m->x1), GG(m->l1_w), GG(m->l1_b));
   // norm1 + self-attention
   if (!x.rc) {
     mmda_ln_bwd_args l = {};
@@ -526,34 +530,34 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
     l.dgamma = GG(m->n1_w); l.dbeta = GG(m->n1_b); l.drop_p = p_tf; l.drop_seed = seed; l.drop_site = SITE_DROP1;
     x.rc = mmda_layernorm_bwd(&l, stream);
   }
-  lin_dx(x, mode, 6 * B, hs, hs, WS(m->d_attn_out), PP(m->out_w), WS(m->d_ctx), 0);
-  lin_dw(x, mode, 6 * B, hs, hs, WS(m->d_attn_out), WS(m->ctx), GG(m->out_w), GG(m->out_b));
+  lin_dx(x, fmode, 6 * B, hs, hs, WS(m->d_attn_out), PP(m->out_w), WS(m->d_ctx), 0);
+  lin_dw(x, fmode, 6 * B, hs, hs, WS(m->d_attn_out), WS(m->ctx), GG(m->out_w), GG(m->out_b));
   if (!x.rc) x.rc = mmda_attn_bwd(WS(m->qkv), WS(m->probs), WS(m->d_ctx), S6, B, hs, NHEAD, WS(m->d_qkv), p_tf, seed, SITE_ATTN, stream);
-  lin_dx(x, mode, 6 * B, 3 * hs, hs, WS(m->d_qkv), PP(m->in_w), WS(m->d_x6), 1);
-  lin_dw(x, mode, 6 * B, 3 * hs, hs, WS(m->d_qkv), WS(m->x6), GG(m->in_w), GG(m->in_b));
+  lin_dx(x, fmode, 6 * B, 3 * hs, hs, WS(m->d_qkv), PP(m->in_w), WS(m->d_x6), 1);
+  lin_dw(x, fmode, 6 * B, 3 * hs, hs, WS(m->d_qkv), WS(m->x6), GG(m->in_w), GG(m->in_b));
   // adversarial branch: discriminator grads, then the REVERSED gradient into the shared codes (functions.py:17-21)
   if (!c.use_cmd_sim) {
-    lin_dx(x, mode, 3 * B, 3, hs, WS(m->d_dom), PP(m->d2_w), WS(m->d_dom_h), 0);
-    lin_dw(x, mode, 3 * B, 3, hs, WS(m->d_dom), WS(m->dom_h), GG(m->d2_w), GG(m->d2_b));
+    lin_dx(x, fmode, 3 * B, 3, hs, WS(m->d_dom), PP(m->d2_w), WS(m->d_dom_h), 0);
+    lin_dw(x, fmode, 3 * B, 3, hs, WS(m->d_dom), WS(m->dom_h), GG(m->d2_w), GG(m->d2_b));
     if (!x.rc) x.rc = mmda_act_dropout_bwd(WS(m->d_dom_h), WS(m->dom_z), WS(m->d_dom_z), 3 * BH, c.act, p_cls, seed, SITE_DISC, stream);
-    lin_dw(x, mode, 3 * B, hs, hs, WS(m->d_dom_z), WS(m->x6 + 3 * BH), GG(m->d1_w), GG(m->d1_b));
+    lin_dw(x, fmode, 3 * B, hs, hs, WS(m->d_dom_z), WS(m->x6 + 3 * BH), GG(m->d1_w), GG(m->d1_b));
     mmda_gemm_args e = {};
     e.alpha = -c.reverse_grad_weight;
-    gemm(x, mode, 0, 0, 3 * B, hs, hs, WS(m->d_dom_z), hs, PP(m->d1_w), hs, WS(m->d_x6 + 3 * BH), hs, nullptr, nullptr, 1, 0, 1, 0, 0, 0, 0, &e);
+    gemm(x, fmode, 0, 0, 3 * B, hs, hs, WS(m->d_dom_z), hs, PP(m->d1_w), hs, WS(m->d_x6 + 3 * BH), hs, nullptr, nullptr, 1, 0, 1, 0, 0, 0, 0, &e);
   }
   // reconstruct: d(private+shared) goes to both halves of d_x6
-  gemm(x, mode, 0, 0, B, hs, hs, WS(m->d_recon), hs, PP(m->rec_w), hs, WS(m->d_x6), hs, nullptr, nullptr, 1, 0, 3, BH, (int64_t)hs * hs, BH);
-  gemm(x, mode, 0, 0, B, hs, hs, WS(m->d_recon), hs, PP(m->rec_w), hs, WS(m->d_x6 + 3 * BH), hs, nullptr, nullptr, 1, 0, 3, BH,
+  gemm(x, fmode, 0, 0, B, hs, hs, WS(m->d_recon), hs, PP(m->rec_w), hs, WS(m->d_x6), hs, nullptr, nullptr, 1, 0, 3, BH, (int64_t)hs * hs, BH);
+  gemm(x, fmode, 0, 0, B, hs, hs, WS(m->d_recon), hs, PP(m->rec_w), hs, WS(m->d_x6 + 3 * BH), hs, nullptr, nullptr, 1, 0, 3, BH,
        (int64_t)hs * hs, BH);
-  gemm(x, mode, 1, 0, hs, hs, B, WS(m->d_recon), hs, WS(m->rsum), hs, GG(m->rec_w), hs, nullptr, nullptr, 1, 0, 3, BH, BH, (int64_t)hs * hs);
+  gemm(x, fmode, 1, 0, hs, hs, B, WS(m->d_recon), hs, WS(m->rsum), hs, GG(m->rec_w), hs, nullptr, nullptr, 1, 0, 3, BH, BH, (int64_t)hs * hs);
   for (int i = 0; i < 3 && !x.rc; ++i) x.rc = mmda_colsum(WS(m->d_recon + i * BH), hs, B, hs, GG(m->rec_b + i * hs), nullptr, stream);
   // sigmoid of private/shared
   if (!x.rc) x.rc = mmda_sigmoid_bwd_inplace(WS(m->d_x6), WS(m->x6), 6 * BH, stream);
-  gemm(x, mode, 0, 0, B, hs, hs, WS(m->d_x6), hs, PP(m->priv_w), hs, WS(m->d_orig), hs, nullptr, nullptr, 1, 0, 3, BH, (int64_t)hs * hs, BH);
-  gemm(x, mode, 1, 0, hs, hs, B, WS(m->d_x6), hs, WS(m->orig), hs, GG(m->priv_w), hs, nullptr, nullptr, 1, 0, 3, BH, BH, (int64_t)hs * hs);
+  gemm(x, fmode, 0, 0, B, hs, hs, WS(m->d_x6), hs, PP(m->priv_w), hs, WS(m->d_orig), hs, nullptr, nullptr, 1, 0, 3, BH, (int64_t)hs * hs, BH);
+  gemm(x, fmode, 1, 0, hs, hs, B, WS(m->d_x6), hs, WS(m->orig), hs, GG(m->priv_w), hs, nullptr, nullptr, 1, 0, 3, BH, BH, (int64_t)hs * hs);
   for (int i = 0; i < 3 && !x.rc; ++i) x.rc = mmda_colsum(WS(m->d_x6 + i * BH), hs, B, hs, GG(m->priv_b + i * hs), nullptr, stream);
-  lin_dx(x, mode, 3 * B, hs, hs, WS(m->d_x6 + 3 * BH), PP(m->sh_w), WS(m->d_orig), 1);
-  lin_dw(x, mode, 3 * B, hs, hs, WS(m->d_x6 + 3 * BH), WS(m->orig), GG(m->sh_w), GG(m->sh_b));
+  lin_dx(x, fmode, 3 * B, hs, hs, WS(m->d_x6 + 3 * BH), PP(m->sh_w), WS(m->d_orig), 1);
+  lin_dw(x, fmode, 3 * B, hs, hs, WS(m->d_x6 + 3 * BH), WS(m->orig), GG(m->sh_w), GG(m->sh_b));
   // projections
   for (int i = 0; i < 3 && !x.rc; ++i) {
     Mod& md = m->mod[i];
@@ -562,8 +566,8 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
     l.mean = WS(m->pmean + i * B); l.rstd = WS(m->prstd + i * B); l.d_x = WS(m->d_z + i * BH);
     l.dgamma = GG(md.plw); l.dbeta = GG(md.plb); l.act = c.act;
     x.rc = mmda_layernorm_bwd(&l, stream);
-    lin_dx(x, mode, B, hs, 4 * md.H, WS(m->d_z + i * BH), PP(md.pw), WS(md.d_utt), 0);
-    lin_dw(x, mode, B, hs, 4 * md.H, WS(m->d_z + i * BH), WS(md.utt), GG(md.pw), GG(md.pb));
+    lin_dx(x, fmode, B, hs, 4 * md.H, WS(m->d_z + i * BH), PP(md.pw), WS(md.d_utt), 0);
+    lin_dw(x, fmode, B, hs, 4 * md.H, WS(m->d_z + i * BH), WS(md.utt), GG(md.pw), GG(md.pb));
   }
   if (x.rc) return x.rc;
   // encoders, top layer first

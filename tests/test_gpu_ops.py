@@ -149,8 +149,9 @@ def _lstm_case(T, B, H, D, ragged, seed):
     torch.manual_seed(seed)
     rnn = torch.nn.LSTM(D, H, bidirectional=True)
     with torch.no_grad():
+        k = 2.0 / math.sqrt(H)            # twice torch's default init range (1/sqrt(H)): harsher than a fresh model
         for p in rnn.parameters():
-            p.uniform_(-0.3, 0.3)
+            p.uniform_(-k, k)
     x = torch.randn(T, B, D, requires_grad=True)
     if ragged:
         lengths = torch.sort(torch.randint(1, T + 1, (B,)), descending=True).values
@@ -230,7 +231,9 @@ def test_lstm_three_modalities_one_launch_matches_separate():
     len_dev = lengths.to(device=d, dtype=torch.int32)
     _lib.check(_lib.load().mmda_lstm_fwd(_lib.BF16, 3, arr, B, T, len_dev.data_ptr(), _lib.stream_ptr()))
     for s, k in zip(singles, keep):
-        assert torch.equal(s["hseq"], k[2]) and torch.equal(s["utt"], k[3]) and torch.equal(s["cstash"], k[1])
+        # same arithmetic, but the kernel is instantiated for a different tile count per wave, so last-bit differences in
+        # the compiler's fma contraction are allowed; an indexing error would be O(1)
+        assert relerr(k[2], s["hseq"]) < 1e-5 and relerr(k[3], s["utt"]) < 1e-5 and relerr(k[1], s["cstash"]) < 1e-5
 
 
 # ------------------------------------------------------------------------------------------------ attention
@@ -361,7 +364,8 @@ def test_dropout_rng_statistics_and_replay():
     keep = (h > 0).float().mean().item()
     assert abs(keep - (1 - p)) < 2e-3                                  # keep-rate
     assert abs(h.mean().item() - 1.0) < 5e-3                           # inverted scaling 1/(1-p)
-    assert set(np.round(torch.unique(h).cpu().numpy(), 5).tolist()) == {0.0, round(1 / (1 - p), 5)}
+    u = torch.unique(h).cpu().tolist()
+    assert len(u) == 2 and u[0] == 0.0 and abs(u[1] - 1 / (1 - p)) < 1e-5
     h2 = ops.dropout_mask_via_act(n, p, seed=123, site=3, device=dev())
     assert torch.equal(h, h2)                                          # same (seed, site, index) -> same mask (fwd/bwd replay)
     h3 = ops.dropout_mask_via_act(n, p, seed=124, site=3, device=dev())
