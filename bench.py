@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--ragged", type=int, default=0)
     ap.add_argument("--confidnet", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streaming-recurrence", action="store_true", help="bf16: stream W_hh from L2 per step instead of LDS-resident")
     ap.add_argument("--cpu-steps", type=int, default=0, help="0 = pick a count that takes ~10-30 s")
     args = ap.parse_args()
 
@@ -64,6 +65,8 @@ def main():
     solver = Solver(cfg, cfg, cfg, None, None, None, is_train=True).build()
     model = solver.model
     model.train()
+    if args.streaming_recurrence:
+        model.set_recurrence(False)
     t, v, a, y, emo, lengths, *_ = synth_batch(cfg, args.batch, args.seq_len, seed=rank, ragged=bool(args.ragged), device=dev)
     sync = solver.dp.sync if solver.dp is not None else None
 
@@ -94,6 +97,8 @@ def main():
     losses = model.read_losses()
     if not all(x == x for x in losses.values()):
         raise SystemExit(f"non-finite losses: {losses}")
+    if model.cluster_aborted():
+        raise SystemExit("a resident-weights recurrence timed out waiting for its workgroup cluster: results invalid")
 
     if rank != 0:
         if world > 1:

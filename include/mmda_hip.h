@@ -122,7 +122,13 @@ typedef struct mmda_lstm_desc {
   float* utt;          /* (B,4H)      final-h destination / its gradient source in backward */
   int layer;           /* 0 or 1: column block (dir*2+layer)*H of utt */
   const float* d_hseq; /* backward only: (T,B,2H) gradient w.r.t. hseq, or NULL */
+  void* xchg;          /* optional cluster-exchange buffer of mmda_lstm_xchg_bytes(H,B) bytes, ZEROED once by the caller when
+                          allocated.  Non-NULL (all descriptors) + MMDA_BF16 selects the LDS-resident-weights kernels; NULL
+                          selects the streaming kernels. */
+  uint32_t epoch_base; /* cluster kernels: monotonic epoch counter of descs[0] is used for the launch; the caller advances it by
+                          at least T+1 between launches that share an xchg buffer (flags are never reset) */
 } mmda_lstm_desc;
+int64_t mmda_lstm_xchg_bytes(int H, int B);
 /* up to 4 independent biLSTMs (modalities) in ONE launch; all share B, T and lengths (device int32, B entries) */
 int mmda_lstm_fwd(int mode, int n, const mmda_lstm_desc* descs, int B, int T, const int32_t* lengths, void* stream);
 /* backward: reads gates/cstash (forward stash), utt = d(utterance), d_hseq; overwrites `gates` with d(pre-activation)
@@ -228,6 +234,10 @@ int mmda_misa_set_workspace(mmda_misa* m, float* ws, int64_t floats, int B, int 
 int64_t mmda_misa_tensor_offset(const mmda_misa* m, const char* name);
 /* set the mode / loss switches after creation (bench toggles) */
 int mmda_misa_set_mode(mmda_misa* m, int mode);
+/* bf16 recurrences: 1 (default) = W_hh resident in LDS across a cluster of workgroups, 0 = streamed from L2 every step */
+int mmda_misa_set_recurrence(mmda_misa* m, int resident_weights);
+/* *aborted_host = 1 if a cluster exchange ever timed out (results after that are invalid); synchronous D2H, off the step path */
+int mmda_misa_cluster_status(const mmda_misa* m, int* aborted_host);
 
 /* models.py:282-285 forward.  t_ids (T,B) int64, v (T,B,d_v), a (T,B,d_a) device; lengths (B) int32 device.
  * training != 0 enables dropout with the given seed.  Packs W_hh first (weights may have changed). */

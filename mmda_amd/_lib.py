@@ -50,7 +50,8 @@ class LnBwdArgs(C.Structure):
 
 class LstmDesc(C.Structure):
     _fields_ = [("H", C.c_int), ("gates", C.c_void_p), ("cstash", C.c_void_p), ("hseq", C.c_void_p),
-                ("wpack", C.c_void_p * 2), ("utt", C.c_void_p), ("layer", C.c_int), ("d_hseq", C.c_void_p)]
+                ("wpack", C.c_void_p * 2), ("utt", C.c_void_p), ("layer", C.c_int), ("d_hseq", C.c_void_p),
+                ("xchg", C.c_void_p), ("epoch_base", C.c_uint32)]
 
 
 class MisaConfig(C.Structure):
@@ -74,6 +75,7 @@ SIGNATURES = {
     "mmda_layernorm_fwd": (_I, [C.POINTER(LnArgs), _P]),
     "mmda_layernorm_bwd": (_I, [C.POINTER(LnBwdArgs), _P]),
     "mmda_lstm_packed_bytes": (_I64, [_I, _I, _I]),
+    "mmda_lstm_xchg_bytes": (_I64, [_I, _I]),
     "mmda_lstm_pack_whh": (_I, [_I, _I, _P, _P, _P, _P]),
     "mmda_lstm_fwd": (_I, [_I, _I, C.POINTER(LstmDesc), _I, _I, _P, _P]),
     "mmda_lstm_bwd": (_I, [_I, _I, C.POINTER(LstmDesc), _I, _I, _P, _P]),
@@ -107,6 +109,8 @@ SIGNATURES = {
     "mmda_misa_set_workspace": (_I, [_P, _P, _I64, _I, _I]),
     "mmda_misa_tensor_offset": (_I64, [_P, C.c_char_p]),
     "mmda_misa_set_mode": (_I, [_P, _I]),
+    "mmda_misa_set_recurrence": (_I, [_P, _I]),
+    "mmda_misa_cluster_status": (_I, [_P, C.POINTER(_I)]),
     "mmda_misa_forward": (_I, [_P, _P, _P, _P, _P, _I, _U64, _P]),
     "mmda_misa_losses": (_I, [_P, _P, _I, _P]),
     "mmda_misa_backward": (_I, [_P, _P, _P, _P, _P, _P]),

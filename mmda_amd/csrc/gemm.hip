@@ -12,7 +12,7 @@ constexpr int LDS_F32_LD = 34;   // floats per LDS row: (2*row + k) % 32 distinc
 constexpr int LDS_BF16_LD = 40;  // shorts per LDS row (80 B, 16-B aligned rows for ds_read_b128)
 
 template <int MODE>
-__global__ __launch_bounds__(256) void gemm_kernel(mmda_gemm_args g) {
+__global__ __launch_bounds__(256) void gemm_kernel(mmda_gemm_args g, int splitk) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BM * LDS_F32_LD * 4];
   float* As_f = reinterpret_cast<float*>(smem);
   float* Bs_f = As_f + BM * LDS_F32_LD;
@@ -22,7 +22,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(mmda_gemm_args g) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w >> 1, wn = w & 1;
   const int row0 = blockIdx.y * BM, col0 = blockIdx.x * BN;
-  const int64_t bz = blockIdx.z;
+  const int64_t bz = blockIdx.z / splitk;
+  const int sp = blockIdx.z % splitk;
   const float* A = g.A + bz * g.strideA;
   const float* A2 = g.A2 ? g.A2 + bz * g.strideA : nullptr;
   const float* Bm = g.B + bz * g.strideB;
@@ -81,9 +82,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(mmda_gemm_args g) {
     }
   };
 
-  const int nk = (K + BK - 1) / BK;
-  load_tile(0);
-  for (int kt = 0; kt < nk; ++kt) {
+  // split-K: this block reduces k-tiles [kt0, kt1); partial results are combined with float atomics in the epilogue
+  const int nk_all = (K + BK - 1) / BK;
+  const int per = (nk_all + splitk - 1) / splitk;
+  const int kt0 = sp * per;
+  const int nk = min(nk_all, kt0 + per);
+  if (splitk > 1 && kt0 >= nk) return;
+  load_tile(kt0 * BK);
+  for (int kt = kt0; kt < nk; ++kt) {
     __syncthreads();            // previous tile's fragment reads are done
     store_tile();
     __syncthreads();
@@ -136,8 +142,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(mmda_gemm_args g) {
       for (int r = 0; r < 4; ++r) {
         int m = row0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r;
         if (m >= M) continue;
-        float v = alpha * acc[i][j][r] + bsum;
         int64_t ci = (int64_t)m * g.ldc + n;
+        if (splitk > 1) {          // host guarantees: no act/dropout/gate, C zeroed or accumulating
+          atomicAdd(&C[ci], alpha * acc[i][j][r] + (sp == 0 ? bsum : 0.f));
+          continue;
+        }
+        float v = alpha * acc[i][j][r] + bsum;
         if (g.accumulate) v += C[ci];
         v = act_fwd(g.act, v);
         if (g.drop_p > 0.f) v *= drop_mul(g.drop_p, g.drop_seed, g.drop_site, ((uint64_t)bz * M + m) * N + n);
@@ -171,11 +181,30 @@ extern "C" int mmda_gemm(const mmda_gemm_args* a, void* stream) {
   if (a->M < 0 || a->N < 0 || a->batch < 0 || a->K < 0 || (a->gather && a->transA)) return MMDA_EINVAL;
   if (a->M == 0 || a->N == 0 || a->batch == 0) return MMDA_OK;
   if (a->mode != MMDA_F32 && a->mode != MMDA_BF16) return MMDA_EINVAL;
-  dim3 grid(ceil_div(a->N, BN), ceil_div(a->M, BM), a->batch);
-  if (grid.y > 65535 || grid.z > 65535) return MMDA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  if (a->mode == MMDA_BF16) hipLaunchKernelGGL(gemm_kernel<MMDA_BF16>, grid, dim3(256), 0, s, *a);
-  else hipLaunchKernelGGL(gemm_kernel<MMDA_F32>, grid, dim3(256), 0, s, *a);
+  // Split-K: these GEMMs are small (B=32: a few dozen output tiles) with long reductions (K = T*B for weight gradients,
+  // 2048 for the FFN, 4H for the projections); one block per tile would leave 250 CUs idle behind a serial k-loop.
+  const int tiles = ceil_div(a->N, BN) * ceil_div(a->M, BM) * a->batch;
+  const int nk = ceil_div(a->K, BK);
+  int splitk = 1;
+  const bool plain_epilogue = a->act == MMDA_ACT_NONE && a->drop_p <= 0.f && !a->gate;
+  if (plain_epilogue && nk >= 8 && tiles <= 256) {
+    splitk = (768 + tiles - 1) / tiles;
+    int max_split = nk / 2;                       // >= 2 k-tiles (64 deep) per block
+    if (splitk > max_split) splitk = max_split;
+    if (splitk > 64) splitk = 64;
+    if (splitk < 1) splitk = 1;
+  }
+  if (splitk > 1 && !a->accumulate) {
+    // the atomics need a zeroed destination; only done for plain contiguous outputs, otherwise no split
+    bool contiguous = (a->ldc == a->N) && (a->batch == 1 || a->strideC == (int64_t)a->M * a->N);
+    if (!contiguous) splitk = 1;
+    else if (hipMemsetAsync(a->C, 0, sizeof(float) * (size_t)a->M * a->N * a->batch, s) != hipSuccess) return MMDA_ELAUNCH;
+  }
+  dim3 grid(ceil_div(a->N, BN), ceil_div(a->M, BM), a->batch * splitk);
+  if (grid.y > 65535 || grid.z > 65535) return MMDA_EINVAL;
+  if (a->mode == MMDA_BF16) hipLaunchKernelGGL(gemm_kernel<MMDA_BF16>, grid, dim3(256), 0, s, *a, splitk);
+  else hipLaunchKernelGGL(gemm_kernel<MMDA_F32>, grid, dim3(256), 0, s, *a, splitk);
   MMDA_CHECK_LAUNCH("mmda_gemm");
   return MMDA_OK;
 }

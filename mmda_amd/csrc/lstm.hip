@@ -323,6 +323,11 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmLaunch L) {
   }
 }
 
+}  // namespace
+int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, const int32_t* lengths, void* stream, bool bwd,
+                             int* used);   // lstm_cluster.hip
+namespace {
+
 int pick_maxt(int n, const mmda_lstm_desc* d) {
   int mx = 0;
   for (int i = 0; i < n; ++i) mx = d[i].H > mx ? d[i].H : mx;
@@ -366,6 +371,12 @@ int lstm_common(int mode, int n, const mmda_lstm_desc* descs, int B, int T, cons
     maxH = d.H > maxH ? d.H : maxH;
   }
   for (int i = n; i < MAXDESC; ++i) L.d[i] = descs[0];
+  if (mode == MMDA_BF16) {      // weights resident on chip when every descriptor brought an exchange buffer
+    int used = 0;
+    int rc = mmda_lstm_cluster_launch(n, descs, B, T, lengths, stream, bwd, &used);
+    if (rc != MMDA_OK) return rc;
+    if (used) return MMDA_OK;
+  }
   int Hp = round_up(maxH, 16), Kp = round_up(maxH, 32);
   size_t lds;
   if (!bwd) lds = (mode == MMDA_BF16) ? (size_t)2 * 16 * (Kp + 8) * 2 : (size_t)2 * 16 * (Kp + 2) * 4;

@@ -23,7 +23,7 @@ struct Mod {           // one modality: two stacked biLSTMs with a LayerNorm bet
   int64_t ln_w, ln_b;                    // {t,v,a}layer_norm
   int64_t pw, pb, plw, plb;              // project_*: Linear + LayerNorm
   // workspace
-  int64_t x, gates[2], c[2], hseq[2], normed, ln_mean, ln_rstd, utt, d_utt, d_hseq1, d_normed, d_x;
+  int64_t x, gates[2], c[2], hseq[2], normed, ln_mean, ln_rstd, utt, d_utt, d_hseq1, d_normed, d_x, xchg, xchg_floats;
 };
 
 enum { SITE_ATTN = 1, SITE_DROP1 = 2, SITE_FFN = 3, SITE_DROP2 = 4, SITE_CLS = 5, SITE_DISC = 6 };
@@ -53,6 +53,8 @@ struct mmda_misa {
   // state of the last forward (dropout replay in backward)
   int training = 0; uint64_t seed = 0;
   // optional per-launch timing of the four recurrent kernels (bench.py roofline leg)
+  unsigned epoch = 1;              // monotonic cluster-exchange epoch (never reset; see lstm_cluster.hip)
+  int use_cluster = 1;
   std::vector<hipEvent_t> ev;      // [step][slot][start/stop]
   int ev_steps = 0, ev_fwd = 0, ev_bwd = 0;
 };
@@ -171,6 +173,8 @@ int64_t layout(mmda_misa* m, int B, int T, bool commit) {
         r.pack_b[d] = k.take(mmda_lstm_packed_bytes(MMDA_F32, r.H, 1) / 4);
       }
     }
+    md.xchg_floats = (mmda_lstm_xchg_bytes(md.H, B) + 3) / 4;
+    md.xchg = md.xchg_floats > 0 ? k.take(md.xchg_floats) : -1;
     md.x = (i == 0) ? k.take(R * md.D) : -1;
     for (int l = 0; l < 2; ++l) {
       md.gates[l] = k.take(R * 8 * md.H);
@@ -314,6 +318,9 @@ extern "C" int mmda_misa_set_workspace(mmda_misa* m, float* ws, int64_t floats, 
   if (floats < need) return MMDA_EINVAL;
   layout(m, B, T, true);
   m->ws = ws; m->ws_floats = floats; m->B = B; m->T = T;
+  // cluster-exchange flags must start at zero (setup time, not on the step path)
+  for (int i = 0; i < 3; ++i)
+    if (m->mod[i].xchg >= 0 && hipMemset(ws + m->mod[i].xchg, 0, sizeof(float) * m->mod[i].xchg_floats) != hipSuccess) return MMDA_ELAUNCH;
   return MMDA_OK;
 }
 extern "C" int64_t mmda_misa_tensor_offset(const mmda_misa* m, const char* name) {
@@ -324,6 +331,23 @@ extern "C" int64_t mmda_misa_tensor_offset(const mmda_misa* m, const char* name)
 extern "C" int mmda_misa_set_mode(mmda_misa* m, int mode) {
   if (!m || (mode != MMDA_F32 && mode != MMDA_BF16)) return MMDA_EINVAL;
   m->cfg.mode = mode;
+  return MMDA_OK;
+}
+extern "C" int mmda_misa_set_recurrence(mmda_misa* m, int resident_weights) {
+  if (!m) return MMDA_EINVAL;
+  m->use_cluster = resident_weights ? 1 : 0;
+  return MMDA_OK;
+}
+extern "C" int mmda_misa_cluster_status(const mmda_misa* m, int* aborted_host) {
+  // reads the sticky abort words of the three exchange buffers (device->host copy: call it off the step path)
+  if (!m || !m->ws || !aborted_host) return MMDA_EINVAL;
+  *aborted_host = 0;
+  for (int i = 0; i < 3; ++i) {
+    if (m->mod[i].xchg < 0) continue;
+    unsigned w = 0;
+    if (hipMemcpy(&w, m->ws + m->mod[i].xchg, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) return MMDA_ELAUNCH;
+    if (w) *aborted_host = 1;
+  }
   return MMDA_OK;
 }
 
@@ -363,7 +387,9 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
       desc[i].H = r.H; desc[i].gates = WS(md.gates[l]); desc[i].cstash = WS(md.c[l]); desc[i].hseq = WS(md.hseq[l]);
       desc[i].wpack[0] = WS(r.pack_f[0]); desc[i].wpack[1] = WS(r.pack_f[1]);
       desc[i].utt = WS(md.utt); desc[i].layer = l; desc[i].d_hseq = nullptr;
+      desc[i].xchg = (m->use_cluster && md.xchg >= 0) ? (void*)WS(md.xchg) : nullptr; desc[i].epoch_base = m->epoch;
     }
+    m->epoch += (unsigned)T + 2u;
     if (x.rc) return x.rc;
     ev_rec(m, m->ev_fwd, l, 0, stream);
     x.rc = mmda_lstm_fwd(mode, 3, desc, B, T, lengths, stream);
@@ -580,7 +606,9 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
       desc[i].H = r.H; desc[i].gates = WS(md.gates[l]); desc[i].cstash = WS(md.c[l]); desc[i].hseq = WS(md.hseq[l]);
       desc[i].wpack[0] = WS(r.pack_b[0]); desc[i].wpack[1] = WS(r.pack_b[1]);
       desc[i].utt = WS(md.d_utt); desc[i].layer = l; desc[i].d_hseq = l == 0 ? WS(md.d_hseq1) : nullptr;
+      desc[i].xchg = (m->use_cluster && md.xchg >= 0) ? (void*)WS(md.xchg) : nullptr; desc[i].epoch_base = m->epoch;
     }
+    m->epoch += (unsigned)T + 2u;
     ev_rec(m, m->ev_bwd, l == 1 ? 2 : 3, 0, stream);
     x.rc = mmda_lstm_bwd(mode, 3, desc, B, T, lengths, stream);
     ev_rec(m, m->ev_bwd, l == 1 ? 2 : 3, 1, stream);

@@ -169,9 +169,9 @@ extern "C" int mmda_layernorm_bwd(const mmda_ln_bwd_args* a, void* stream) {
   if (!a || !a->dy || !a->x || !a->gamma || !a->mean || !a->rstd || a->rows < 0 || a->n <= 0 || a->n > LN_MAXQ * 64) return MMDA_EINVAL;
   if (a->permute_S > 0 && (a->permute_B <= 0 || a->permute_S * a->permute_B != a->rows)) return MMDA_EINVAL;
   if (a->rows == 0) return MMDA_OK;
-  int blocks = ceil_div(a->rows, 4 * 8);          // >= 8 rows per wave so the column atomics amortise
+  int blocks = ceil_div(a->rows, 4 * 2);          // 2 rows per wave: enough blocks to fill the chip at rows ~ T*B = 1600
   if (blocks < 1) blocks = 1;
-  if (blocks > 512) blocks = 512;
+  if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *a);
   MMDA_CHECK_LAUNCH("mmda_layernorm_bwd");
   return MMDA_OK;

@@ -378,6 +378,20 @@ class MISA(nn.Module):
     def dense_floats(self) -> int:
         return self._dense_floats
 
+    def cluster_aborted(self) -> bool:
+        """True if a resident-weights recurrence ever timed out waiting for its cluster (results are invalid after that).
+        Synchronous device->host read: call it off the step path."""
+        import ctypes
+        if self._ws is None:
+            return False
+        flag = ctypes.c_int(0)
+        _lib.check(self._lib.mmda_misa_cluster_status(self._h, ctypes.byref(flag)), "cluster_status")
+        return bool(flag.value)
+
+    def set_recurrence(self, resident_weights: bool):
+        """bf16 recurrences: W_hh resident in LDS across a workgroup cluster (default) or streamed from L2 per step."""
+        _lib.check(self._lib.mmda_misa_set_recurrence(self._h, int(resident_weights)), "set_recurrence")
+
     def set_precision(self, precision: str):
         self.precision = precision
         _lib.check(self._lib.mmda_misa_set_mode(self._h, _lib.BF16 if precision == "bf16" else _lib.F32), "set_mode")

@@ -126,15 +126,22 @@ def lstm_pack(whh, mode):
     return pf, pb
 
 
-def _desc(H, gates, cstash, hseq, wp0, wp1, utt, layer, d_hseq=None):
+def _desc(H, gates, cstash, hseq, wp0, wp1, utt, layer, d_hseq=None, xchg=None, epoch_base=0):
     d = _lib.LstmDesc()
     d.H = H; d.gates = ptr(gates); d.cstash = ptr(cstash); d.hseq = ptr(hseq)
     d.wpack[0] = ptr(wp0); d.wpack[1] = ptr(wp1)
     d.utt = ptr(utt); d.layer = layer; d.d_hseq = ptr(d_hseq)
+    d.xchg = ptr(xchg); d.epoch_base = epoch_base
     return d
 
 
-def lstm_bidir_fwd(pre, whh_f, whh_r, lengths, *, mode="fp32", layer=0, utt=None):
+def lstm_xchg(H, B, device):
+    """Zeroed cluster-exchange buffer (None when the shape has no resident-weights plan)."""
+    n = load().mmda_lstm_xchg_bytes(H, B)
+    return torch.zeros(n, dtype=torch.uint8, device=device) if n > 0 else None
+
+
+def lstm_bidir_fwd(pre, whh_f, whh_r, lengths, *, mode="fp32", layer=0, utt=None, resident=False):
     """pre: (T,B,2,4H) = x W_ih^T + b_ih + b_hh per direction.  Returns dict(hseq, gates, cstash, utt, packs)."""
     lib = load()
     T, B, _, G4 = pre.shape
@@ -147,9 +154,10 @@ def lstm_bidir_fwd(pre, whh_f, whh_r, lengths, *, mode="fp32", layer=0, utt=None
     pf0, pb0 = lstm_pack(whh_f, mode)
     pf1, pb1 = lstm_pack(whh_r, mode)
     len_dev = lengths.to(device=pre.device, dtype=torch.int32)
-    d = (_lib.LstmDesc * 1)(_desc(H, gates, cst, hseq, pf0, pf1, utt, layer))
+    xchg = lstm_xchg(H, B, pre.device) if resident else None
+    d = (_lib.LstmDesc * 1)(_desc(H, gates, cst, hseq, pf0, pf1, utt, layer, None, xchg, 0))
     check(lib.mmda_lstm_fwd(MODE[mode], 1, d, B, T, ptr(len_dev), stream_ptr()), "lstm_fwd")
-    return dict(hseq=hseq, gates=gates, cstash=cst, utt=utt, packs=(pf0, pb0, pf1, pb1), len_dev=len_dev)
+    return dict(hseq=hseq, gates=gates, cstash=cst, utt=utt, packs=(pf0, pb0, pf1, pb1), len_dev=len_dev, xchg=xchg, T=T)
 
 
 def lstm_bidir_bwd(fw, d_utt, d_hseq, *, mode="fp32", layer=0):
@@ -159,9 +167,15 @@ def lstm_bidir_bwd(fw, d_utt, d_hseq, *, mode="fp32", layer=0):
     T, B, _, G4 = gates.shape
     H = G4 // 4
     pf0, pb0, pf1, pb1 = fw["packs"]
-    d = (_lib.LstmDesc * 1)(_desc(H, gates, fw["cstash"], fw["hseq"], pb0, pb1, d_utt, layer, d_hseq))
+    d = (_lib.LstmDesc * 1)(_desc(H, gates, fw["cstash"], fw["hseq"], pb0, pb1, d_utt, layer, d_hseq, fw.get("xchg"), T + 2))
     check(lib.mmda_lstm_bwd(MODE[mode], 1, d, B, T, ptr(fw["len_dev"]), stream_ptr()), "lstm_bwd")
     return gates
+
+
+def lstm_aborted(fw):
+    """True if a cluster exchange timed out (sticky abort word at the start of the exchange buffer)."""
+    x = fw.get("xchg")
+    return False if x is None else bool(x[:4].view(torch.int32).item() != 0)
 
 
 def attn_fwd(qkv, S, B, E, nhead, drop_p=0.0, seed=0, site=0):

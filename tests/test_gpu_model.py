@@ -186,9 +186,18 @@ def test_bf16_path_within_1e2(name):
     for s in SIDE:
         assert rel(pub[s], z["out::" + s]) < 1e-2, s
     L = model.read_losses()
+    assert not model.cluster_aborted()
     for k in ("cls", "diff", "sim", "recon", "conf", "total"):
         assert abs(L[k] - float(z["loss::" + k])) < 1e-2 * abs(float(z["loss::" + k])), k
     model._assign_grad_views()
+    # the two bf16 recurrence implementations (LDS-resident cluster vs L2-streaming) agree to rounding
+    g_res = model.flat_buckets()[1].clone()
+    model.set_recurrence(False)
+    model.train_step(b["t"], b["v"], b["a"], b["l"], b["emo"], lr=cfg.learning_rate, clip=cfg.clip, do_adam=False, training=False)
+    g_str = model.flat_buckets()[1]
+    assert float((g_res - g_str).norm() / g_str.norm()) < 2e-2
+    model.set_recurrence(True)
+    model.train_step(b["t"], b["v"], b["a"], b["l"], b["emo"], lr=cfg.learning_rate, clip=cfg.clip, do_adam=False, training=False)
     _, _, G = orc.loss_and_grads(P, cfg, batch)
     none = set(meta["none_grads"])
     for k, p in model.named_parameters():
@@ -246,7 +255,8 @@ def test_long_sequence_t500_finite_and_length_semantics():
     v2 = b["v"].clone(); v2[lmin:, -1] += 100.0
     a2 = b["a"].clone(); a2[lmin:, -1] -= 100.0
     model.train_step(b["t"], v2, a2, b["l"], b["emo"], lr=1e-4, clip=1.0, do_adam=False, training=False)
-    assert torch.equal(s1, model._public()["scores"])
+    # not bitwise: the split-K GEMMs combine partial sums with float atomics (order varies run to run)
+    assert rel(model._public()["scores"], s1) < 1e-5
 
 
 def test_training_mode_dropout_changes_outputs_but_stays_calibrated():
@@ -283,7 +293,7 @@ def test_state_dict_roundtrip_and_orthogonal_init_on_device():
     with torch.no_grad():
         a1, _ = m(b["t"], b["v"], b["a"], b["l"]); a1 = a1.clone()
         a2, _ = m2(b["t"], b["v"], b["a"], b["l"])
-    assert torch.equal(a1, a2)
+    assert rel(a2, a1) < 1e-5          # float-atomic split-K: equal up to summation order
 
 
 def test_cpu_inputs_fail_loudly():

@@ -161,11 +161,15 @@ def _lstm_case(T, B, H, D, ragged, seed):
     return rnn, x, lengths
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16", "bf16-resident"])
 @pytest.mark.parametrize("T,B,H,ragged", [(9, 5, 6, True), (12, 16, 35, True), (7, 20, 74, True), (10, 32, 300, False),
-                                          (6, 3, 300, True), (5, 17, 128, True)])
+                                          (6, 3, 300, True), (5, 17, 128, True), (8, 70, 300, True)])
 def test_lstm_fwd_bwd_vs_nn_lstm(mode, T, B, H, ragged):
+    """Three implementations of the recurrence behind one entry point: exact f32-MFMA streaming kernel, bf16 streaming kernel,
+    and the bf16 kernel with W_hh resident in LDS across a cluster of workgroups (per-step h / dG all-gather)."""
     from mmda_amd import ops
+    resident = mode.endswith("resident")
+    mode = mode.split("-")[0]
     D = H if H < 100 else 40
     rnn, x, lengths = _lstm_case(T, B, H, D, ragged, 7)
     pk = torch.nn.utils.rnn.pack_padded_sequence(x, lengths, enforce_sorted=False)
@@ -179,7 +183,9 @@ def test_lstm_fwd_bwd_vs_nn_lstm(mode, T, B, H, ragged):
     bih = torch.cat((rnn.bias_ih_l0, rnn.bias_ih_l0_reverse), 0).detach()
     bhh = torch.cat((rnn.bias_hh_l0, rnn.bias_hh_l0_reverse), 0).detach()
     pre = ops.gemm(x.detach().reshape(T * B, D).to(d), wih.to(d), mode=mode, bias=bih.to(d), bias2=bhh.to(d)).view(T, B, 2, 4 * H)
-    fw = ops.lstm_bidir_fwd(pre, rnn.weight_hh_l0.detach().to(d), rnn.weight_hh_l0_reverse.detach().to(d), lengths, mode=mode, layer=1)
+    fw = ops.lstm_bidir_fwd(pre, rnn.weight_hh_l0.detach().to(d), rnn.weight_hh_l0_reverse.detach().to(d), lengths, mode=mode, layer=1,
+                            resident=resident)
+    assert not ops.lstm_aborted(fw), "cluster exchange timed out in forward"
     tol = TOL[mode]
     assert relerr(fw["hseq"], pad) < tol
     utt = fw["utt"].cpu().view(B, 4, H)     # [h1_fwd, h2_fwd, h1_bwd, h2_bwd]; layer=1 fills slots 1 and 3
@@ -188,6 +194,7 @@ def test_lstm_fwd_bwd_vs_nn_lstm(mode, T, B, H, ragged):
     # backward
     d_utt = torch.zeros(B, 4, H); d_utt[:, 1] = d_hn[0]; d_utt[:, 3] = d_hn[1]
     dG = ops.lstm_bidir_bwd(fw, d_utt.view(B, 4 * H).to(d), d_out.to(d), mode=mode, layer=1).view(T * B, 8 * H)
+    assert not ops.lstm_aborted(fw), "cluster exchange timed out in backward"
     mask = (torch.arange(T)[:, None] < lengths[None, :]).reshape(T * B)
     assert float(dG.cpu()[~mask].abs().max() if (~mask).any() else 0.0) == 0.0, "dG must be zero at padded positions"
     btol = tol * (3 if mode == "bf16" else 1)
