@@ -129,6 +129,8 @@ typedef struct mmda_lstm_desc {
                           at least T+1 between launches that share an xchg buffer (flags are never reset) */
 } mmda_lstm_desc;
 int64_t mmda_lstm_xchg_bytes(int H, int B);
+/* diagnostics only: 8 x uint64 per workgroup, phase cycle sums of the resident-weights forward kernel (NULL disables) */
+int mmda_debug_set_lstm_stamps(void* device_buffer);
 /* up to 4 independent biLSTMs (modalities) in ONE launch; all share B, T and lengths (device int32, B entries) */
 int mmda_lstm_fwd(int mode, int n, const mmda_lstm_desc* descs, int B, int T, const int32_t* lengths, void* stream);
 /* backward: reads gates/cstash (forward stash), utt = d(utterance), d_hseq; overwrites `gates` with d(pre-activation)

@@ -76,6 +76,7 @@ SIGNATURES = {
     "mmda_layernorm_bwd": (_I, [C.POINTER(LnBwdArgs), _P]),
     "mmda_lstm_packed_bytes": (_I64, [_I, _I, _I]),
     "mmda_lstm_xchg_bytes": (_I64, [_I, _I]),
+    "mmda_debug_set_lstm_stamps": (_I, [_P]),
     "mmda_lstm_pack_whh": (_I, [_I, _I, _P, _P, _P, _P]),
     "mmda_lstm_fwd": (_I, [_I, _I, C.POINTER(LstmDesc), _I, _I, _P, _P]),
     "mmda_lstm_bwd": (_I, [_I, _I, C.POINTER(LstmDesc), _I, _I, _P, _P]),

@@ -40,13 +40,9 @@ __device__ __forceinline__ float tanhf_(float x) {
   return copysignf(t, x);
 }
 // fast versions (v_exp_f32 + v_rcp_f32) for the bf16 recurrent kernels where the gate math sits on the serial chain
-__device__ __forceinline__ float sigmoid_fast(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float tanh_fast(float x) {
-  float ax = fabsf(x);
-  float e = __expf(-2.0f * ax);
-  float t = (1.0f - e) * __frcp_rn(1.0f + e);
-  return copysignf(t, x);
-}
+// (__frcp_rn is a correctly rounded reciprocal = a ~10-instruction division sequence; v_rcp_f32 is 1 ulp and one issue)
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
 // Counter-based dropout RNG: murmur3 fmix64 of (seed, site, element index).  The same triple gives the same bit in
 // forward and backward, so masks are never stored.

@@ -131,8 +131,10 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_kernel(LstmLaunch L) {
         int b = bt * 16 + fq * 4 + r;
         bool act = (j < H) && (t < len_r[r]);
         gbase[r] = (((int64_t)t * B + b) * 2 + dir) * G4 + j;
+        // unconditional loads from clamped addresses + select (a load under a lane-dependent branch serialises on vmcnt(0))
+        int64_t gsafe = (((int64_t)t * B + min(b, B - 1)) * 2 + dir) * G4 + min(j, H - 1);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) pre[g][r] = act ? D.gates[gbase[r] + g * H] : 0.f;
+        for (int g = 0; g < 4; ++g) { float v = D.gates[gsafe + g * H]; pre[g][r] = act ? v : 0.f; }
       }
       f32x4 acc[4];
 #pragma unroll
@@ -260,15 +262,23 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmLaunch L) {
         bool act = inb && (t < len_r[r]);
         float dp[4] = {0.f, 0.f, 0.f, 0.f};
         int64_t gb = (((int64_t)t * B + b) * 2 + dir) * G4 + j;
+        // unconditional stash loads from clamped addresses (no lane-dependent branch around a load)
+        const int bc = min(b, B - 1), jc = min(j, H - 1);
+        const int64_t gs = (((int64_t)t * B + bc) * 2 + dir) * G4 + jc;
+        const float l_gi = D.gates[gs], l_gf = D.gates[gs + H], l_gg = D.gates[gs + 2 * H], l_go = D.gates[gs + 3 * H];
+        const float l_ct = D.cstash[(((int64_t)t * B + bc) * 2 + dir) * H + jc];
+        const int tp = dir ? t + 1 : t - 1;
+        const float l_cp = D.cstash[(((int64_t)min(max(tp, 0), T - 1) * B + bc) * 2 + dir) * H + jc];
+        float l_dh = 0.f;
+        if (D.d_hseq) l_dh = D.d_hseq[((int64_t)t * B + bc) * 2 * H + dir * H + jc];
+        const float l_ut = D.utt[(int64_t)bc * 4 * H + (dir * 2 + D.layer) * H + jc];
         if (act) {
-          float gi = D.gates[gb], gf = D.gates[gb + H], gg = D.gates[gb + 2 * H], go = D.gates[gb + 3 * H];
-          float ct = D.cstash[(((int64_t)t * B + b) * 2 + dir) * H + j];
-          int tp = dir ? t + 1 : t - 1;
-          float cp = (tp >= 0 && tp < len_r[r]) ? D.cstash[(((int64_t)tp * B + b) * 2 + dir) * H + j] : 0.f;
-          float dh = dh_rec[ti][r];
-          if (D.d_hseq) dh += D.d_hseq[((int64_t)t * B + b) * 2 * H + dir * H + j];
+          float gi = l_gi, gf = l_gf, gg = l_gg, go = l_go;
+          float ct = l_ct;
+          float cp = (tp >= 0 && tp < len_r[r]) ? l_cp : 0.f;
+          float dh = dh_rec[ti][r] + l_dh;
           bool fin = dir ? (t == 0) : (t == len_r[r] - 1);
-          if (fin) dh += D.utt[(int64_t)b * 4 * H + (dir * 2 + D.layer) * H + j];
+          dh += fin ? l_ut : 0.f;
           float tc = tanh_<MODE>(ct);
           float dct = dc[ti][r] + dh * go * (1.f - tc * tc);
           dp[0] = dct * gg * gi * (1.f - gi);

@@ -43,6 +43,7 @@ struct CLaunch {
   int n, B, T, g0, ng;               // batch groups [g0, g0+ng) of this launch
   const int32_t* lengths;
   unsigned epoch_base;
+  unsigned long long* dbg;           // diagnostics only: per-workgroup phase cycle sums (NULL in production)
 };
 
 // xchg layout per descriptor: [0,64) abort word | flags: (dir, group, wg) x 64 B | X: (dir, group, parity) x GROUP x XW bf16
@@ -110,11 +111,21 @@ __device__ __forceinline__ bool wait_cluster(unsigned char* flags, unsigned char
   return *lds_ok != 0;
 }
 
-template <bool FAST> __device__ __forceinline__ float sg(float x) { return sigmoid_fast(x); }
-__device__ __forceinline__ float th(float x) { return tanh_fast(x); }
+// Branch-free global I/O: every per-step load/store goes through a buffer descriptor with a 32-bit byte offset; lanes
+// that have nothing to do (padding columns, samples past the batch, t >= len_b) use an offset beyond the descriptor, for
+// which the hardware returns 0 / drops the store.  (A load under a lane-dependent branch makes hipcc wait vmcnt(0) per
+// element, and 64-bit index arithmetic per access costs ~20 VALU instructions.)
+constexpr unsigned OOB = 0xFFFFFF00u;
+__device__ __forceinline__ float ldf(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+__device__ __forceinline__ void stf(__amdgpu_buffer_rsrc_t r, unsigned off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
+}
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int MAXTW>
+// wave -> (m-tile mt = wave&1 : 16 of the group's 32 samples, local hidden tile lt = wave>>1 < TPW)
+template <int KSC>
 __global__ __launch_bounds__(256, 1) void lstm_fwd_cluster_kernel(CLaunch L) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const Where wh = locate(L);
@@ -123,10 +134,14 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_cluster_kernel(CLaunch L) {
   const int B = L.B, T = L.T, dir = wh.dir, me = wh.me;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
-  const int mt = wave & 1, htl = wave >> 1;           // wave -> (16-sample m-tile, local hidden tile parity)
+  const int mt = wave & 1, lt = wave >> 1;
+  const int ht = me * TPW + lt;
+  const bool tile_ok = lt < TPW && ht < nHT;             // wave-uniform
+  const int col = ht * 16 + fr;
   const int ld = Kp + 8;
   const int XW = 4 * Hp;
   const int ngt = (B + GROUP - 1) / GROUP;
+  const unsigned G4 = 4u * H;
 
   uint4* Wl = reinterpret_cast<uint4*>(smem);                                            // TPW*4*KS*64 x 16 B
   unsigned short* hb = reinterpret_cast<unsigned short*>(smem + (size_t)TPW * 4 * KS * 1024);   // 2 x GROUP x ld
@@ -141,41 +156,39 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_cluster_kernel(CLaunch L) {
     const uint4* src = reinterpret_cast<const uint4*>(D.wpack[dir]);
     const int per_tile = 4 * KS * 64;
     for (int i = tid; i < TPW * per_tile; i += 256) {
-      int lt = i / per_tile, ht = me * TPW + lt;
-      Wl[i] = ht < nHT ? src[(size_t)ht * per_tile + (i % per_tile)] : uint4{0, 0, 0, 0};
+      int l2 = i / per_tile, h2 = me * TPW + l2;
+      Wl[i] = h2 < nHT ? src[(size_t)h2 * per_tile + (i % per_tile)] : uint4{0, 0, 0, 0};
     }
     for (int i = tid; i < 2 * GROUP * ld; i += 256) hb[i] = 0;
   }
-  float c_reg[MAXTW][4], h_reg[MAXTW][4];
-  float pre[2][MAXTW][4][4];                           // input-to-hidden pre-activations, prefetched TWO steps ahead
-  float st[MAXTW][6][4];                               // this step's stash (i,f,g,o,c,h), stored after the exchange is issued
+  const __amdgpu_buffer_rsrc_t rg = make_rsrc(D.gates, (unsigned)T * B * 2u * G4 * 4u);
+  const __amdgpu_buffer_rsrc_t rc = make_rsrc(D.cstash, (unsigned)T * B * 2u * H * 4u);
+  const __amdgpu_buffer_rsrc_t rh = make_rsrc(D.hseq, (unsigned)T * B * 2u * H * 4u);
+  const unsigned sg = (unsigned)B * 2u * G4 * 4u, sc = (unsigned)B * 2u * H * 4u;   // byte strides per time step (hseq: sc too)
+  unsigned og[4], oc[4], oh[4];
   int len_r[4];
+  bool inb[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    int b = wh.grp * GROUP + mt * 16 + fq * 4 + r;
-    len_r[r] = b < B ? L.lengths[b] : 0;
+    const int b = wh.grp * GROUP + mt * 16 + fq * 4 + r;
+    inb[r] = tile_ok && col < H && b < B;
+    const int lv = L.lengths[min(b, B - 1)];
+    len_r[r] = inb[r] ? lv : 0;
+    og[r] = (((unsigned)b * 2u + dir) * G4 + col) * 4u;
+    oc[r] = (((unsigned)b * 2u + dir) * H + col) * 4u;
+    oh[r] = ((unsigned)b * 2u * H + dir * H + col) * 4u;
   }
-#pragma unroll
-  for (int j = 0; j < MAXTW; ++j)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { c_reg[j][r] = 0.f; h_reg[j][r] = 0.f; }
-  const int G4 = 4 * H;
+  float c_reg[4] = {0.f, 0.f, 0.f, 0.f}, h_reg[4] = {0.f, 0.f, 0.f, 0.f};
+  float pre[2][4][4];                                   // input-to-hidden pre-activations, prefetched TWO steps ahead
 
-  auto load_pre = [&](float (&dst)[MAXTW][4][4], int step) {
-    if (step >= T) return;
+  auto load_pre = [&](float (&dst)[4][4], int step) {
     const int t = dir ? T - 1 - step : step;
 #pragma unroll
-    for (int j = 0; j < MAXTW; ++j) {
-      const int lt = htl + 2 * j, ht = me * TPW + lt;
-      const int col = ht * 16 + fr;
+    for (int r = 0; r < 4; ++r) {
+      const bool act = step < T && t < len_r[r];
+      const unsigned o = og[r] + (unsigned)t * sg;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int b = wh.grp * GROUP + mt * 16 + fq * 4 + r;
-        bool act = lt < TPW && ht < nHT && col < H && t < len_r[r];
-        int64_t gb = (((int64_t)t * B + b) * 2 + dir) * G4 + col;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) dst[j][g][r] = act ? D.gates[gb + g * H] : 0.f;
-      }
+      for (int g = 0; g < 4; ++g) dst[g][r] = ldf(rg, act ? o + g * H * 4u : OOB);
     }
   };
   load_pre(pre[0], 0);
@@ -186,101 +199,121 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_cluster_kernel(CLaunch L) {
   xr[0] = make_rsrc(Xb, (unsigned)(GROUP * XW * 2));
   xr[1] = make_rsrc(Xb + (size_t)GROUP * XW * 2, (unsigned)(GROUP * XW * 2));
 
+  // all-gather tables (fixed for the whole sequence): X byte offset (OOB = nothing to fetch) and LDS destination
+  unsigned goff[8]; int gdst0[8];
+  {
+    const int cprow = Hp / 8;                            // 16-byte chunks per row over all hidden tiles
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      int i = u * 256 + tid;
+      int row = i / cprow, cc = (i % cprow) * 8;
+      bool want = i < GROUP * cprow && cc / (TPW * 16) != me;
+      gdst0[u] = want ? row * ld + cc : -1;
+      goff[u] = want ? (unsigned)((row * XW + cc) * 2) : OOB;
+    }
+  }
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last = 0;
+#define STAMP(i) do { if (L.dbg && tid == 0) { unsigned long long now_ = __builtin_readcyclecounter(); ph[i] += now_ - last; last = now_; } } while (0)
+  if (L.dbg && tid == 0) last = __builtin_readcyclecounter();
+
   // one time step with the pre-activation buffer `P` (static index: the loop below is unrolled by two)
-  auto do_step = [&](int step, float (&P)[MAXTW][4][4], int cur) -> bool {
+  auto do_step = [&](int step, float (&P)[4][4], int cur) -> bool {
     const int t = dir ? T - 1 - step : step;
     const unsigned epoch = L.epoch_base + (unsigned)step + 1u;
-#pragma unroll
-    for (int j = 0; j < MAXTW; ++j) {
-      const int lt = htl + 2 * j, ht = me * TPW + lt;
-      if (lt >= TPW || ht >= nHT) continue;
-      const int col = ht * 16 + fr;
+    if (tile_ok) {
       f32x4 acc[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
       const unsigned short* hrow = hb + (cur * GROUP + mt * 16 + fr) * ld + fq * 8;
       const bf16x8* wp = reinterpret_cast<const bf16x8*>(Wl) + (size_t)(lt * 4) * KS * 64 + lane;
-#pragma unroll 2
-      for (int ks = 0; ks < KS; ++ks) {
-        bf16x8 a = *reinterpret_cast<const bf16x8*>(hrow + ks * 32);
+      if (KSC > 0 && KS == KSC) {
+        // compile-time trip count (text: 10).  The 25 fragment reads of each half are issued first (100 VGPRs), then its 20 MFMAs consume them behind counted lgkmcnt waits: left to
+        // itself hipcc keeps only 2-3 ds_read_b128 in flight and every MFMA eats a full LDS round trip.
+        constexpr int HK = KSC / 2;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wp[(g * KS + ks) * 64], acc[g], 0, 0, 0);
+        for (int half = 0; half < 2; ++half) {
+          bf16x8 af[HK], bfr[HK][4];
+#pragma unroll
+          for (int k2 = 0; k2 < HK; ++k2) {
+            af[k2] = *reinterpret_cast<const bf16x8*>(hrow + (half * HK + k2) * 32);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bfr[k2][g] = wp[(g * KSC + half * HK + k2) * 64];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int k2 = 0; k2 < HK; ++k2) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k2], bfr[k2][g], acc[g], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll 2
+        for (int ks = 0; ks < KS; ++ks) {
+          bf16x8 a = *reinterpret_cast<const bf16x8*>(hrow + ks * 32);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wp[(g * KS + ks) * 64], acc[g], 0, 0, 0);
+        }
       }
+      // lane-local cell update, branch-free (inactive lanes compute on zeros and are masked by the selects / OOB stores)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        int b = wh.grp * GROUP + mt * 16 + fq * 4 + r;
-        bool act = (b < B) && (col < H) && (t < len_r[r]);
-        if (act) {
-          float gi = sigmoid_fast(acc[0][r] + P[j][0][r]);
-          float gf = sigmoid_fast(acc[1][r] + P[j][1][r]);
-          float gg = tanh_fast(acc[2][r] + P[j][2][r]);
-          float go = sigmoid_fast(acc[3][r] + P[j][3][r]);
-          float cn = gf * c_reg[j][r] + gi * gg;
-          float hn = go * tanh_fast(cn);
-          c_reg[j][r] = cn; h_reg[j][r] = hn;
-          st[j][0][r] = gi; st[j][1][r] = gf; st[j][2][r] = gg; st[j][3][r] = go; st[j][4][r] = cn; st[j][5][r] = hn;
-        }
-        hb[((cur ^ 1) * GROUP + mt * 16 + fq * 4 + r) * ld + col] = f2bf(h_reg[j][r]);
+        const bool act = t < len_r[r];
+        const float gi = sigmoid_fast(acc[0][r] + P[0][r]);
+        const float gf = sigmoid_fast(acc[1][r] + P[1][r]);
+        const float gg = tanh_fast(acc[2][r] + P[2][r]);
+        const float go = sigmoid_fast(acc[3][r] + P[3][r]);
+        const float cn = gf * c_reg[r] + gi * gg;
+        const float hn = go * tanh_fast(cn);
+        c_reg[r] = act ? cn : c_reg[r];
+        h_reg[r] = act ? hn : h_reg[r];
+        hb[((cur ^ 1) * GROUP + mt * 16 + fq * 4 + r) * ld + col] = f2bf(h_reg[r]);
+        // stash of this step: the publish drain below covers these stores, nothing younger stays outstanding later
+        const unsigned o = act ? og[r] + (unsigned)t * sg : OOB;
+        stf(rg, o, gi); stf(rg, act ? o + H * 4u : OOB, gf); stf(rg, act ? o + 2u * H * 4u : OOB, gg);
+        stf(rg, act ? o + 3u * H * 4u : OOB, go);
+        stf(rc, act ? oc[r] + (unsigned)t * sc : OOB, cn);
+        stf(rh, inb[r] ? oh[r] + (unsigned)t * sc : OOB, act ? hn : 0.f);     // zero at padded positions (pad_packed_sequence)
       }
     }
+    STAMP(0);
     __syncthreads();                                     // own h slice complete in LDS
+    STAMP(1);
     bool ok = true;
-    u32x4 gv[8]; int gdst[8];
     if (NC > 1) {
       __amdgpu_buffer_rsrc_t X = (epoch & 1u) ? xr[1] : xr[0];
       const int cpr = TPW * 2;                           // 16-byte chunks of the own slice per row
       const int c0 = me * TPW * 16;
       for (int i = tid; i < GROUP * cpr; i += 256) {
-        int row = i / cpr, col = c0 + (i % cpr) * 8;
-        if (col >= Hp) continue;                         // last workgroup: tiles past the padded width do not exist
-        u32x4 v = *reinterpret_cast<const u32x4*>(&hb[((cur ^ 1) * GROUP + row) * ld + col]);
-        st16_sc1(X, (unsigned)((row * XW + col) * 2), v);
+        int row = i / cpr, cc = c0 + (i % cpr) * 8;
+        if (cc >= Hp) continue;                          // last workgroup: tiles past the padded width do not exist
+        u32x4 v = *reinterpret_cast<const u32x4*>(&hb[((cur ^ 1) * GROUP + row) * ld + cc]);
+        st16_sc1(X, (unsigned)((row * XW + cc) * 2), v);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
+      STAMP(2);
       __syncthreads();
       if (tid == 0) st_flag(flags + (size_t)me * 64, epoch);
+      STAMP(3);
+      load_pre(P, step + 2);                             // lands while the cluster is being polled
       ok = wait_cluster(flags, abort_w, NC, me, epoch, &lds_ok);
+      STAMP(4);
       if (ok) {
-        const int cprow = Hp / 8;                        // 16-byte chunks per row over all hidden tiles
+        u32x4 gv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          int i = u * 256 + tid;
-          gdst[u] = -1;
-          if (i < GROUP * cprow) {
-            int row = i / cprow, col = (i % cprow) * 8;
-            if (col / (TPW * 16) != me) { gdst[u] = ((cur ^ 1) * GROUP + row) * ld + col; gv[u] = ld16_sc1(X, (unsigned)((row * XW + col) * 2)); }
-          }
-        }
+        for (int u = 0; u < 8; ++u) gv[u] = ld16_sc1(X, goff[u]);
+        STAMP(5);
+        const int nb = (cur ^ 1) * GROUP * ld;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (gdst0[u] >= 0) *reinterpret_cast<u32x4*>(&hb[nb + gdst0[u]]) = gv[u];
       }
+    } else {
+      load_pre(P, step + 2);
     }
-    // stash + the pre-activations of step+2 go out while the gathered h is in flight
-#pragma unroll
-    for (int j = 0; j < MAXTW; ++j) {
-      const int lt = htl + 2 * j, ht = me * TPW + lt;
-      if (lt >= TPW || ht >= nHT) continue;
-      const int col = ht * 16 + fr;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int b = wh.grp * GROUP + mt * 16 + fq * 4 + r;
-        bool inb = (b < B) && (col < H);
-        bool act = inb && (t < len_r[r]);
-        if (act) {
-          int64_t gb = (((int64_t)t * B + b) * 2 + dir) * G4 + col;
-          D.gates[gb] = st[j][0][r]; D.gates[gb + H] = st[j][1][r]; D.gates[gb + 2 * H] = st[j][2][r]; D.gates[gb + 3 * H] = st[j][3][r];
-          D.cstash[(((int64_t)t * B + b) * 2 + dir) * H + col] = st[j][4][r];
-          D.hseq[((int64_t)t * B + b) * 2 * H + dir * H + col] = st[j][5][r];
-        } else if (inb) {
-          D.hseq[((int64_t)t * B + b) * 2 * H + dir * H + col] = 0.f;
-        }
-      }
-    }
-    load_pre(P, step + 2);
-    if (NC > 1 && ok) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (gdst[u] >= 0) *reinterpret_cast<u32x4*>(&hb[gdst[u]]) = gv[u];
-    }
+    STAMP(6);
     __syncthreads();
+    STAMP(7);
     return ok;
   };
   {
@@ -291,21 +324,19 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_cluster_kernel(CLaunch L) {
     }
     if (step < T) do_step(step, pre[0], cur);
   }
+  if (L.dbg && tid == 0)
+    for (int i = 0; i < 8; ++i) L.dbg[(size_t)blockIdx.x * 8 + i] = ph[i];
+#undef STAMP
+  // final hidden state straight into the utterance layout [h1_fwd, h2_fwd, h1_bwd, h2_bwd] (models.py:203)
 #pragma unroll
-  for (int j = 0; j < MAXTW; ++j) {
-    const int lt = htl + 2 * j, ht = me * TPW + lt;
-    if (lt >= TPW || ht >= nHT) continue;
-    const int col = ht * 16 + fr;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      int b = wh.grp * GROUP + mt * 16 + fq * 4 + r;
-      if (b < B && col < H) D.utt[(int64_t)b * 4 * H + (dir * 2 + D.layer) * H + col] = h_reg[j][r];
-    }
+  for (int r = 0; r < 4; ++r) {
+    const int b = wh.grp * GROUP + mt * 16 + fq * 4 + r;
+    if (inb[r]) D.utt[(int64_t)b * 4 * H + (dir * 2 + D.layer) * H + col] = h_reg[r];
   }
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-template <int MAXTW>
+template <int KSBC>
 __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(CLaunch L) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const Where wh = locate(L);
@@ -314,10 +345,14 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(CLaunch L) {
   const int B = L.B, T = L.T, dir = wh.dir, me = wh.me;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
-  const int mt = wave & 1, htl = wave >> 1;
+  const int mt = wave & 1, lt = wave >> 1;
+  const int ht = me * TPW + lt;
+  const bool tile_ok = lt < TPW && ht < nHT;
+  const int col = ht * 16 + fr;
   const int XW = 4 * Hp;
   const int ld = XW + 8;
   const int ngt = (B + GROUP - 1) / GROUP;
+  const unsigned G4 = 4u * H;
 
   uint4* Wl = reinterpret_cast<uint4*>(smem);                                              // TPW*KSB*64 x 16 B
   unsigned short* dg = reinterpret_cast<unsigned short*>(smem + (size_t)TPW * KSB * 1024);         // GROUP x ld
@@ -330,52 +365,47 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(CLaunch L) {
     const uint4* src = reinterpret_cast<const uint4*>(D.wpack[dir]);       // backward packing [ht*KSB + ks][lane] x 16 B
     const int per_tile = KSB * 64;
     for (int i = tid; i < TPW * per_tile; i += 256) {
-      int lt = i / per_tile, ht = me * TPW + lt;
-      Wl[i] = ht < nHT ? src[(size_t)ht * per_tile + (i % per_tile)] : uint4{0, 0, 0, 0};
+      int l2 = i / per_tile, h2 = me * TPW + l2;
+      Wl[i] = h2 < nHT ? src[(size_t)h2 * per_tile + (i % per_tile)] : uint4{0, 0, 0, 0};
     }
     for (int i = tid; i < GROUP * ld; i += 256) dg[i] = 0;
   }
-  float dh_rec[MAXTW][4], dc[MAXTW][4];
-  struct Stash { float g[MAXTW][4][4], c[MAXTW][4], cp[MAXTW][4], dh[MAXTW][4]; };
-  Stash sb[2];                                          // forward stash of the coming steps, prefetched TWO steps ahead
-  float dgv[MAXTW][4][4];                               // this step's gate gradients, stored after the exchange is issued
+  const __amdgpu_buffer_rsrc_t rg = make_rsrc(D.gates, (unsigned)T * B * 2u * G4 * 4u);
+  const __amdgpu_buffer_rsrc_t rc = make_rsrc(D.cstash, (unsigned)T * B * 2u * H * 4u);
+  const __amdgpu_buffer_rsrc_t rd = make_rsrc(const_cast<float*>(D.d_hseq), D.d_hseq ? (unsigned)T * B * 2u * H * 4u : 0u);
+  const __amdgpu_buffer_rsrc_t ru = make_rsrc(D.utt, (unsigned)B * 4u * H * 4u);
+  const unsigned sg = (unsigned)B * 2u * G4 * 4u, sc = (unsigned)B * 2u * H * 4u;
+  unsigned og[4], oc[4], oh[4];
   int len_r[4];
+  bool inb[4];
+  float d_fin[4];                                       // gradient of the final hidden state of this (sample, unit)
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    int b = wh.grp * GROUP + mt * 16 + fq * 4 + r;
-    len_r[r] = b < B ? L.lengths[b] : 0;
+    const int b = wh.grp * GROUP + mt * 16 + fq * 4 + r;
+    inb[r] = tile_ok && col < H && b < B;
+    const int lv = L.lengths[min(b, B - 1)];
+    len_r[r] = inb[r] ? lv : 0;
+    og[r] = (((unsigned)b * 2u + dir) * G4 + col) * 4u;
+    oc[r] = (((unsigned)b * 2u + dir) * H + col) * 4u;
+    oh[r] = ((unsigned)b * 2u * H + dir * H + col) * 4u;
+    d_fin[r] = ldf(ru, inb[r] ? ((unsigned)b * 4u * H + (dir * 2 + D.layer) * H + col) * 4u : OOB);
   }
-#pragma unroll
-  for (int j = 0; j < MAXTW; ++j)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { dh_rec[j][r] = 0.f; dc[j][r] = 0.f; }
-  const int G4 = 4 * H;
+  float dh_rec[4] = {0.f, 0.f, 0.f, 0.f}, dc[4] = {0.f, 0.f, 0.f, 0.f};
+  struct Stash { float g[4][4], c[4], cp[4], dh[4]; };
+  Stash sb[2];                                          // forward stash of the coming steps, prefetched TWO steps ahead
 
   auto load_stash = [&](Stash& S, int step) {
-    if (step >= T) return;
     const int t = dir ? step : T - 1 - step;
+    const int tp = dir ? t + 1 : t - 1;
 #pragma unroll
-    for (int j = 0; j < MAXTW; ++j) {
-      const int lt = htl + 2 * j, ht = me * TPW + lt;
-      const int col = ht * 16 + fr;
+    for (int r = 0; r < 4; ++r) {
+      const bool act = step < T && t < len_r[r];
+      const unsigned o = og[r] + (unsigned)t * sg;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int b = wh.grp * GROUP + mt * 16 + fq * 4 + r;
-        bool act = lt < TPW && ht < nHT && col < H && t < len_r[r];
-        int64_t gb = (((int64_t)t * B + b) * 2 + dir) * G4 + col;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) S.g[j][g][r] = act ? D.gates[gb + g * H] : 0.f;
-        S.c[j][r] = act ? D.cstash[(((int64_t)t * B + b) * 2 + dir) * H + col] : 0.f;
-        int tp = dir ? t + 1 : t - 1;
-        S.cp[j][r] = (act && tp >= 0 && tp < len_r[r]) ? D.cstash[(((int64_t)tp * B + b) * 2 + dir) * H + col] : 0.f;
-        float dh = 0.f;
-        if (act) {
-          if (D.d_hseq) dh += D.d_hseq[((int64_t)t * B + b) * 2 * H + dir * H + col];
-          bool fin = dir ? (t == 0) : (t == len_r[r] - 1);
-          if (fin) dh += D.utt[(int64_t)b * 4 * H + (dir * 2 + D.layer) * H + col];
-        }
-        S.dh[j][r] = dh;
-      }
+      for (int g = 0; g < 4; ++g) S.g[g][r] = ldf(rg, act ? o + g * H * 4u : OOB);
+      S.c[r] = ldf(rc, act ? oc[r] + (unsigned)t * sc : OOB);
+      S.cp[r] = ldf(rc, (act && tp >= 0 && tp < len_r[r]) ? oc[r] + (unsigned)tp * sc : OOB);
+      S.dh[r] = ldf(rd, act ? oh[r] + (unsigned)t * sc : OOB);          // zero-record descriptor when d_hseq == NULL
     }
   };
   load_stash(sb[0], 0);
@@ -386,35 +416,34 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(CLaunch L) {
   xr[0] = make_rsrc(Xb, (unsigned)(GROUP * XW * 2));
   xr[1] = make_rsrc(Xb + (size_t)GROUP * XW * 2, (unsigned)(GROUP * XW * 2));
   constexpr int GB = 20;                                // 16-byte gather chunks per thread and batch (text: 19 -> one batch)
+  const int own_lo = me * TPW * 16, own_hi = own_lo + TPW * 16;   // own hidden columns inside each gate block
 
   auto do_step = [&](int step, Stash& S) -> bool {
     const int t = dir ? step : T - 1 - step;
     const unsigned epoch = L.epoch_base + (unsigned)step + 1u;
-    // (1) lane-local gate gradients of the own hidden units
-#pragma unroll
-    for (int j = 0; j < MAXTW; ++j) {
-      const int lt = htl + 2 * j, ht = me * TPW + lt;
-      if (lt >= TPW || ht >= nHT) continue;
-      const int col = ht * 16 + fr;
+    // (1) lane-local gate gradients of the own hidden units (branch-free)
+    if (tile_ok) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        int b = wh.grp * GROUP + mt * 16 + fq * 4 + r;
-        bool act = (b < B) && (col < H) && (t < len_r[r]);
-        float dp[4] = {0.f, 0.f, 0.f, 0.f};
-        if (act) {
-          float gi = S.g[j][0][r], gf = S.g[j][1][r], gg = S.g[j][2][r], go = S.g[j][3][r];
-          float dh = dh_rec[j][r] + S.dh[j][r];
-          float tc = tanh_fast(S.c[j][r]);
-          float dct = dc[j][r] + dh * go * (1.f - tc * tc);
-          dp[0] = dct * gg * gi * (1.f - gi);
-          dp[1] = dct * S.cp[j][r] * gf * (1.f - gf);
-          dp[2] = dct * gi * (1.f - gg * gg);
-          dp[3] = dh * tc * go * (1.f - go);
-          dc[j][r] = dct * gf;
-        }
+        const bool act = t < len_r[r];
+        const bool fin = dir ? (t == 0) : (t == len_r[r] - 1);
+        const float gi = S.g[0][r], gf = S.g[1][r], gg = S.g[2][r], go = S.g[3][r];
+        const float dh = dh_rec[r] + S.dh[r] + (fin ? d_fin[r] : 0.f);
+        const float tc = tanh_fast(S.c[r]);
+        const float dct = dc[r] + dh * go * (1.f - tc * tc);
+        float dp[4];
+        dp[0] = act ? dct * gg * gi * (1.f - gi) : 0.f;
+        dp[1] = act ? dct * S.cp[r] * gf * (1.f - gf) : 0.f;
+        dp[2] = act ? dct * gi * (1.f - gg * gg) : 0.f;
+        dp[3] = act ? dh * tc * go * (1.f - go) : 0.f;
+        dc[r] = act ? dct * gf : dc[r];
         const int row = mt * 16 + fq * 4 + r;
+        const unsigned o = inb[r] ? og[r] + (unsigned)t * sg : OOB;       // zero at padded positions too
 #pragma unroll
-        for (int g = 0; g < 4; ++g) { dgv[j][g][r] = dp[g]; dg[row * ld + g * Hp + col] = f2bf(dp[g]); }
+        for (int g = 0; g < 4; ++g) {
+          dg[row * ld + g * Hp + col] = f2bf(dp[g]);
+          stf(rg, inb[r] ? o + g * H * 4u : OOB, dp[g]);                  // fp32 dG in place over the stash
+        }
       }
     }
     __syncthreads();                                     // own dG slice complete in LDS
@@ -427,73 +456,77 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(CLaunch L) {
         int row = i / (4 * cpg), rem = i % (4 * cpg);
         int cu = c0 + (rem % cpg) * 8;
         if (cu >= Hp) continue;                          // last workgroup: tiles past the padded width do not exist
-        int col = (rem / cpg) * Hp + cu;
-        u32x4 v = *reinterpret_cast<const u32x4*>(&dg[row * ld + col]);
-        st16_sc1(X, (unsigned)((row * XW + col) * 2), v);
+        int cc = (rem / cpg) * Hp + cu;
+        u32x4 v = *reinterpret_cast<const u32x4*>(&dg[row * ld + cc]);
+        st16_sc1(X, (unsigned)((row * XW + cc) * 2), v);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) st_flag(flags + (size_t)me * 64, epoch);
+      load_stash(S, step + 2);                           // lands while the cluster is being polled
       ok = wait_cluster(flags, abort_w, NC, me, epoch, &lds_ok);
-    }
-    // this step's dG (fp32, in place over the stash) and the stash of step+2 go out while the gather is in flight
-    auto side_traffic = [&]() {
+      if (ok) {
+        const int cprow = XW / 8;
+        const int total = GROUP * cprow;
+        for (int i0 = 0; i0 < total; i0 += 256 * GB) {
+          u32x4 v[GB]; int dst[GB];
+          int row = (i0 + tid) / cprow, ch = (i0 + tid) % cprow;      // one division per batch, then incremental
+          const int drow = 256 / cprow, dch = 256 % cprow;
 #pragma unroll
-      for (int j = 0; j < MAXTW; ++j) {
-        const int lt = htl + 2 * j, ht = me * TPW + lt;
-        if (lt >= TPW || ht >= nHT) continue;
-        const int col = ht * 16 + fr;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          int b = wh.grp * GROUP + mt * 16 + fq * 4 + r;
-          if (b < B && col < H) {
-            int64_t gb = (((int64_t)t * B + b) * 2 + dir) * G4 + col;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) D.gates[gb + g * H] = dgv[j][g][r];
+          for (int u = 0; u < GB; ++u) {           // unconditional loads; out-of-range offset -> zeros
+            const int cc = ch * 8;
+            int cm = cc; cm = cm >= Hp ? cm - Hp : cm; cm = cm >= Hp ? cm - Hp : cm; cm = cm >= Hp ? cm - Hp : cm;   // cc % Hp (cc < 4 Hp)
+            bool want = row < GROUP && cm >= own_lo && cm < own_hi ? false : row < GROUP;
+            dst[u] = want ? row * ld + cc : -1;
+            v[u] = ld16_sc1(X, want ? (unsigned)((row * XW + cc) * 2) : OOB);
+            row += drow; ch += dch;
+            if (ch >= cprow) { ch -= cprow; row += 1; }
           }
-        }
-      }
-      load_stash(S, step + 2);
-    };
-    if (NC > 1 && ok) {
-      const int cprow = XW / 8;
-      const int total = GROUP * cprow;
-      bool side_done = false;
-      for (int i0 = 0; i0 < total; i0 += 256 * GB) {
-        u32x4 v[GB]; int dst[GB];
 #pragma unroll
-        for (int u = 0; u < GB; ++u) {
-          int i = i0 + u * 256 + tid;
-          dst[u] = -1;
-          if (i < total) {
-            int row = i / cprow, col = (i % cprow) * 8;
-            if ((col % Hp) / (TPW * 16) != me) { dst[u] = row * ld + col; v[u] = ld16_sc1(X_of(epoch, xr), (unsigned)((row * XW + col) * 2)); }
-          }
+          for (int u = 0; u < GB; ++u)
+            if (dst[u] >= 0) *reinterpret_cast<u32x4*>(&dg[dst[u]]) = v[u];
         }
-        if (!side_done) { side_traffic(); side_done = true; }
-#pragma unroll
-        for (int u = 0; u < GB; ++u)
-          if (dst[u] >= 0) *reinterpret_cast<u32x4*>(&dg[dst[u]]) = v[u];
       }
       __syncthreads();
     } else {
-      side_traffic();
+      load_stash(S, step + 2);
     }
     // (2) dh_{t-1}[own units] = dG(all gate rows) * W_hh[:, own units] out of LDS
-#pragma unroll
-    for (int j = 0; j < MAXTW; ++j) {
-      const int lt = htl + 2 * j, ht = me * TPW + lt;
-      if (lt >= TPW || ht >= nHT) continue;
+    if (tile_ok) {
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
       const unsigned short* arow = dg + (mt * 16 + fr) * ld + fq * 8;
       const bf16x8* wp = reinterpret_cast<const bf16x8*>(Wl) + (size_t)lt * KSB * 64 + lane;
+      if (KSBC > 0 && KSB == KSBC) {
+        // text: 38 k-steps in two halves of 19: all 38 fragment reads of a half are issued before its MFMAs (see forward)
+        f32x4 acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          constexpr int HK = KSBC / 2;
+          bf16x8 af[HK], bfr[HK];
+#pragma unroll
+          for (int k2 = 0; k2 < HK; ++k2) {
+            af[k2] = *reinterpret_cast<const bf16x8*>(arow + (half * HK + k2) * 32);
+            bfr[k2] = wp[(half * HK + k2) * 64];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int k2 = 0; k2 < HK; ++k2) {
+            if (k2 & 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k2], bfr[k2], acc2, 0, 0, 0);
+            else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k2], bfr[k2], acc, 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
+      } else {
 #pragma unroll 4
-      for (int ks = 0; ks < KSB; ++ks) {
-        bf16x8 a = *reinterpret_cast<const bf16x8*>(arow + ks * 32);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wp[ks * 64], acc, 0, 0, 0);
+        for (int ks = 0; ks < KSB; ++ks) {
+          bf16x8 a = *reinterpret_cast<const bf16x8*>(arow + ks * 32);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wp[ks * 64], acc, 0, 0, 0);
+        }
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dh_rec[j][r] = acc[r];
+      for (int r = 0; r < 4; ++r) dh_rec[r] = acc[r];
     }
     __syncthreads();                                     // dG tile is overwritten by the next step
     return ok;
@@ -515,7 +548,7 @@ Plan plan_for(int H) {
   int Hp = round_up(H, 16), Kp = round_up(H, 32), KS = Kp / 32, KSB = 4 * Hp / 32, nHT = Hp / 16;
   const size_t cap = 160 * 1024 - 1024;
   p.ok = false;
-  for (int t = 6; t >= 1; --t) {
+  for (int t = 2; t >= 1; --t) {          // <= 2 hidden tiles per workgroup: every wave owns exactly one (m-tile, hidden tile)
     if (t > nHT && t > 1) continue;
     size_t lf = (size_t)t * 4 * KS * 1024 + (size_t)2 * GROUP * (Kp + 8) * 2 + 16;
     size_t lb = (size_t)t * KSB * 1024 + (size_t)GROUP * (4 * Hp + 8) * 2 + 16;
@@ -538,6 +571,10 @@ extern "C" int64_t mmda_lstm_xchg_bytes(int H, int B) {
   return (int64_t)((xchg_bytes(ngt, p.NC, round_up(H, 16)) + 255) & ~(size_t)255);
 }
 
+static unsigned long long* g_dbg = nullptr;
+// diagnostics only (tools/): device buffer of 8 x u64 per workgroup receiving the forward kernel's phase cycle sums
+extern "C" int mmda_debug_set_lstm_stamps(void* device_buffer) { g_dbg = (unsigned long long*)device_buffer; return MMDA_OK; }
+
 // returns MMDA_OK and sets *used = 1 when the cluster kernels ran; *used = 0 means "not applicable, use the streaming path"
 int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, const int32_t* lengths, void* stream, bool bwd,
                              int* used) {
@@ -554,7 +591,10 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
     size_t l = bwd ? plans[i].lds_b : plans[i].lds_f;
     lds = l > lds ? l : lds;
   }
-  if (maxtw > 3) return MMDA_OK;
+  if (maxtw > 1) return MMDA_OK;
+  // buffer descriptors address 32-bit byte offsets: every per-step tensor must stay below 4 GiB
+  for (int i = 0; i < n; ++i)
+    if ((double)T * B * 2.0 * 4.0 * descs[i].H * 4.0 >= 4.0e9) return MMDA_OK;
   const int ngt = ceil_div(B, GROUP);
   int wg_per_group = 0;
   for (int i = 0; i < n; ++i) wg_per_group += 2 * plans[i].NC;
@@ -564,7 +604,7 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
   for (int g0 = 0; g0 < ngt; g0 += groups_per_launch) {
     CLaunch L;
     L.n = n; L.B = B; L.T = T; L.g0 = g0; L.ng = (ngt - g0) < groups_per_launch ? (ngt - g0) : groups_per_launch;
-    L.lengths = lengths; L.epoch_base = descs[0].epoch_base;
+    L.lengths = lengths; L.epoch_base = descs[0].epoch_base; L.dbg = bwd ? nullptr : g_dbg;
     int wg = 0;
     for (int i = 0; i < MAXD; ++i) {
       const mmda_lstm_desc& d = descs[i < n ? i : 0];
@@ -578,16 +618,14 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
       if (i < n) wg += 2 * L.ng * p.NC;
     }
     dim3 grid(wg), block(256);
-#define LAUNCH_C(MT)                                                                                             \
+#define LAUNCH_C()                                                                                               \
   do {                                                                                                           \
-    auto kfn = bwd ? lstm_bwd_cluster_kernel<MT> : lstm_fwd_cluster_kernel<MT>;                                  \
+    auto kfn = bwd ? lstm_bwd_cluster_kernel<38> : lstm_fwd_cluster_kernel<10>;                                  \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,     \
                             (int)lds) != hipSuccess) { (void)hipGetLastError(); }                                \
     hipLaunchKernelGGL(kfn, grid, block, lds, s, L);                                                             \
   } while (0)
-    if (maxtw <= 1) LAUNCH_C(1);
-    else if (maxtw <= 2) LAUNCH_C(2);
-    else LAUNCH_C(3);
+    LAUNCH_C();
 #undef LAUNCH_C
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { mmda_set_error(bwd ? "mmda_lstm_bwd(cluster)" : "mmda_lstm_fwd(cluster)", e); return MMDA_ELAUNCH; }
