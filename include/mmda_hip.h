@@ -64,6 +64,8 @@ typedef struct mmda_gemm_args {
   float alpha;                                  /* scales the product before bias/accumulate; 0 is read as 1 */
 } mmda_gemm_args;
 int mmda_gemm(const mmda_gemm_args* args, void* stream);
+/* n independent GEMMs (any mix of shapes / layouts / modes) in one launch; results as n mmda_gemm calls in any order */
+int mmda_gemm_grouped(const mmda_gemm_args* args, int n, void* stream);
 
 /* column sums: out[n] += sum_m X[m*ld + n] (and out2[n] += the same, if out2 != NULL)   (bias gradients; atomics) */
 int mmda_colsum(const float* X, int ld, int M, int N, float* out, float* out2, void* stream);

@@ -69,6 +69,7 @@ SIGNATURES = {
     "mmda_last_error": (C.c_char_p, []),
     "mmda_abi_version": (_I, []),
     "mmda_gemm": (_I, [C.POINTER(GemmArgs), _P]),
+    "mmda_gemm_grouped": (_I, [C.POINTER(GemmArgs), _I, _P]),
     "mmda_colsum": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "mmda_embed_gather": (_I, [_P, _P, _I, _I, _P, _P]),
     "mmda_embed_scatter_add": (_I, [_P, _P, _I, _I, _P, _P]),

@@ -4,6 +4,7 @@
 //
 // Tile 64x64x32, 256 threads = 4 waves (2x2), each wave a 32x32 sub-tile = 2x2 MFMA 16x16 accumulators.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -12,8 +13,7 @@ constexpr int LDS_F32_LD = 34;   // floats per LDS row: (2*row + k) % 32 distinc
 constexpr int LDS_BF16_LD = 40;  // shorts per LDS row (80 B, 16-B aligned rows for ds_read_b128)
 
 template <int MODE>
-__global__ __launch_bounds__(256) void gemm_kernel(mmda_gemm_args g, int splitk) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BM * LDS_F32_LD * 4];
+__device__ __forceinline__ void gemm_body(const mmda_gemm_args& g, int splitk, unsigned char* smem, int bx, int by, int bzz) {
   float* As_f = reinterpret_cast<float*>(smem);
   float* Bs_f = As_f + BM * LDS_F32_LD;
   unsigned short* As_h = reinterpret_cast<unsigned short*>(smem);
@@ -21,9 +21,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(mmda_gemm_args g, int splitk)
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w >> 1, wn = w & 1;
-  const int row0 = blockIdx.y * BM, col0 = blockIdx.x * BN;
-  const int64_t bz = blockIdx.z / splitk;
-  const int sp = blockIdx.z % splitk;
+  const int row0 = by * BM, col0 = bx * BN;
+  const int64_t bz = bzz / splitk;
+  const int sp = bzz % splitk;
   const float* A = g.A + bz * g.strideA;
   const float* A2 = g.A2 ? g.A2 + bz * g.strideA : nullptr;
   const float* Bm = g.B + bz * g.strideB;
@@ -157,6 +157,161 @@ __global__ __launch_bounds__(256) void gemm_kernel(mmda_gemm_args g, int splitk)
     }
 }
 
+
+template <int MODE>
+__global__ __launch_bounds__(256) void gemm_kernel(mmda_gemm_args g, int splitk) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BM * LDS_F32_LD * 4];
+  gemm_body<MODE>(g, splitk, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Grouped launch: up to GROUP_MAX independent GEMMs (different shapes, layouts, modes) in ONE grid, so that the many small
+// LSTM gradient GEMMs of the three modalities fill the chip together instead of running one after another at a few dozen
+// workgroups each.  blockIdx.x -> (problem, tile) through the prefix table.
+constexpr int GROUP_MAX = 16;
+struct GroupLaunch {
+  mmda_gemm_args p[GROUP_MAX];
+  int start[GROUP_MAX + 1];
+  int tx[GROUP_MAX], ty[GROUP_MAX], splitk[GROUP_MAX];
+  int n;
+};
+__global__ __launch_bounds__(256) void gemm_grouped_kernel(GroupLaunch G) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BM * LDS_F32_LD * 4];
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < GROUP_MAX; ++k)
+    if (k < G.n && (int)blockIdx.x >= G.start[k]) i = k;
+  const int local = blockIdx.x - G.start[i];
+  const int bx = local % G.tx[i], by = (local / G.tx[i]) % G.ty[i], bzz = local / (G.tx[i] * G.ty[i]);
+  if (G.p[i].mode == MMDA_BF16) gemm_body<MMDA_BF16>(G.p[i], G.splitk[i], smem, bx, by, bzz);
+  else gemm_body<MMDA_F32>(G.p[i], G.splitk[i], smem, bx, by, bzz);
+}
+
+// ------------------------------------------------------------------------------------------------ 128x128 bf16 tile
+// The LSTM-sized GEMMs (M = T*B rows, N/K in {300, 600, 1200, 2400}) with 16-byte fp32 staging loads, a 128x128x32 tile
+// and a 64x64 sub-tile per wave: 16 MFMA 16x16x32 per wave and k-tile against 8 ds_read_b128 (the 64x64 kernel above
+// issues 4 MFMAs per 4 reads and 16 scalar loads per thread).  Requires 16-byte aligned rows (leading dims % 4 == 0,
+// K % 4 == 0, M % 4 == 0 for transA / N % 4 == 0 for !transB) and a plain epilogue; the host picks it when that holds.
+constexpr int TM = 128, TN = 128;
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm128_bf16_kernel(mmda_gemm_args g, int splitk) {
+  __shared__ __attribute__((aligned(16))) unsigned short As[TM * LDS_BF16_LD];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[TN * LDS_BF16_LD];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const int row0 = blockIdx.y * TM, col0 = blockIdx.x * TN;
+  const int64_t bz = blockIdx.z / splitk;
+  const int sp = blockIdx.z % splitk;
+  const float* A = g.A + bz * g.strideA;
+  const float* Bm = g.B + bz * g.strideB;
+  float* C = g.C + bz * g.strideC;
+  const int M = g.M, N = g.N, K = g.K;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float4 ra[4], rb[4];
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int gi = tid + 256 * i;
+      float4 v = float4{0.f, 0.f, 0.f, 0.f};
+      if (!TA) {                       // A (M,K): 8 groups of 4 k per row
+        const int r = gi >> 3, k = k0 + (gi & 7) * 4;
+        if (row0 + r < M && k < K) v = *reinterpret_cast<const float4*>(A + (int64_t)(row0 + r) * g.lda + k);
+      } else {                         // A (K,M): 32 groups of 4 m per k-row
+        const int k = k0 + (gi >> 5), m = row0 + (gi & 31) * 4;
+        if (k < K && m < M) v = *reinterpret_cast<const float4*>(A + (int64_t)k * g.lda + m);
+      }
+      ra[i] = v;
+      float4 u = float4{0.f, 0.f, 0.f, 0.f};
+      if (TB) {                        // B (N,K)
+        const int r = gi >> 3, k = k0 + (gi & 7) * 4;
+        if (col0 + r < N && k < K) u = *reinterpret_cast<const float4*>(Bm + (int64_t)(col0 + r) * g.ldb + k);
+      } else {                         // B (K,N)
+        const int k = k0 + (gi >> 5), n = col0 + (gi & 31) * 4;
+        if (k < K && n < N) u = *reinterpret_cast<const float4*>(Bm + (int64_t)k * g.ldb + n);
+      }
+      rb[i] = u;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int gi = tid + 256 * i;
+      if (!TA) {
+        const int r = gi >> 3, k = (gi & 7) * 4;
+        uint2 p; p.x = f2bf(ra[i].x) | ((unsigned)f2bf(ra[i].y) << 16); p.y = f2bf(ra[i].z) | ((unsigned)f2bf(ra[i].w) << 16);
+        *reinterpret_cast<uint2*>(&As[r * LDS_BF16_LD + k]) = p;
+      } else {
+        const int k = gi >> 5, m = (gi & 31) * 4;
+        As[(m + 0) * LDS_BF16_LD + k] = f2bf(ra[i].x); As[(m + 1) * LDS_BF16_LD + k] = f2bf(ra[i].y);
+        As[(m + 2) * LDS_BF16_LD + k] = f2bf(ra[i].z); As[(m + 3) * LDS_BF16_LD + k] = f2bf(ra[i].w);
+      }
+      if (TB) {
+        const int r = gi >> 3, k = (gi & 7) * 4;
+        uint2 p; p.x = f2bf(rb[i].x) | ((unsigned)f2bf(rb[i].y) << 16); p.y = f2bf(rb[i].z) | ((unsigned)f2bf(rb[i].w) << 16);
+        *reinterpret_cast<uint2*>(&Bs[r * LDS_BF16_LD + k]) = p;
+      } else {
+        const int k = gi >> 5, n = (gi & 31) * 4;
+        Bs[(n + 0) * LDS_BF16_LD + k] = f2bf(rb[i].x); Bs[(n + 1) * LDS_BF16_LD + k] = f2bf(rb[i].y);
+        Bs[(n + 2) * LDS_BF16_LD + k] = f2bf(rb[i].z); Bs[(n + 3) * LDS_BF16_LD + k] = f2bf(rb[i].w);
+      }
+    }
+  };
+
+  const int nk_all = (K + BK - 1) / BK;
+  const int per = (nk_all + splitk - 1) / splitk;
+  const int kt0 = sp * per;
+  const int nk = min(nk_all, kt0 + per);
+  if (splitk > 1 && kt0 >= nk) return;
+  load_tile(kt0 * BK);
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int kt = kt0; kt < nk; ++kt) {
+    __syncthreads();
+    store_tile();
+    __syncthreads();
+    if (kt + 1 < nk) load_tile((kt + 1) * BK);
+    bf16x8 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      a[i] = *reinterpret_cast<const bf16x8*>(&As[(wm * 64 + i * 16 + fr) * LDS_BF16_LD + fq * 8]);
+      b[i] = *reinterpret_cast<const bf16x8*>(&Bs[(wn * 64 + i * 16 + fr) * LDS_BF16_LD + fq * 8]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+
+  const float* bias = g.bias ? g.bias + bz * g.strideBias : nullptr;
+  const float* bias2 = g.bias2 ? g.bias2 + bz * g.strideBias : nullptr;
+  const float alpha = g.alpha == 0.f ? 1.f : g.alpha;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = col0 + wn * 64 + j * 16 + (lane & 15);
+      if (n >= N) continue;
+      float bsum = 0.f;
+      if (bias) bsum += bias[n];
+      if (bias2) bsum += bias2[n];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = row0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+        if (m >= M) continue;
+        const int64_t ci = (int64_t)m * g.ldc + n;
+        if (splitk > 1) { atomicAdd(&C[ci], alpha * acc[i][j][r] + (sp == 0 ? bsum : 0.f)); continue; }
+        float v = alpha * acc[i][j][r] + bsum;
+        if (g.accumulate) v += C[ci];
+        C[ci] = v;
+      }
+    }
+}
+
 __global__ void colsum_kernel(const float* __restrict__ X, int ld, int M, int N, float* out, float* out2, int rows_per_block) {
   __shared__ float red[4][64];
   int c = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -201,11 +356,87 @@ extern "C" int mmda_gemm(const mmda_gemm_args* a, void* stream) {
     if (!contiguous) splitk = 1;
     else if (hipMemsetAsync(a->C, 0, sizeof(float) * (size_t)a->M * a->N * a->batch, s) != hipSuccess) return MMDA_ELAUNCH;
   }
+  // large aligned bf16 GEMMs -> 128x128 tile kernel with 16-byte staging loads
+  const bool aligned = ((a->lda | a->ldb | a->K) & 3) == 0 && (((uintptr_t)a->A | (uintptr_t)a->B) & 15) == 0 &&
+                       ((a->strideA | a->strideB) & 3) == 0 && (!a->transA || (a->M & 3) == 0) && (a->transB || (a->N & 3) == 0);
+  static const bool use128 = []() { const char* e = getenv("MMDA_GEMM128"); return !(e && e[0] == '0'); }();   // A/B switch (tools/)
+  if (use128 && a->mode == MMDA_BF16 && plain_epilogue && aligned && !a->A2 && !a->gather && a->M >= 128 && a->N >= 128) {
+    const int tiles128 = ceil_div(a->N, TN) * ceil_div(a->M, TM) * a->batch;
+    int sk = 1;
+    if (nk >= 8 && tiles128 <= 256) {
+      sk = (512 + tiles128 - 1) / tiles128;
+      if (sk > nk / 2) sk = nk / 2;
+      if (sk > 64) sk = 64;
+      if (sk < 1) sk = 1;
+    }
+    if (sk > 1 && !a->accumulate) {
+      bool contiguous = (a->ldc == a->N) && (a->batch == 1 || a->strideC == (int64_t)a->M * a->N);
+      if (!contiguous) sk = 1;
+      else if (splitk <= 1 && hipMemsetAsync(a->C, 0, sizeof(float) * (size_t)a->M * a->N * a->batch, s) != hipSuccess) return MMDA_ELAUNCH;
+    }
+    dim3 grid128(ceil_div(a->N, TN), ceil_div(a->M, TM), a->batch * sk);
+    if (grid128.y > 65535 || grid128.z > 65535) return MMDA_EINVAL;
+    if (!a->transA && a->transB) hipLaunchKernelGGL((gemm128_bf16_kernel<false, true>), grid128, dim3(256), 0, s, *a, sk);
+    else if (!a->transA && !a->transB) hipLaunchKernelGGL((gemm128_bf16_kernel<false, false>), grid128, dim3(256), 0, s, *a, sk);
+    else if (a->transA && !a->transB) hipLaunchKernelGGL((gemm128_bf16_kernel<true, false>), grid128, dim3(256), 0, s, *a, sk);
+    else hipLaunchKernelGGL((gemm128_bf16_kernel<true, true>), grid128, dim3(256), 0, s, *a, sk);
+    MMDA_CHECK_LAUNCH("mmda_gemm(128)");
+    return MMDA_OK;
+  }
   dim3 grid(ceil_div(a->N, BN), ceil_div(a->M, BM), a->batch * splitk);
   if (grid.y > 65535 || grid.z > 65535) return MMDA_EINVAL;
   if (a->mode == MMDA_BF16) hipLaunchKernelGGL(gemm_kernel<MMDA_BF16>, grid, dim3(256), 0, s, *a, splitk);
   else hipLaunchKernelGGL(gemm_kernel<MMDA_F32>, grid, dim3(256), 0, s, *a, splitk);
   MMDA_CHECK_LAUNCH("mmda_gemm");
+  return MMDA_OK;
+}
+
+extern "C" int mmda_gemm_grouped(const mmda_gemm_args* args, int n, void* stream) {
+  if (!args || n < 0) return MMDA_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  for (int base = 0; base < n; base += GROUP_MAX) {
+    GroupLaunch G;
+    G.n = 0;
+    int blocks = 0;
+    const int cnt = (n - base) < GROUP_MAX ? (n - base) : GROUP_MAX;
+    // size split-K so that the whole group offers ~4 workgroups per CU
+    int tiles_total = 0;
+    for (int i = 0; i < cnt; ++i) {
+      const mmda_gemm_args& a = args[base + i];
+      if (!a.A || !a.B || !a.C || a.M < 0 || a.N < 0 || a.K < 0 || a.batch < 0 || (a.gather && a.transA)) return MMDA_EINVAL;
+      if (a.mode != MMDA_F32 && a.mode != MMDA_BF16) return MMDA_EINVAL;
+      tiles_total += ceil_div(a.N, BN) * ceil_div(a.M, BM) * a.batch;
+    }
+    for (int i = 0; i < cnt; ++i) {
+      const mmda_gemm_args& a = args[base + i];
+      if (a.M == 0 || a.N == 0 || a.batch == 0) continue;
+      const int k = G.n++;
+      G.p[k] = a;
+      G.tx[k] = ceil_div(a.N, BN); G.ty[k] = ceil_div(a.M, BM);
+      const int nk = ceil_div(a.K, BK);
+      int sk = 1;
+      const bool plain = a.act == MMDA_ACT_NONE && a.drop_p <= 0.f && !a.gate;
+      if (plain && nk >= 8 && tiles_total < 1024) {
+        sk = (1024 + tiles_total - 1) / tiles_total;
+        if (sk > nk / 2) sk = nk / 2;
+        if (sk > 32) sk = 32;
+        if (sk < 1) sk = 1;
+      }
+      if (sk > 1 && !a.accumulate) {
+        bool contiguous = (a.ldc == a.N) && (a.batch == 1 || a.strideC == (int64_t)a.M * a.N);
+        if (!contiguous) sk = 1;
+        else if (hipMemsetAsync(a.C, 0, sizeof(float) * (size_t)a.M * a.N * a.batch, s) != hipSuccess) return MMDA_ELAUNCH;
+      }
+      G.splitk[k] = sk;
+      G.start[k] = blocks;
+      blocks += G.tx[k] * G.ty[k] * a.batch * sk;
+    }
+    for (int k = G.n; k <= GROUP_MAX; ++k) G.start[k] = blocks;
+    for (int k = G.n; k < GROUP_MAX; ++k) { G.p[k] = G.p[0]; G.tx[k] = G.ty[k] = G.splitk[k] = 1; }
+    if (blocks == 0) continue;
+    hipLaunchKernelGGL(gemm_grouped_kernel, dim3(blocks), dim3(256), 0, s, G);
+    MMDA_CHECK_LAUNCH("mmda_gemm_grouped");
+  }
   return MMDA_OK;
 }
 

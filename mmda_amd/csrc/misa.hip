@@ -227,7 +227,15 @@ int64_t layout(mmda_misa* m, int B, int T, bool commit) {
 }
 
 // ---------------------------------------------------------------------------------------------- GEMM shorthands
-struct Ctx { mmda_misa* m; void* s; int rc = 0; };
+struct Ctx { mmda_misa* m; void* s; int rc = 0; bool grouping = false; std::vector<mmda_gemm_args> pending; };
+
+// independent GEMMs issued between group_begin/group_end go out as ONE grouped launch
+void group_begin(Ctx& c) { c.grouping = true; c.pending.clear(); }
+void group_end(Ctx& c) {
+  c.grouping = false;
+  if (!c.rc && !c.pending.empty()) c.rc = mmda_gemm_grouped(c.pending.data(), (int)c.pending.size(), c.s);
+  c.pending.clear();
+}
 
 void gemm(Ctx& c, int mode, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* Bp, int ldb, float* C,
           int ldc, const float* bias = nullptr, const float* bias2 = nullptr, int acc = 0, int act = 0, int batch = 1,
@@ -238,7 +246,8 @@ void gemm(Ctx& c, int mode, int tA, int tB, int M, int N, int K, const float* A,
   g.mode = mode; g.transA = tA; g.transB = tB; g.M = M; g.N = N; g.K = K; g.batch = batch;
   g.A = A; g.lda = lda; g.strideA = sA; g.B = Bp; g.ldb = ldb; g.strideB = sB; g.C = C; g.ldc = ldc; g.strideC = sC;
   g.bias = bias; g.bias2 = bias2; g.strideBias = sBias; g.accumulate = acc; g.act = act;
-  c.rc = mmda_gemm(&g, c.s);
+  if (c.grouping) c.pending.push_back(g);
+  else c.rc = mmda_gemm(&g, c.s);
 }
 // y(M,N) = x(M,K) W(N,K)^T + b
 void lin_fwd(Ctx& c, int mode, int M, int N, int K, const float* x, const float* W, const float* b, float* y, int act = 0) {
@@ -378,6 +387,7 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
   const float* xin[3] = {WS(m->mod[0].x), v, a};
   for (int l = 0; l < 2; ++l) {
     mmda_lstm_desc desc[3];
+    group_begin(x);
     for (int i = 0; i < 3; ++i) {
       Mod& md = m->mod[i]; Rnn& r = md.rnn[l];
       const float* in = l == 0 ? xin[i] : WS(md.normed);
@@ -390,6 +400,7 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
       desc[i].xchg = (m->use_cluster && md.xchg >= 0) ? (void*)WS(md.xchg) : nullptr; desc[i].epoch_base = m->epoch;
     }
     m->epoch += (unsigned)T + 2u;
+    group_end(x);
     if (x.rc) return x.rc;
     ev_rec(m, m->ev_fwd, l, 0, stream);
     x.rc = mmda_lstm_fwd(mode, 3, desc, B, T, lengths, stream);
@@ -613,14 +624,15 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
     x.rc = mmda_lstm_bwd(mode, 3, desc, B, T, lengths, stream);
     ev_rec(m, m->ev_bwd, l == 1 ? 2 : 3, 1, stream);
     if (x.rc) return x.rc;
-    for (int i = 0; i < 3 && !x.rc; ++i) {
+    // all weight / input gradient GEMMs of this layer (three modalities) are independent: one grouped launch
+    group_begin(x);
+    for (int i = 0; i < 3; ++i) {
       Mod& md = m->mod[i]; Rnn& r = md.rnn[l];
       const int H = r.H, G8 = 8 * H;
       const float* dG = WS(md.gates[l]);
       const float* in = l == 0 ? xin[i] : WS(md.normed);
-      // dW_ih (both directions stacked), biases
+      // dW_ih (both directions stacked)
       gemm(x, mode, 1, 0, G8, r.D, R, dG, G8, in, r.D, GG(r.w_ih), r.D, nullptr, nullptr, 1);
-      if (!x.rc) x.rc = mmda_colsum(dG, G8, R, G8, GG(r.b_ih), GG(r.b_hh), stream);
       // dW_hh: forward direction pairs dG[t] with h[t-1]; reverse direction pairs dG[t] with h[t+1] (zero past len)
       if (T > 1) {
         const float* hs_ = WS(md.hseq[l]);
@@ -628,19 +640,26 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
         gemm(x, mode, 1, 0, 4 * H, H, (T - 1) * B, dG + 4 * H, G8, hs_ + (int64_t)B * 2 * H + H, 2 * H, GG(r.w_hh[1]), H, nullptr,
              nullptr, 1);
       }
+      // d(normed) = dG W_ih (layer 2) / d(embedding rows) (text layer 1)
+      if (l == 1) gemm(x, mode, 0, 0, R, r.D, G8, dG, G8, PP(r.w_ih), r.D, WS(md.d_normed), r.D);
+      else if (i == 0) gemm(x, mode, 0, 0, R, r.D, G8, dG, G8, PP(r.w_ih), r.D, WS(md.d_x), r.D);
+    }
+    group_end(x);
+    for (int i = 0; i < 3 && !x.rc; ++i) {
+      Mod& md = m->mod[i]; Rnn& r = md.rnn[l];
+      const int H = r.H, G8 = 8 * H;
+      const float* dG = WS(md.gates[l]);
+      x.rc = mmda_colsum(dG, G8, R, G8, GG(r.b_ih), GG(r.b_hh), stream);
+      if (x.rc) break;
       if (l == 1) {
-        // d(normed) = dG W_ih ; then the inter-layer LayerNorm backward gives d(hseq of layer 1)
-        gemm(x, mode, 0, 0, R, r.D, G8, dG, G8, PP(r.w_ih), r.D, WS(md.d_normed), r.D);
-        if (!x.rc) {
-          mmda_ln_bwd_args lb = {};
-          lb.rows = R; lb.n = 2 * H; lb.dy = WS(md.d_normed); lb.x = WS(md.hseq[0]); lb.gamma = PP(md.ln_w);
-          lb.mean = WS(md.ln_mean); lb.rstd = WS(md.ln_rstd); lb.d_x = WS(md.d_hseq1); lb.dgamma = GG(md.ln_w); lb.dbeta = GG(md.ln_b);
-          x.rc = mmda_layernorm_bwd(&lb, stream);
-        }
+        // the inter-layer LayerNorm backward gives d(hseq of layer 1)
+        mmda_ln_bwd_args lb = {};
+        lb.rows = R; lb.n = 2 * H; lb.dy = WS(md.d_normed); lb.x = WS(md.hseq[0]); lb.gamma = PP(md.ln_w);
+        lb.mean = WS(md.ln_mean); lb.rstd = WS(md.ln_rstd); lb.d_x = WS(md.d_hseq1); lb.dgamma = GG(md.ln_w); lb.dbeta = GG(md.ln_b);
+        x.rc = mmda_layernorm_bwd(&lb, stream);
       } else if (i == 0) {
         // text: gradient w.r.t. the embedding rows, scattered densely into embed.weight.grad (sparse=False)
-        gemm(x, mode, 0, 0, R, r.D, G8, dG, G8, PP(r.w_ih), r.D, WS(md.d_x), r.D);
-        if (!x.rc) x.rc = mmda_embed_scatter_add(GG(m->embed), t_ids, R, c.d_t, WS(md.d_x), stream);
+        x.rc = mmda_embed_scatter_add(GG(m->embed), t_ids, R, c.d_t, WS(md.d_x), stream);
       }
     }
     if (x.rc) return x.rc;

@@ -53,6 +53,45 @@ def test_gemm_nn_tn_accumulate_alpha(mode):
     assert relerr(out, C0 - 0.5 * dY.t() @ X) < TOL[mode]
 
 
+@pytest.mark.parametrize("shape", ["tn_dwih", "nn_dx", "tn_dwhh_offsets", "nt_small_k"])
+def test_gemm_128_tile_kernel_lstm_shapes(shape):
+    """The aligned bf16 fast kernel (128x128 tile, 16-byte staging) on the LSTM-sized GEMMs of the backward pass,
+    including split-K and sub-matrix (row/column offset) operands."""
+    from mmda_amd import ops, _lib
+    import ctypes as C
+    torch.manual_seed(13)
+    d = dev()
+    T, B, H, D = 50, 32, 300, 600
+    R = T * B
+    if shape == "tn_dwih":          # dW_ih (8H, D) += dG^T X
+        dG = torch.randn(R, 8 * H) * 0.1; X = torch.randn(R, D)
+        C0 = torch.randn(8 * H, D)
+        out = ops.gemm(dG.to(d), X.to(d), mode="bf16", transA=True, transB=False, out=C0.clone().to(d), accumulate=True)
+        assert relerr(out, C0 + dG.t() @ X) < 1e-2
+    elif shape == "nn_dx":          # dX (R, D) = dG W_ih
+        dG = torch.randn(R, 8 * H) * 0.1; W = torch.randn(8 * H, D) / math.sqrt(D)
+        out = ops.gemm(dG.to(d), W.to(d), mode="bf16", transB=False)
+        assert relerr(out, dG @ W) < 1e-2
+    elif shape == "nt_small_k":     # gates = X W^T + b, K = 300 (9 full k-tiles + 12)
+        X = torch.randn(R, 300); W = torch.randn(8 * H, 300) / math.sqrt(300); b = torch.randn(8 * H)
+        out = ops.gemm(X.to(d), W.to(d), mode="bf16", bias=b.to(d))
+        assert relerr(out, X @ W.t() + b) < 1e-2
+    else:                           # dW_hh: dG[1:, :, fwd] with hseq[:-1, :, :H]; and the reverse pairing, in place on views
+        dG = (torch.randn(T, B, 2, 4 * H) * 0.1); hs = torch.randn(T, B, 2 * H)
+        ref_f = dG[1:, :, 0].reshape(-1, 4 * H).t() @ hs[:-1, :, :H].reshape(-1, H)
+        ref_r = dG[:-1, :, 1].reshape(-1, 4 * H).t() @ hs[1:, :, H:].reshape(-1, H)
+        dGd, hsd = dG.to(d), hs.to(d)
+        lib = _lib.load()
+        for ref, a_off, b_off in ((ref_f, B * 8 * H, 0), (ref_r, 4 * H, B * 2 * H + H)):
+            out = torch.zeros(4 * H, H, device=d)
+            g = _lib.GemmArgs()
+            g.mode = 1; g.transA = 1; g.transB = 0; g.M = 4 * H; g.N = H; g.K = (T - 1) * B; g.batch = 1
+            g.A = dGd.data_ptr() + 4 * a_off; g.lda = 8 * H; g.B = hsd.data_ptr() + 4 * b_off; g.ldb = 2 * H
+            g.C = out.data_ptr(); g.ldc = H; g.accumulate = 1
+            _lib.check(lib.mmda_gemm(C.byref(g), _lib.stream_ptr()))
+            assert relerr(out, ref) < 1e-2
+
+
 def test_gemm_batched_strided_and_act_gather():
     from mmda_amd import ops
     torch.manual_seed(2)
