@@ -62,6 +62,9 @@ typedef struct mmda_gemm_args {
   float drop_p; uint64_t drop_seed; int drop_site;
   const float* gate; int ldgate; float gate_scale;
   float alpha;                                  /* scales the product before bias/accumulate; 0 is read as 1 */
+  float* bias_grad; float* bias_grad2;          /* optional (transA=1 weight-gradient GEMMs): bias_grad[m] += sum_k A[k,m], i.e. the
+                                                   column sums of dY come out of the same MFMA pass as a virtual all-ones column
+                                                   of B; bias_grad2 receives the same sums (b_ih and b_hh share a gradient) */
 } mmda_gemm_args;
 int mmda_gemm(const mmda_gemm_args* args, void* stream);
 /* n independent GEMMs (any mix of shapes / layouts / modes) in one launch; results as n mmda_gemm calls in any order */
@@ -114,6 +117,9 @@ int mmda_layernorm_bwd(const mmda_ln_bwd_args* a, void* stream);
  * mmda_lstm_pack_whh (once per optimizer step).  Packed sizes from mmda_lstm_packed_bytes. */
 int64_t mmda_lstm_packed_bytes(int mode, int H, int backward);
 int mmda_lstm_pack_whh(int mode, int H, const float* whh, void* packed_fwd, void* packed_bwd, void* stream);
+/* n (<= 16) matrices in one launch */
+int mmda_lstm_pack_whh_multi(int mode, int n, const int* H, const float* const* whh, void* const* packed_fwd,
+                             void* const* packed_bwd, void* stream);
 
 typedef struct mmda_lstm_desc {
   int H;

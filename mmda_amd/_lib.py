@@ -29,7 +29,7 @@ class GemmArgs(C.Structure):
                 ("accumulate", C.c_int), ("act", C.c_int),
                 ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_site", C.c_int),
                 ("gate", C.c_void_p), ("ldgate", C.c_int), ("gate_scale", C.c_float),
-                ("alpha", C.c_float)]
+                ("alpha", C.c_float), ("bias_grad", C.c_void_p), ("bias_grad2", C.c_void_p)]
 
 
 class LnArgs(C.Structure):
@@ -79,6 +79,8 @@ SIGNATURES = {
     "mmda_lstm_xchg_bytes": (_I64, [_I, _I]),
     "mmda_debug_set_lstm_stamps": (_I, [_P]),
     "mmda_lstm_pack_whh": (_I, [_I, _I, _P, _P, _P, _P]),
+    "mmda_lstm_pack_whh_multi": (_I, [_I, _I, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                      C.POINTER(C.c_void_p), _P]),
     "mmda_lstm_fwd": (_I, [_I, _I, C.POINTER(LstmDesc), _I, _I, _P, _P]),
     "mmda_lstm_bwd": (_I, [_I, _I, C.POINTER(LstmDesc), _I, _I, _P, _P]),
     "mmda_attn_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _U64, _I, _P]),

@@ -66,6 +66,7 @@ __device__ __forceinline__ void gemm_body(const mmda_gemm_args& g, int splitk, u
       k = k0 + b_k[i];
       float u = 0.f;
       if (n < N && k < K) u = g.transB ? Bm[(int64_t)n * g.ldb + k] : Bm[(int64_t)k * g.ldb + n];
+      if (g.bias_grad && n == N && k < K) u = 1.0f;          // virtual all-ones column: its output is the bias gradient
       rb[i] = u;
     }
   };
@@ -134,6 +135,17 @@ __device__ __forceinline__ void gemm_body(const mmda_gemm_args& g, int splitk, u
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       int n = col0 + wn * 32 + j * 16 + (lane & 15);
+      if (g.bias_grad && n == N) {                           // column sums of A (= dY): accumulate into the bias gradient(s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int m = row0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r;
+          if (m < M) {
+            atomicAdd(&g.bias_grad[bz * g.strideBias + m], acc[i][j][r]);
+            if (g.bias_grad2) atomicAdd(&g.bias_grad2[bz * g.strideBias + m], acc[i][j][r]);
+          }
+        }
+        continue;
+      }
       if (n >= N) continue;
       float bsum = 0.f;
       if (bias) bsum += bias[n];
@@ -182,8 +194,10 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(GroupLaunch G) {
     if (k < G.n && (int)blockIdx.x >= G.start[k]) i = k;
   const int local = blockIdx.x - G.start[i];
   const int bx = local % G.tx[i], by = (local / G.tx[i]) % G.ty[i], bzz = local / (G.tx[i] * G.ty[i]);
-  if (G.p[i].mode == MMDA_BF16) gemm_body<MMDA_BF16>(G.p[i], G.splitk[i], smem, bx, by, bzz);
-  else gemm_body<MMDA_F32>(G.p[i], G.splitk[i], smem, bx, by, bzz);
+  const mmda_gemm_args g = G.p[i];      // one copy into SGPRs; indexing the kernarg array inside the k-loop would re-load fields
+  const int sk = G.splitk[i];
+  if (g.mode == MMDA_BF16) gemm_body<MMDA_BF16>(g, sk, smem, bx, by, bzz);
+  else gemm_body<MMDA_F32>(g, sk, smem, bx, by, bzz);
 }
 
 // ------------------------------------------------------------------------------------------------ 128x128 bf16 tile
@@ -339,7 +353,9 @@ extern "C" int mmda_gemm(const mmda_gemm_args* a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   // Split-K: these GEMMs are small (B=32: a few dozen output tiles) with long reductions (K = T*B for weight gradients,
   // 2048 for the FFN, 4H for the projections); one block per tile would leave 250 CUs idle behind a serial k-loop.
-  const int tiles = ceil_div(a->N, BN) * ceil_div(a->M, BM) * a->batch;
+  const int Neff = a->N + (a->bias_grad ? 1 : 0);          // + the virtual ones column
+  if (a->bias_grad && !a->transA) return MMDA_EINVAL;
+  const int tiles = ceil_div(Neff, BN) * ceil_div(a->M, BM) * a->batch;
   const int nk = ceil_div(a->K, BK);
   int splitk = 1;
   const bool plain_epilogue = a->act == MMDA_ACT_NONE && a->drop_p <= 0.f && !a->gate;
@@ -360,7 +376,7 @@ extern "C" int mmda_gemm(const mmda_gemm_args* a, void* stream) {
   const bool aligned = ((a->lda | a->ldb | a->K) & 3) == 0 && (((uintptr_t)a->A | (uintptr_t)a->B) & 15) == 0 &&
                        ((a->strideA | a->strideB) & 3) == 0 && (!a->transA || (a->M & 3) == 0) && (a->transB || (a->N & 3) == 0);
   static const bool use128 = []() { const char* e = getenv("MMDA_GEMM128"); return !(e && e[0] == '0'); }();   // A/B switch (tools/)
-  if (use128 && a->mode == MMDA_BF16 && plain_epilogue && aligned && !a->A2 && !a->gather && a->M >= 128 && a->N >= 128) {
+  if (use128 && a->mode == MMDA_BF16 && plain_epilogue && aligned && !a->A2 && !a->gather && !a->bias_grad && a->M >= 128 && a->N >= 128) {
     const int tiles128 = ceil_div(a->N, TN) * ceil_div(a->M, TM) * a->batch;
     int sk = 1;
     if (nk >= 8 && tiles128 <= 256) {
@@ -383,7 +399,7 @@ extern "C" int mmda_gemm(const mmda_gemm_args* a, void* stream) {
     MMDA_CHECK_LAUNCH("mmda_gemm(128)");
     return MMDA_OK;
   }
-  dim3 grid(ceil_div(a->N, BN), ceil_div(a->M, BM), a->batch * splitk);
+  dim3 grid(ceil_div(Neff, BN), ceil_div(a->M, BM), a->batch * splitk);
   if (grid.y > 65535 || grid.z > 65535) return MMDA_EINVAL;
   if (a->mode == MMDA_BF16) hipLaunchKernelGGL(gemm_kernel<MMDA_BF16>, grid, dim3(256), 0, s, *a, splitk);
   else hipLaunchKernelGGL(gemm_kernel<MMDA_F32>, grid, dim3(256), 0, s, *a, splitk);
@@ -405,14 +421,15 @@ extern "C" int mmda_gemm_grouped(const mmda_gemm_args* args, int n, void* stream
       const mmda_gemm_args& a = args[base + i];
       if (!a.A || !a.B || !a.C || a.M < 0 || a.N < 0 || a.K < 0 || a.batch < 0 || (a.gather && a.transA)) return MMDA_EINVAL;
       if (a.mode != MMDA_F32 && a.mode != MMDA_BF16) return MMDA_EINVAL;
-      tiles_total += ceil_div(a.N, BN) * ceil_div(a.M, BM) * a.batch;
+      if (a.bias_grad && !a.transA) return MMDA_EINVAL;
+      tiles_total += ceil_div(a.N + (a.bias_grad ? 1 : 0), BN) * ceil_div(a.M, BM) * a.batch;
     }
     for (int i = 0; i < cnt; ++i) {
       const mmda_gemm_args& a = args[base + i];
       if (a.M == 0 || a.N == 0 || a.batch == 0) continue;
       const int k = G.n++;
       G.p[k] = a;
-      G.tx[k] = ceil_div(a.N, BN); G.ty[k] = ceil_div(a.M, BM);
+      G.tx[k] = ceil_div(a.N + (a.bias_grad ? 1 : 0), BN); G.ty[k] = ceil_div(a.M, BM);
       const int nk = ceil_div(a.K, BK);
       int sk = 1;
       const bool plain = a.act == MMDA_ACT_NONE && a.drop_p <= 0.f && !a.gate;

@@ -73,6 +73,43 @@ __global__ void pack_kernel(int H, const float* __restrict__ W, void* outF, void
   }
 }
 
+struct PackMulti { int H[16]; const float* W[16]; void* F[16]; void* Bk[16]; int start[17]; int n; };
+template <int MODE>
+__global__ void pack_multi_kernel(PackMulti P) {
+  // blockIdx.x -> matrix through the prefix table; each matrix gets ceil(elements/256) blocks
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < 16; ++k)
+    if (k < P.n && (int)blockIdx.x >= P.start[k]) i = k;
+  const int H = P.H[i];
+  const float* __restrict__ W = P.W[i];
+  const int Hp = pad16(H), nHT = Hp / 16;
+  const int per = (MODE == MMDA_BF16) ? 8 : 4;
+  const int kspan = (MODE == MMDA_BF16) ? 32 : 16;
+  const int KS = (MODE == MMDA_BF16) ? pad32(H) / 32 : Hp / 16;
+  const int KSB = 4 * Hp / kspan;
+  const int64_t nF = (int64_t)nHT * 4 * KS * 64 * per, nB = (int64_t)nHT * KSB * 64 * per;
+  const int64_t e0 = (int64_t)(blockIdx.x - P.start[i]) * blockDim.x + threadIdx.x;
+  if (e0 >= nF + nB) return;
+  const bool bwd = e0 >= nF;
+  const int64_t e = bwd ? e0 - nF : e0;
+  const int j = e % per, lane = (e / per) % 64;
+  const int64_t frag = e / (per * 64);
+  const int koff = (MODE == MMDA_BF16) ? 8 * (lane >> 4) + j : 4 * j + (lane >> 4);
+  float v = 0.f;
+  if (!bwd) {
+    int ks = frag % KS, tg = frag / KS, g = tg & 3, ht = tg >> 2;
+    int n = ht * 16 + (lane & 15), k = ks * kspan + koff;
+    if (n < H && k < H) v = W[(int64_t)(g * H + n) * H + k];
+  } else {
+    int ks = frag % KSB, ht = frag / KSB, kk = ks * kspan + koff;
+    int g = kk / Hp, jj = kk % Hp, n = ht * 16 + (lane & 15);
+    if (jj < H && n < H) v = W[(int64_t)(g * H + jj) * H + n];
+  }
+  if (MODE == MMDA_BF16) reinterpret_cast<unsigned short*>(bwd ? P.Bk[i] : P.F[i])[e] = f2bf(v);
+  else reinterpret_cast<float*>(bwd ? P.Bk[i] : P.F[i])[e] = v;
+}
+
 template <int MODE> __device__ __forceinline__ float sig_(float x) { return MODE == MMDA_BF16 ? sigmoid_fast(x) : sigmoidf_(x); }
 template <int MODE> __device__ __forceinline__ float tanh_(float x) { return MODE == MMDA_BF16 ? tanh_fast(x) : tanhf_(x); }
 
@@ -427,6 +464,28 @@ extern "C" int mmda_lstm_pack_whh(int mode, int H, const float* whh, void* packe
   else if (mode == MMDA_F32) hipLaunchKernelGGL(pack_kernel<MMDA_F32>, dim3(blocks), dim3(256), 0, s, H, whh, packed_fwd, packed_bwd);
   else return MMDA_EINVAL;
   MMDA_CHECK_LAUNCH("mmda_lstm_pack_whh");
+  return MMDA_OK;
+}
+
+extern "C" int mmda_lstm_pack_whh_multi(int mode, int n, const int* H, const float* const* whh, void* const* packed_fwd,
+                                        void* const* packed_bwd, void* stream) {
+  if (n <= 0 || n > 16 || !H || !whh || !packed_fwd || !packed_bwd || (mode != MMDA_BF16 && mode != MMDA_F32)) return MMDA_EINVAL;
+  PackMulti P;
+  P.n = n;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    if (H[i] <= 0 || H[i] > 512 || !whh[i] || !packed_fwd[i] || !packed_bwd[i]) return MMDA_EINVAL;
+    P.H[i] = H[i]; P.W[i] = whh[i]; P.F[i] = packed_fwd[i]; P.Bk[i] = packed_bwd[i];
+    P.start[i] = blocks;
+    int64_t total = (mmda_lstm_packed_bytes(mode, H[i], 0) + mmda_lstm_packed_bytes(mode, H[i], 1)) / (mode == MMDA_BF16 ? 2 : 4);
+    blocks += (int)((total + 255) / 256);
+  }
+  for (int i = n; i < 16; ++i) { P.H[i] = P.H[0]; P.W[i] = P.W[0]; P.F[i] = P.F[0]; P.Bk[i] = P.Bk[0]; }
+  for (int i = n; i <= 16; ++i) P.start[i] = blocks;
+  hipStream_t s = (hipStream_t)stream;
+  if (mode == MMDA_BF16) hipLaunchKernelGGL(pack_multi_kernel<MMDA_BF16>, dim3(blocks), dim3(256), 0, s, P);
+  else hipLaunchKernelGGL(pack_multi_kernel<MMDA_F32>, dim3(blocks), dim3(256), 0, s, P);
+  MMDA_CHECK_LAUNCH("mmda_lstm_pack_whh_multi");
   return MMDA_OK;
 }
 

@@ -259,8 +259,9 @@ void lin_dx(Ctx& c, int mode, int M, int N, int K, const float* dy, const float*
 }
 // dW(N,K) += dy(M,N)^T x(M,K);  db(N) += colsum(dy)
 void lin_dw(Ctx& c, int mode, int M, int N, int K, const float* dy, const float* x, float* dW, float* db) {
-  gemm(c, mode, 1, 0, N, K, M, dy, N, x, K, dW, K, nullptr, nullptr, 1);
-  if (!c.rc && db) c.rc = mmda_colsum(dy, N, M, N, db, nullptr, c.s);
+  mmda_gemm_args e = {};
+  e.bias_grad = db;                 // the bias gradient rides along as a virtual ones-column of the same GEMM
+  gemm(c, mode, 1, 0, N, K, M, dy, N, x, K, dW, K, nullptr, nullptr, 1, 0, 1, 0, 0, 0, 0, &e);
 }
 
 __global__ void total_loss_kernel(float* L, float dw, float sw, float rw, float cw, int use_conf) {
@@ -374,13 +375,18 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
   m->training = training; m->seed = seed;
   const float p_tf = training ? c.fusion_dropout : 0.f, p_cls = training ? c.dropout : 0.f;
 
-  // W_hh -> MFMA fragment order (weights changed since the last step)
-  for (int i = 0; i < 3 && !x.rc; ++i)
-    for (int l = 0; l < 2 && !x.rc; ++l)
-      for (int d = 0; d < 2 && !x.rc; ++d) {
-        Rnn& r = m->mod[i].rnn[l];
-        x.rc = mmda_lstm_pack_whh(mode, r.H, PP(r.w_hh[d]), WS(r.pack_f[d]), WS(r.pack_b[d]), stream);
-      }
+  // W_hh -> MFMA fragment order (weights changed since the last step): all twelve matrices in one launch
+  {
+    int Hs[12]; const float* Wp[12]; void* Fp[12]; void* Bp[12];
+    int k = 0;
+    for (int i = 0; i < 3; ++i)
+      for (int l = 0; l < 2; ++l)
+        for (int d = 0; d < 2; ++d, ++k) {
+          Rnn& r = m->mod[i].rnn[l];
+          Hs[k] = r.H; Wp[k] = PP(r.w_hh[d]); Fp[k] = WS(r.pack_f[d]); Bp[k] = WS(r.pack_b[d]);
+        }
+    x.rc = mmda_lstm_pack_whh_multi(mode, 12, Hs, Wp, Fp, Bp, stream);
+  }
   if (x.rc) return x.rc;
   // embedding rows (models.py:201)
   x.rc = mmda_embed_gather(PP(m->embed), t_ids, R, c.d_t, WS(m->mod[0].x), stream);
@@ -586,13 +592,21 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
   gemm(x, fmode, 0, 0, B, hs, hs, WS(m->d_recon), hs, PP(m->rec_w), hs, WS(m->d_x6), hs, nullptr, nullptr, 1, 0, 3, BH, (int64_t)hs * hs, BH);
   gemm(x, fmode, 0, 0, B, hs, hs, WS(m->d_recon), hs, PP(m->rec_w), hs, WS(m->d_x6 + 3 * BH), hs, nullptr, nullptr, 1, 0, 3, BH,
        (int64_t)hs * hs, BH);
-  gemm(x, fmode, 1, 0, hs, hs, B, WS(m->d_recon), hs, WS(m->rsum), hs, GG(m->rec_w), hs, nullptr, nullptr, 1, 0, 3, BH, BH, (int64_t)hs * hs);
-  for (int i = 0; i < 3 && !x.rc; ++i) x.rc = mmda_colsum(WS(m->d_recon + i * BH), hs, B, hs, GG(m->rec_b + i * hs), nullptr, stream);
+  {
+    mmda_gemm_args e = {};
+    e.bias_grad = GG(m->rec_b);      // strideBias = hs: one bias gradient per batched problem
+    gemm(x, fmode, 1, 0, hs, hs, B, WS(m->d_recon), hs, WS(m->rsum), hs, GG(m->rec_w), hs, nullptr, nullptr, 1, 0, 3, BH, BH, (int64_t)hs * hs,
+         hs, &e);
+  }
   // sigmoid of private/shared
   if (!x.rc) x.rc = mmda_sigmoid_bwd_inplace(WS(m->d_x6), WS(m->x6), 6 * BH, stream);
   gemm(x, fmode, 0, 0, B, hs, hs, WS(m->d_x6), hs, PP(m->priv_w), hs, WS(m->d_orig), hs, nullptr, nullptr, 1, 0, 3, BH, (int64_t)hs * hs, BH);
-  gemm(x, fmode, 1, 0, hs, hs, B, WS(m->d_x6), hs, WS(m->orig), hs, GG(m->priv_w), hs, nullptr, nullptr, 1, 0, 3, BH, BH, (int64_t)hs * hs);
-  for (int i = 0; i < 3 && !x.rc; ++i) x.rc = mmda_colsum(WS(m->d_x6 + i * BH), hs, B, hs, GG(m->priv_b + i * hs), nullptr, stream);
+  {
+    mmda_gemm_args e = {};
+    e.bias_grad = GG(m->priv_b);
+    gemm(x, fmode, 1, 0, hs, hs, B, WS(m->d_x6), hs, WS(m->orig), hs, GG(m->priv_w), hs, nullptr, nullptr, 1, 0, 3, BH, BH, (int64_t)hs * hs,
+         hs, &e);
+  }
   lin_dx(x, fmode, 3 * B, hs, hs, WS(m->d_x6 + 3 * BH), PP(m->sh_w), WS(m->d_orig), 1);
   lin_dw(x, fmode, 3 * B, hs, hs, WS(m->d_x6 + 3 * BH), WS(m->orig), GG(m->sh_w), GG(m->sh_b));
   // projections
@@ -631,8 +645,12 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
       const int H = r.H, G8 = 8 * H;
       const float* dG = WS(md.gates[l]);
       const float* in = l == 0 ? xin[i] : WS(md.normed);
-      // dW_ih (both directions stacked)
-      gemm(x, mode, 1, 0, G8, r.D, R, dG, G8, in, r.D, GG(r.w_ih), r.D, nullptr, nullptr, 1);
+      // dW_ih (both directions stacked); db_ih = db_hh = column sums of dG ride along as a virtual ones-column
+      {
+        mmda_gemm_args e = {};
+        e.bias_grad = GG(r.b_ih); e.bias_grad2 = GG(r.b_hh);
+        gemm(x, mode, 1, 0, G8, r.D, R, dG, G8, in, r.D, GG(r.w_ih), r.D, nullptr, nullptr, 1, 0, 1, 0, 0, 0, 0, &e);
+      }
       // dW_hh: forward direction pairs dG[t] with h[t-1]; reverse direction pairs dG[t] with h[t+1] (zero past len)
       if (T > 1) {
         const float* hs_ = WS(md.hseq[l]);
@@ -647,10 +665,7 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
     group_end(x);
     for (int i = 0; i < 3 && !x.rc; ++i) {
       Mod& md = m->mod[i]; Rnn& r = md.rnn[l];
-      const int H = r.H, G8 = 8 * H;
-      const float* dG = WS(md.gates[l]);
-      x.rc = mmda_colsum(dG, G8, R, G8, GG(r.b_ih), GG(r.b_hh), stream);
-      if (x.rc) break;
+      const int H = r.H;
       if (l == 1) {
         // the inter-layer LayerNorm backward gives d(hseq of layer 1)
         mmda_ln_bwd_args lb = {};

@@ -21,7 +21,7 @@ def _f(t):
 
 
 def gemm(A, B, *, mode="fp32", transA=False, transB=True, bias=None, bias2=None, out=None, accumulate=False, act="none",
-         A2=None, gather=None, alpha=1.0, drop_p=0.0, seed=0, site=0, gate=None, gate_scale=1.0):
+         A2=None, gather=None, alpha=1.0, drop_p=0.0, seed=0, site=0, gate=None, gate_scale=1.0, bias_grad=None, bias_grad2=None):
     """C = act(alpha * opA(A (+A2)) @ opB(B) + bias + bias2 (+C)).  A,B 2-D or 3-D (batched, uniform strides)."""
     lib = load()
     batched = A.dim() == 3
@@ -51,6 +51,9 @@ def gemm(A, B, *, mode="fp32", transA=False, transB=True, bias=None, bias2=None,
     g.accumulate = int(accumulate); g.act = ACT[act]
     g.drop_p = drop_p; g.drop_seed = seed; g.drop_site = site
     g.gate = ptr(gate); g.ldgate = N; g.gate_scale = gate_scale; g.alpha = alpha
+    g.bias_grad = ptr(bias_grad); g.bias_grad2 = ptr(bias_grad2)
+    if bias_grad is not None and bias_grad.dim() == 2:
+        g.strideBias = bias_grad.stride(0)
     check(lib.mmda_gemm(C.byref(g), stream_ptr()), "mmda_gemm")
     return out
 

@@ -92,6 +92,23 @@ def test_gemm_128_tile_kernel_lstm_shapes(shape):
             assert relerr(out, ref) < 1e-2
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(1600, 2400, 300), (192, 128, 128), (32, 12, 768), (96, 128, 2048)])
+def test_gemm_weight_grad_with_fused_bias_grad(mode, M, N, K):
+    """dW += dY^T X and db += colsum(dY) (also db2) out of ONE GEMM: the bias gradient is a virtual all-ones column of X.
+    N multiple of 64 (extra tile column), split-K and non-split shapes."""
+    from mmda_amd import ops
+    torch.manual_seed(14)
+    dY = torch.randn(M, N) * 0.3; X = torch.randn(M, K)
+    dW0 = torch.randn(N, K); db0 = torch.randn(N); db20 = torch.zeros(N)
+    d = dev()
+    db = db0.clone().to(d); db2 = db20.clone().to(d)
+    out = ops.gemm(dY.to(d), X.to(d), mode=mode, transA=True, transB=False, out=dW0.clone().to(d), accumulate=True, bias_grad=db,
+                   bias_grad2=db2)
+    assert relerr(out, dW0 + dY.t() @ X) < TOL[mode]
+    assert relerr(db, db0 + dY.sum(0)) < TOL[mode] and relerr(db2, dY.sum(0)) < TOL[mode]
+
+
 def test_gemm_batched_strided_and_act_gather():
     from mmda_amd import ops
     torch.manual_seed(2)
