@@ -115,11 +115,13 @@ int mmda_layernorm_bwd(const mmda_ln_bwd_args* a, void* stream);
  *
  * Weight packing: W_hh (4H,H) of each direction must first be packed into MFMA fragment order with
  * mmda_lstm_pack_whh (once per optimizer step).  Packed sizes from mmda_lstm_packed_bytes. */
-int64_t mmda_lstm_packed_bytes(int mode, int H, int backward);
+int64_t mmda_lstm_packed_bytes(int mode, int H, int which);   /* which: 0 forward, 1 backward, 2 cluster-backward (bf16 only) */
 int mmda_lstm_pack_whh(int mode, int H, const float* whh, void* packed_fwd, void* packed_bwd, void* stream);
+/* the cluster-backward packing of one matrix (bf16): [(ht*nHT + nt)*2 + ks2][lane][8] */
+int mmda_lstm_pack_whh_cluster(int H, const float* whh, void* packed_c, void* stream);
 /* n (<= 16) matrices in one launch */
 int mmda_lstm_pack_whh_multi(int mode, int n, const int* H, const float* const* whh, void* const* packed_fwd,
-                             void* const* packed_bwd, void* stream);
+                             void* const* packed_bwd, void* const* packed_c /* NULL or per-matrix (bf16) */, void* stream);
 
 typedef struct mmda_lstm_desc {
   int H;
@@ -127,6 +129,8 @@ typedef struct mmda_lstm_desc {
   float* cstash;       /* (T,B,2,H)   cell state after each step (stash) */
   float* hseq;         /* (T,B,2H)    layer output [fwd H | rev H], zero at padded positions */
   const void* wpack[2];/* packed W_hh per direction (forward packing for fwd, backward packing for bwd) */
+  const void* wpack_c[2]; /* backward only, optional: "cluster-backward" packing (mmda_lstm_packed_bytes(mode,H,2)) used by the
+                          resident-weights kernel; NULL -> the streaming backward kernel runs */
   float* utt;          /* (B,4H)      final-h destination / its gradient source in backward */
   int layer;           /* 0 or 1: column block (dir*2+layer)*H of utt */
   const float* d_hseq; /* backward only: (T,B,2H) gradient w.r.t. hseq, or NULL */

@@ -50,7 +50,7 @@ class LnBwdArgs(C.Structure):
 
 class LstmDesc(C.Structure):
     _fields_ = [("H", C.c_int), ("gates", C.c_void_p), ("cstash", C.c_void_p), ("hseq", C.c_void_p),
-                ("wpack", C.c_void_p * 2), ("utt", C.c_void_p), ("layer", C.c_int), ("d_hseq", C.c_void_p),
+                ("wpack", C.c_void_p * 2), ("wpack_c", C.c_void_p * 2), ("utt", C.c_void_p), ("layer", C.c_int), ("d_hseq", C.c_void_p),
                 ("xchg", C.c_void_p), ("epoch_base", C.c_uint32)]
 
 
@@ -80,7 +80,8 @@ SIGNATURES = {
     "mmda_debug_set_lstm_stamps": (_I, [_P]),
     "mmda_lstm_pack_whh": (_I, [_I, _I, _P, _P, _P, _P]),
     "mmda_lstm_pack_whh_multi": (_I, [_I, _I, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
-                                      C.POINTER(C.c_void_p), _P]),
+                                      C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _P]),
+    "mmda_lstm_pack_whh_cluster": (_I, [_I, _P, _P, _P]),
     "mmda_lstm_fwd": (_I, [_I, _I, C.POINTER(LstmDesc), _I, _I, _P, _P]),
     "mmda_lstm_bwd": (_I, [_I, _I, C.POINTER(LstmDesc), _I, _I, _P, _P]),
     "mmda_attn_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _U64, _I, _P]),

@@ -73,7 +73,7 @@ __global__ void pack_kernel(int H, const float* __restrict__ W, void* outF, void
   }
 }
 
-struct PackMulti { int H[16]; const float* W[16]; void* F[16]; void* Bk[16]; int start[17]; int n; };
+struct PackMulti { int H[16]; const float* W[16]; void* F[16]; void* Bk[16]; void* Ck[16]; int start[17]; int n; };
 template <int MODE>
 __global__ void pack_multi_kernel(PackMulti P) {
   // blockIdx.x -> matrix through the prefix table; each matrix gets ceil(elements/256) blocks
@@ -90,7 +90,21 @@ __global__ void pack_multi_kernel(PackMulti P) {
   const int KSB = 4 * Hp / kspan;
   const int64_t nF = (int64_t)nHT * 4 * KS * 64 * per, nB = (int64_t)nHT * KSB * 64 * per;
   const int64_t e0 = (int64_t)(blockIdx.x - P.start[i]) * blockDim.x + threadIdx.x;
-  if (e0 >= nF + nB) return;
+  const int64_t nC = (MODE == MMDA_BF16 && P.Ck[i]) ? (int64_t)nHT * nHT * 2 * 64 * 8 : 0;
+  if (e0 >= nF + nB + nC) return;
+  if (e0 >= nF + nB) {
+    // cluster-backward packing [(ht*nHT + nt)*2 + ks2][lane][8]: k = gate rows of hidden tile ht, n = hidden tile nt
+    const int64_t e = e0 - nF - nB;
+    const int j = e % 8, lane = (e / 8) % 64;
+    const int64_t frag = e / 512;
+    const int ks2 = frag & 1, nt = (frag >> 1) % nHT, ht = (frag >> 1) / nHT;
+    const int kk = ks2 * 32 + 8 * (lane >> 4) + j;
+    const int g = kk >> 4, jl = kk & 15;
+    const int unit = ht * 16 + jl, n = nt * 16 + (lane & 15);
+    float v = (unit < H && n < H) ? W[(int64_t)(g * H + unit) * H + n] : 0.f;
+    reinterpret_cast<unsigned short*>(P.Ck[i])[e] = f2bf(v);
+    return;
+  }
   const bool bwd = e0 >= nF;
   const int64_t e = bwd ? e0 - nF : e0;
   const int j = e % per, lane = (e / per) % 64;
@@ -444,6 +458,7 @@ int lstm_common(int mode, int n, const mmda_lstm_desc* descs, int B, int T, cons
 extern "C" int64_t mmda_lstm_packed_bytes(int mode, int H, int backward) {
   if (H <= 0 || H > 512) return MMDA_EINVAL;
   int Hp = round_up(H, 16), nHT = Hp / 16;
+  if (backward == 2) return mode == MMDA_BF16 ? (int64_t)nHT * nHT * 2 * 64 * 8 * 2 : MMDA_EINVAL;
   if (mode == MMDA_BF16) {
     int KS = round_up(H, 32) / 32, KSB = 4 * Hp / 32;
     return backward ? (int64_t)nHT * KSB * 64 * 8 * 2 : (int64_t)nHT * 4 * KS * 64 * 8 * 2;
@@ -468,7 +483,7 @@ extern "C" int mmda_lstm_pack_whh(int mode, int H, const float* whh, void* packe
 }
 
 extern "C" int mmda_lstm_pack_whh_multi(int mode, int n, const int* H, const float* const* whh, void* const* packed_fwd,
-                                        void* const* packed_bwd, void* stream) {
+                                        void* const* packed_bwd, void* const* packed_c, void* stream) {
   if (n <= 0 || n > 16 || !H || !whh || !packed_fwd || !packed_bwd || (mode != MMDA_BF16 && mode != MMDA_F32)) return MMDA_EINVAL;
   PackMulti P;
   P.n = n;
@@ -476,16 +491,36 @@ extern "C" int mmda_lstm_pack_whh_multi(int mode, int n, const int* H, const flo
   for (int i = 0; i < n; ++i) {
     if (H[i] <= 0 || H[i] > 512 || !whh[i] || !packed_fwd[i] || !packed_bwd[i]) return MMDA_EINVAL;
     P.H[i] = H[i]; P.W[i] = whh[i]; P.F[i] = packed_fwd[i]; P.Bk[i] = packed_bwd[i];
+    P.Ck[i] = (packed_c && mode == MMDA_BF16) ? packed_c[i] : nullptr;
     P.start[i] = blocks;
     int64_t total = (mmda_lstm_packed_bytes(mode, H[i], 0) + mmda_lstm_packed_bytes(mode, H[i], 1)) / (mode == MMDA_BF16 ? 2 : 4);
+    if (P.Ck[i]) total += mmda_lstm_packed_bytes(mode, H[i], 2) / 2;
     blocks += (int)((total + 255) / 256);
   }
-  for (int i = n; i < 16; ++i) { P.H[i] = P.H[0]; P.W[i] = P.W[0]; P.F[i] = P.F[0]; P.Bk[i] = P.Bk[0]; }
+  for (int i = n; i < 16; ++i) { P.H[i] = P.H[0]; P.W[i] = P.W[0]; P.F[i] = P.F[0]; P.Bk[i] = P.Bk[0]; P.Ck[i] = P.Ck[0]; }
   for (int i = n; i <= 16; ++i) P.start[i] = blocks;
   hipStream_t s = (hipStream_t)stream;
   if (mode == MMDA_BF16) hipLaunchKernelGGL(pack_multi_kernel<MMDA_BF16>, dim3(blocks), dim3(256), 0, s, P);
   else hipLaunchKernelGGL(pack_multi_kernel<MMDA_F32>, dim3(blocks), dim3(256), 0, s, P);
   MMDA_CHECK_LAUNCH("mmda_lstm_pack_whh_multi");
+  return MMDA_OK;
+}
+
+extern "C" int mmda_lstm_pack_whh_cluster(int H, const float* whh, void* packed_c, void* stream) {
+  // single-matrix form on top of the multi kernel: forward/backward packings go to scratch-free dummies (not written)
+  if (!whh || !packed_c || H <= 0 || H > 512) return MMDA_EINVAL;
+  PackMulti P;
+  P.n = 1;
+  for (int i = 0; i < 16; ++i) { P.H[i] = H; P.W[i] = whh; P.F[i] = nullptr; P.Bk[i] = nullptr; P.Ck[i] = packed_c; }
+  // only the cluster segment is launched: blocks cover [nF+nB, nF+nB+nC)
+  int64_t nFB = (mmda_lstm_packed_bytes(MMDA_BF16, H, 0) + mmda_lstm_packed_bytes(MMDA_BF16, H, 1)) / 2;
+  int64_t nC = mmda_lstm_packed_bytes(MMDA_BF16, H, 2) / 2;
+  if (nFB % 256) return MMDA_EINVAL;            // fragment counts are multiples of 512 elements
+  int first = (int)(nFB / 256), blocks = (int)((nC + 255) / 256);
+  P.start[0] = -first;                          // shift so that block 0 lands on the cluster segment
+  for (int i = 1; i <= 16; ++i) P.start[i] = blocks;
+  hipLaunchKernelGGL(pack_multi_kernel<MMDA_BF16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P);
+  MMDA_CHECK_LAUNCH("mmda_lstm_pack_whh_cluster");
   return MMDA_OK;
 }
 

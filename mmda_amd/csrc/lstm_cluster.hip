@@ -34,7 +34,8 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 
 struct CDesc {
   int H, Hp, Kp, KS, KSB, nHT, TPW, NC;
-  float* gates; float* cstash; float* hseq; const void* wpack[2]; float* utt; int layer; const float* d_hseq;
+  float* gates; float* cstash; float* hseq; const void* wpack[2]; const void* wpack_c[2]; float* utt; int layer;
+  const float* d_hseq;
   unsigned char* xchg;
   int wg_begin;
 };
@@ -49,8 +50,10 @@ struct CLaunch {
 // xchg layout per descriptor: [0,64) abort word | flags: (dir, group, wg) x 64 B | X: (dir, group, parity) x GROUP x XW bf16
 __host__ __device__ inline size_t xchg_flags_off() { return 64; }
 __host__ __device__ inline size_t xchg_x_off(int ngroups_total, int NC) { return 64 + (size_t)2 * ngroups_total * NC * 64; }
+// one exchange slot = one (direction, group, parity): forward uses GROUP x 4Hp bf16 of it, backward NC x GROUP x Hp
+__host__ __device__ inline size_t xchg_slot(int NC, int Hp) { return (size_t)(NC > 4 ? NC : 4) * GROUP * Hp * 2; }
 __host__ __device__ inline size_t xchg_bytes(int ngroups_total, int NC, int Hp) {
-  return xchg_x_off(ngroups_total, NC) + (size_t)2 * ngroups_total * 2 * GROUP * (4 * Hp) * 2;
+  return xchg_x_off(ngroups_total, NC) + (size_t)2 * ngroups_total * 2 * xchg_slot(NC, Hp);
 }
 
 __device__ __forceinline__ void st_rlx(void* p, u64 v) { __hip_atomic_store((gu64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_cluster_kernel(CLaunch L) {
 
   unsigned char* abort_w = D.xchg;
   unsigned char* flags = D.xchg + xchg_flags_off() + ((size_t)(dir * ngt + wh.grp) * NC) * 64;
-  unsigned char* Xb = D.xchg + xchg_x_off(ngt, NC) + ((size_t)(dir * ngt + wh.grp) * 2) * GROUP * XW * 2;
+  unsigned char* Xb = D.xchg + xchg_x_off(ngt, NC) + ((size_t)(dir * ngt + wh.grp) * 2) * xchg_slot(NC, Hp);
 
   // resident weights: the forward packing is [(ht*4+g)*KS + ks][lane] x 16 B; this workgroup owns tiles me*TPW..+TPW
   {
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_cluster_kernel(CLaunch L) {
   __syncthreads();
   __amdgpu_buffer_rsrc_t xr[2];
   xr[0] = make_rsrc(Xb, (unsigned)(GROUP * XW * 2));
-  xr[1] = make_rsrc(Xb + (size_t)GROUP * XW * 2, (unsigned)(GROUP * XW * 2));
+  xr[1] = make_rsrc(Xb + xchg_slot(NC, Hp), (unsigned)(GROUP * XW * 2));
 
   // all-gather tables (fixed for the whole sequence): X byte offset (OOB = nothing to fetch) and LDS destination
   unsigned goff[8]; int gdst0[8];
@@ -336,12 +339,20 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_cluster_kernel(CLaunch L) {
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-template <int KSBC>
+// dh_{t-1} = dG_t W_hh.  The workgroup owns the GATE ROWS of its hidden units (K = TPW*64 rows of W_hh, all Hp columns,
+// resident in LDS) and computes a PARTIAL dh over all hidden columns from its own dG slice; the partials are then
+// reduce-scattered inside the cluster: each workgroup publishes its (GROUP x Hp) bf16 partial and gathers only the
+// 2*TPW*16-byte column slices of its own units from the other NC-1 workgroups (18 KB per step for the text LSTM instead of
+// the 70 KB an all-gather of dG would cost), sums them in fp32 and continues with its lane-local cell backward.
+constexpr int MAXNT = 16;          // n-tiles per wave (two waves share an m-tile): supports nHT <= 32
+constexpr int BPU = 8, BGU = 8;    // publish / gather 16-byte chunks per thread (text: 5 and 5)
+
+template <int NTC>
 __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(CLaunch L) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const Where wh = locate(L);
   const CDesc& D = L.d[wh.di];
-  const int H = D.H, Hp = D.Hp, KSB = D.KSB, nHT = D.nHT, TPW = D.TPW, NC = D.NC;
+  const int H = D.H, Hp = D.Hp, nHT = D.nHT, TPW = D.TPW, NC = D.NC;
   const int B = L.B, T = L.T, dir = wh.dir, me = wh.me;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
@@ -349,26 +360,32 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(CLaunch L) {
   const int ht = me * TPW + lt;
   const bool tile_ok = lt < TPW && ht < nHT;
   const int col = ht * 16 + fr;
-  const int XW = 4 * Hp;
-  const int ld = XW + 8;
+  const int KW = TPW * 64, lda = KW + 8, lds = Hp + 8, OW = TPW * 16;
   const int ngt = (B + GROUP - 1) / GROUP;
   const unsigned G4 = 4u * H;
 
-  uint4* Wl = reinterpret_cast<uint4*>(smem);                                              // TPW*KSB*64 x 16 B
-  unsigned short* dg = reinterpret_cast<unsigned short*>(smem + (size_t)TPW * KSB * 1024);         // GROUP x ld
-  volatile int& lds_ok = *reinterpret_cast<volatile int*>(smem + (size_t)TPW * KSB * 1024 + (size_t)GROUP * ld * 2);
+  // LDS: W slice [lt][nt][ks2] fragments | A (own dG) | staging (partial dh) | gathered partials | flag
+  size_t off = 0;
+  uint4* Wl = reinterpret_cast<uint4*>(smem);                        off += (size_t)TPW * nHT * 2 * 1024;
+  unsigned short* Ab = reinterpret_cast<unsigned short*>(smem + off); off += (size_t)GROUP * lda * 2;
+  unsigned short* St = reinterpret_cast<unsigned short*>(smem + off); off += (size_t)GROUP * lds * 2;
+  unsigned short* Gb = reinterpret_cast<unsigned short*>(smem + off); off += (size_t)(NC > 1 ? NC - 1 : 1) * GROUP * OW * 2;
+  volatile int& lds_ok = *reinterpret_cast<volatile int*>(smem + off);
 
   unsigned char* abort_w = D.xchg;
   unsigned char* flags = D.xchg + xchg_flags_off() + ((size_t)(dir * ngt + wh.grp) * NC) * 64;
-  unsigned char* Xb = D.xchg + xchg_x_off(ngt, NC) + ((size_t)(dir * ngt + wh.grp) * 2) * GROUP * XW * 2;
+  unsigned char* Xb = D.xchg + xchg_x_off(ngt, NC) + ((size_t)(dir * ngt + wh.grp) * 2) * xchg_slot(NC, Hp);
   {
-    const uint4* src = reinterpret_cast<const uint4*>(D.wpack[dir]);       // backward packing [ht*KSB + ks][lane] x 16 B
-    const int per_tile = KSB * 64;
+    // cluster-backward packing: [(ht*nHT + nt)*2 + ks2][lane] x 16 B; the tiles of this workgroup are contiguous blocks
+    const uint4* src = reinterpret_cast<const uint4*>(D.wpack_c[dir]);
+    const int per_tile = nHT * 2 * 64;
     for (int i = tid; i < TPW * per_tile; i += 256) {
       int l2 = i / per_tile, h2 = me * TPW + l2;
       Wl[i] = h2 < nHT ? src[(size_t)h2 * per_tile + (i % per_tile)] : uint4{0, 0, 0, 0};
     }
-    for (int i = tid; i < GROUP * ld; i += 256) dg[i] = 0;
+    for (int i = tid; i < GROUP * lda; i += 256) Ab[i] = 0;
+    for (int i = tid; i < GROUP * lds; i += 256) St[i] = 0;
+    for (int i = tid; i < (NC > 1 ? NC - 1 : 1) * GROUP * OW; i += 256) Gb[i] = 0;
   }
   const __amdgpu_buffer_rsrc_t rg = make_rsrc(D.gates, (unsigned)T * B * 2u * G4 * 4u);
   const __amdgpu_buffer_rsrc_t rc = make_rsrc(D.cstash, (unsigned)T * B * 2u * H * 4u);
@@ -411,17 +428,41 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(CLaunch L) {
   load_stash(sb[0], 0);
   load_stash(sb[1], 1);
   if (tid == 0) lds_ok = 1;
-  __syncthreads();
   __amdgpu_buffer_rsrc_t xr[2];
-  xr[0] = make_rsrc(Xb, (unsigned)(GROUP * XW * 2));
-  xr[1] = make_rsrc(Xb + (size_t)GROUP * XW * 2, (unsigned)(GROUP * XW * 2));
-  constexpr int GB = 20;                                // 16-byte gather chunks per thread and batch (text: 19 -> one batch)
-  const int own_lo = me * TPW * 16, own_hi = own_lo + TPW * 16;   // own hidden columns inside each gate block
+  xr[0] = make_rsrc(Xb, (unsigned)(NC * GROUP * Hp * 2));
+  xr[1] = make_rsrc(Xb + xchg_slot(NC, Hp), (unsigned)(NC * GROUP * Hp * 2));
+  // publish table: 16-byte chunks of the staged partial that belong to OTHER workgroups' columns -> X[me][row][col]
+  unsigned poff[BPU]; int psrc[BPU];
+  // gather table: the own-column chunks of every other workgroup's partial -> Gb[src'][row][.]
+  unsigned goff[BGU]; int gdst[BGU];
+  {
+    const int cprow = Hp / 8, cpo = OW / 8;
+    const int own_lo = me * OW, own_hi = own_lo + OW;
+#pragma unroll
+    for (int u = 0; u < BPU; ++u) {
+      int i = u * 256 + tid;
+      int row = i / cprow, cc = (i % cprow) * 8;
+      bool want = NC > 1 && i < GROUP * cprow && !(cc >= own_lo && cc < own_hi);
+      psrc[u] = want ? row * lds + cc : 0;
+      poff[u] = want ? (unsigned)(((me * GROUP + row) * Hp + cc) * 2) : OOB;
+    }
+#pragma unroll
+    for (int u = 0; u < BGU; ++u) {
+      int i = u * 256 + tid;
+      int sp = i / (GROUP * cpo), rem = i % (GROUP * cpo);
+      int row = rem / cpo, ch = rem % cpo;
+      int src = sp < me ? sp : sp + 1;
+      bool want = NC > 1 && sp < NC - 1 && own_lo + ch * 8 < Hp;
+      gdst[u] = want ? (sp * GROUP + row) * OW + ch * 8 : -1;
+      goff[u] = want ? (unsigned)(((src * GROUP + row) * Hp + own_lo + ch * 8) * 2) : OOB;
+    }
+  }
+  __syncthreads();
 
   auto do_step = [&](int step, Stash& S) -> bool {
     const int t = dir ? step : T - 1 - step;
     const unsigned epoch = L.epoch_base + (unsigned)step + 1u;
-    // (1) lane-local gate gradients of the own hidden units (branch-free)
+    // (1) lane-local gate gradients of the own hidden units (branch-free); A operand into LDS, fp32 dG in place over the stash
     if (tile_ok) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -441,24 +482,39 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(CLaunch L) {
         const unsigned o = inb[r] ? og[r] + (unsigned)t * sg : OOB;       // zero at padded positions too
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          dg[row * ld + g * Hp + col] = f2bf(dp[g]);
-          stf(rg, inb[r] ? o + g * H * 4u : OOB, dp[g]);                  // fp32 dG in place over the stash
+          Ab[row * lda + lt * 64 + g * 16 + fr] = f2bf(dp[g]);
+          stf(rg, inb[r] ? o + g * H * 4u : OOB, dp[g]);
         }
       }
     }
-    __syncthreads();                                     // own dG slice complete in LDS
+    __syncthreads();                                     // own dG slice (A operand) complete
+    // (2) partial dh over ALL hidden columns: (16 x KW) x (KW x 16) per n-tile, W_hh rows of the own units from LDS
+    {
+      bf16x8 af[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        af[ks] = *reinterpret_cast<const bf16x8*>(&Ab[(mt * 16 + fr) * lda + (ks < TPW * 2 ? ks : 0) * 32 + fq * 8]);
+      const bf16x8* wbase = reinterpret_cast<const bf16x8*>(Wl) + lane;
+#pragma unroll
+      for (int i = 0; i < (NTC > 0 ? NTC : MAXNT); ++i) {
+        const int nt = (wave >> 1) + 2 * i;
+        if (nt >= nHT) break;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          if (ks < TPW * 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], wbase[(((ks >> 1) * nHT + nt) * 2 + (ks & 1)) * 64], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) St[(mt * 16 + fq * 4 + r) * lds + nt * 16 + fr] = f2bf(acc[r]);
+      }
+    }
+    __syncthreads();                                     // staged partial complete
     bool ok = true;
     if (NC > 1) {
       __amdgpu_buffer_rsrc_t X = (epoch & 1u) ? xr[1] : xr[0];
-      const int cpg = TPW * 2;                           // 16-byte chunks per (row, gate) of the own slice
-      const int c0 = me * TPW * 16;
-      for (int i = tid; i < GROUP * 4 * cpg; i += 256) {
-        int row = i / (4 * cpg), rem = i % (4 * cpg);
-        int cu = c0 + (rem % cpg) * 8;
-        if (cu >= Hp) continue;                          // last workgroup: tiles past the padded width do not exist
-        int cc = (rem / cpg) * Hp + cu;
-        u32x4 v = *reinterpret_cast<const u32x4*>(&dg[row * ld + cc]);
-        st16_sc1(X, (unsigned)((row * XW + cc) * 2), v);
+#pragma unroll
+      for (int u = 0; u < BPU; ++u) {
+        u32x4 v = *reinterpret_cast<const u32x4*>(&St[psrc[u]]);
+        st16_sc1(X, poff[u], v);                         // out-of-range offsets (own columns / past the end) are dropped
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -466,69 +522,27 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(CLaunch L) {
       load_stash(S, step + 2);                           // lands while the cluster is being polled
       ok = wait_cluster(flags, abort_w, NC, me, epoch, &lds_ok);
       if (ok) {
-        const int cprow = XW / 8;
-        const int total = GROUP * cprow;
-        for (int i0 = 0; i0 < total; i0 += 256 * GB) {
-          u32x4 v[GB]; int dst[GB];
-          int row = (i0 + tid) / cprow, ch = (i0 + tid) % cprow;      // one division per batch, then incremental
-          const int drow = 256 / cprow, dch = 256 % cprow;
+        u32x4 gv[BGU];
 #pragma unroll
-          for (int u = 0; u < GB; ++u) {           // unconditional loads; out-of-range offset -> zeros
-            const int cc = ch * 8;
-            int cm = cc; cm = cm >= Hp ? cm - Hp : cm; cm = cm >= Hp ? cm - Hp : cm; cm = cm >= Hp ? cm - Hp : cm;   // cc % Hp (cc < 4 Hp)
-            bool want = row < GROUP && cm >= own_lo && cm < own_hi ? false : row < GROUP;
-            dst[u] = want ? row * ld + cc : -1;
-            v[u] = ld16_sc1(X, want ? (unsigned)((row * XW + cc) * 2) : OOB);
-            row += drow; ch += dch;
-            if (ch >= cprow) { ch -= cprow; row += 1; }
-          }
+        for (int u = 0; u < BGU; ++u) gv[u] = ld16_sc1(X, goff[u]);
 #pragma unroll
-          for (int u = 0; u < GB; ++u)
-            if (dst[u] >= 0) *reinterpret_cast<u32x4*>(&dg[dst[u]]) = v[u];
-        }
+        for (int u = 0; u < BGU; ++u)
+          if (gdst[u] >= 0) *reinterpret_cast<u32x4*>(&Gb[gdst[u]]) = gv[u];
       }
       __syncthreads();
     } else {
       load_stash(S, step + 2);
     }
-    // (2) dh_{t-1}[own units] = dG(all gate rows) * W_hh[:, own units] out of LDS
+    // (3) reduce: dh_{t-1} of the own units = own partial + the NC-1 gathered partials (fp32 sum of bf16 partials)
     if (tile_ok) {
-      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-      const unsigned short* arow = dg + (mt * 16 + fr) * ld + fq * 8;
-      const bf16x8* wp = reinterpret_cast<const bf16x8*>(Wl) + (size_t)lt * KSB * 64 + lane;
-      if (KSBC > 0 && KSB == KSBC) {
-        // text: 38 k-steps in two halves of 19: all 38 fragment reads of a half are issued before its MFMAs (see forward)
-        f32x4 acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          constexpr int HK = KSBC / 2;
-          bf16x8 af[HK], bfr[HK];
-#pragma unroll
-          for (int k2 = 0; k2 < HK; ++k2) {
-            af[k2] = *reinterpret_cast<const bf16x8*>(arow + (half * HK + k2) * 32);
-            bfr[k2] = wp[(half * HK + k2) * 64];
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int k2 = 0; k2 < HK; ++k2) {
-            if (k2 & 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k2], bfr[k2], acc2, 0, 0, 0);
-            else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k2], bfr[k2], acc, 0, 0, 0);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
-      } else {
-#pragma unroll 4
-        for (int ks = 0; ks < KSB; ++ks) {
-          bf16x8 a = *reinterpret_cast<const bf16x8*>(arow + ks * 32);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wp[ks * 64], acc, 0, 0, 0);
-        }
+      for (int r = 0; r < 4; ++r) {
+        const int row = mt * 16 + fq * 4 + r;
+        float sum = bf2f(St[row * lds + me * OW + lt * 16 + fr]);
+        for (int sp = 0; sp < NC - 1; ++sp) sum += bf2f(Gb[(sp * GROUP + row) * OW + lt * 16 + fr]);
+        dh_rec[r] = sum;
       }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dh_rec[r] = acc[r];
     }
-    __syncthreads();                                     // dG tile is overwritten by the next step
     return ok;
   };
   {
@@ -545,13 +559,15 @@ struct Plan { int TPW, NC, maxtw; size_t lds_f, lds_b; bool ok; };
 
 Plan plan_for(int H) {
   Plan p{};
-  int Hp = round_up(H, 16), Kp = round_up(H, 32), KS = Kp / 32, KSB = 4 * Hp / 32, nHT = Hp / 16;
+  int Hp = round_up(H, 16), Kp = round_up(H, 32), KS = Kp / 32, nHT = Hp / 16;
   const size_t cap = 160 * 1024 - 1024;
   p.ok = false;
   for (int t = 2; t >= 1; --t) {          // <= 2 hidden tiles per workgroup: every wave owns exactly one (m-tile, hidden tile)
     if (t > nHT && t > 1) continue;
     size_t lf = (size_t)t * 4 * KS * 1024 + (size_t)2 * GROUP * (Kp + 8) * 2 + 16;
-    size_t lb = (size_t)t * KSB * 1024 + (size_t)GROUP * (4 * Hp + 8) * 2 + 16;
+    const int nc = ceil_div(nHT, t);
+    size_t lb = (size_t)t * nHT * 2 * 1024 + (size_t)GROUP * (t * 64 + 8) * 2 + (size_t)GROUP * (Hp + 8) * 2 +
+                (size_t)(nc > 1 ? nc - 1 : 1) * GROUP * t * 16 * 2 + 16;
     if (lf <= cap && lb <= cap) {
       p.TPW = t; p.NC = ceil_div(nHT, t); p.maxtw = ceil_div(t, 2); p.lds_f = lf; p.lds_b = lb; p.ok = p.NC <= 64;
       break;
@@ -585,6 +601,7 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
   size_t lds = 0;
   for (int i = 0; i < n; ++i) {
     if (!descs[i].xchg) return MMDA_OK;
+    if (bwd && (!descs[i].wpack_c[0] || !descs[i].wpack_c[1])) return MMDA_OK;
     plans[i] = plan_for(descs[i].H);
     if (!plans[i].ok) return MMDA_OK;
     maxtw = plans[i].maxtw > maxtw ? plans[i].maxtw : maxtw;
@@ -613,6 +630,7 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
       c.H = d.H; c.Hp = round_up(d.H, 16); c.Kp = round_up(d.H, 32); c.KS = c.Kp / 32; c.KSB = 4 * c.Hp / 32; c.nHT = c.Hp / 16;
       c.TPW = p.TPW; c.NC = p.NC;
       c.gates = d.gates; c.cstash = d.cstash; c.hseq = d.hseq; c.wpack[0] = d.wpack[0]; c.wpack[1] = d.wpack[1];
+      c.wpack_c[0] = d.wpack_c[0]; c.wpack_c[1] = d.wpack_c[1];
       c.utt = d.utt; c.layer = d.layer; c.d_hseq = d.d_hseq; c.xchg = (unsigned char*)d.xchg;
       c.wg_begin = wg;
       if (i < n) wg += 2 * L.ng * p.NC;
@@ -620,7 +638,7 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
     dim3 grid(wg), block(256);
 #define LAUNCH_C()                                                                                               \
   do {                                                                                                           \
-    auto kfn = bwd ? lstm_bwd_cluster_kernel<38> : lstm_fwd_cluster_kernel<10>;                                  \
+    auto kfn = bwd ? lstm_bwd_cluster_kernel<0> : lstm_fwd_cluster_kernel<10>;                                  \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,     \
                             (int)lds) != hipSuccess) { (void)hipGetLastError(); }                                \
     hipLaunchKernelGGL(kfn, grid, block, lds, s, L);                                                             \

@@ -14,7 +14,7 @@ struct ParamInfo { std::string name; int64_t off; int rows, cols; };
 struct Rnn {           // one bidirectional LSTM layer
   int D, H;
   int64_t w_ih, w_hh[2], b_ih, b_hh;     // w_ih: (8H,D) = [fwd;rev]; b_*: (8H) = [fwd;rev]
-  int64_t pack_f[2], pack_b[2];          // workspace float offsets of the packed W_hh (per direction)
+  int64_t pack_f[2], pack_b[2], pack_c[2];   // workspace float offsets of the packed W_hh (per direction)
 };
 
 struct Mod {           // one modality: two stacked biLSTMs with a LayerNorm between, then a projection
@@ -54,7 +54,7 @@ struct mmda_misa {
   int training = 0; uint64_t seed = 0;
   // optional per-launch timing of the four recurrent kernels (bench.py roofline leg)
   unsigned epoch = 1;              // monotonic cluster-exchange epoch (never reset; see lstm_cluster.hip)
-  int use_cluster = 1;
+  int use_cluster = 1, packed_c_valid = 0;
   std::vector<hipEvent_t> ev;      // [step][slot][start/stop]
   int ev_steps = 0, ev_fwd = 0, ev_bwd = 0;
 };
@@ -171,6 +171,7 @@ int64_t layout(mmda_misa* m, int B, int T, bool commit) {
       for (int d = 0; d < 2; ++d) {     // sized for the larger (fp32) packing so the mode can be switched in place
         r.pack_f[d] = k.take(mmda_lstm_packed_bytes(MMDA_F32, r.H, 0) / 4);
         r.pack_b[d] = k.take(mmda_lstm_packed_bytes(MMDA_F32, r.H, 1) / 4);
+        r.pack_c[d] = k.take(mmda_lstm_packed_bytes(MMDA_BF16, r.H, 2) / 4);
       }
     }
     md.xchg_floats = (mmda_lstm_xchg_bytes(md.H, B) + 3) / 4;
@@ -377,15 +378,17 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
 
   // W_hh -> MFMA fragment order (weights changed since the last step): all twelve matrices in one launch
   {
-    int Hs[12]; const float* Wp[12]; void* Fp[12]; void* Bp[12];
+    int Hs[12]; const float* Wp[12]; void* Fp[12]; void* Bp[12]; void* Cp[12];
     int k = 0;
     for (int i = 0; i < 3; ++i)
       for (int l = 0; l < 2; ++l)
         for (int d = 0; d < 2; ++d, ++k) {
           Rnn& r = m->mod[i].rnn[l];
-          Hs[k] = r.H; Wp[k] = PP(r.w_hh[d]); Fp[k] = WS(r.pack_f[d]); Bp[k] = WS(r.pack_b[d]);
+          Hs[k] = r.H; Wp[k] = PP(r.w_hh[d]); Fp[k] = WS(r.pack_f[d]); Bp[k] = WS(r.pack_b[d]); Cp[k] = WS(r.pack_c[d]);
         }
-    x.rc = mmda_lstm_pack_whh_multi(mode, 12, Hs, Wp, Fp, Bp, stream);
+    const bool want_c = m->use_cluster && mode == MMDA_BF16;
+    x.rc = mmda_lstm_pack_whh_multi(mode, 12, Hs, Wp, Fp, Bp, want_c ? Cp : nullptr, stream);
+    m->packed_c_valid = want_c ? 1 : 0;
   }
   if (x.rc) return x.rc;
   // embedding rows (models.py:201)
@@ -630,6 +633,7 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
       desc[i] = mmda_lstm_desc{};
       desc[i].H = r.H; desc[i].gates = WS(md.gates[l]); desc[i].cstash = WS(md.c[l]); desc[i].hseq = WS(md.hseq[l]);
       desc[i].wpack[0] = WS(r.pack_b[0]); desc[i].wpack[1] = WS(r.pack_b[1]);
+      desc[i].wpack_c[0] = m->packed_c_valid ? WS(r.pack_c[0]) : nullptr; desc[i].wpack_c[1] = m->packed_c_valid ? WS(r.pack_c[1]) : nullptr;
       desc[i].utt = WS(md.d_utt); desc[i].layer = l; desc[i].d_hseq = l == 0 ? WS(md.d_hseq1) : nullptr;
       desc[i].xchg = (m->use_cluster && md.xchg >= 0) ? (void*)WS(md.xchg) : nullptr; desc[i].epoch_base = m->epoch;
     }

@@ -129,10 +129,20 @@ def lstm_pack(whh, mode):
     return pf, pb
 
 
-def _desc(H, gates, cstash, hseq, wp0, wp1, utt, layer, d_hseq=None, xchg=None, epoch_base=0):
+def lstm_pack_cluster(whh):
+    """Cluster-backward packing (bf16) of one direction's W_hh."""
+    lib = load()
+    H = whh.shape[1]
+    pc = torch.empty(lib.mmda_lstm_packed_bytes(BF16, H, 2), dtype=torch.uint8, device=whh.device)
+    check(lib.mmda_lstm_pack_whh_cluster(H, ptr(_f(whh)), ptr(pc), stream_ptr()), "lstm_pack_cluster")
+    return pc
+
+
+def _desc(H, gates, cstash, hseq, wp0, wp1, utt, layer, d_hseq=None, xchg=None, epoch_base=0, wc0=None, wc1=None):
     d = _lib.LstmDesc()
     d.H = H; d.gates = ptr(gates); d.cstash = ptr(cstash); d.hseq = ptr(hseq)
     d.wpack[0] = ptr(wp0); d.wpack[1] = ptr(wp1)
+    d.wpack_c[0] = ptr(wc0); d.wpack_c[1] = ptr(wc1)
     d.utt = ptr(utt); d.layer = layer; d.d_hseq = ptr(d_hseq)
     d.xchg = ptr(xchg); d.epoch_base = epoch_base
     return d
@@ -158,9 +168,10 @@ def lstm_bidir_fwd(pre, whh_f, whh_r, lengths, *, mode="fp32", layer=0, utt=None
     pf1, pb1 = lstm_pack(whh_r, mode)
     len_dev = lengths.to(device=pre.device, dtype=torch.int32)
     xchg = lstm_xchg(H, B, pre.device) if resident else None
+    pcs = (lstm_pack_cluster(whh_f), lstm_pack_cluster(whh_r)) if (resident and MODE[mode] == BF16) else (None, None)
     d = (_lib.LstmDesc * 1)(_desc(H, gates, cst, hseq, pf0, pf1, utt, layer, None, xchg, 0))
     check(lib.mmda_lstm_fwd(MODE[mode], 1, d, B, T, ptr(len_dev), stream_ptr()), "lstm_fwd")
-    return dict(hseq=hseq, gates=gates, cstash=cst, utt=utt, packs=(pf0, pb0, pf1, pb1), len_dev=len_dev, xchg=xchg, T=T)
+    return dict(hseq=hseq, gates=gates, cstash=cst, utt=utt, packs=(pf0, pb0, pf1, pb1), len_dev=len_dev, xchg=xchg, T=T, pcs=pcs)
 
 
 def lstm_bidir_bwd(fw, d_utt, d_hseq, *, mode="fp32", layer=0):
@@ -170,7 +181,8 @@ def lstm_bidir_bwd(fw, d_utt, d_hseq, *, mode="fp32", layer=0):
     T, B, _, G4 = gates.shape
     H = G4 // 4
     pf0, pb0, pf1, pb1 = fw["packs"]
-    d = (_lib.LstmDesc * 1)(_desc(H, gates, fw["cstash"], fw["hseq"], pb0, pb1, d_utt, layer, d_hseq, fw.get("xchg"), T + 2))
+    pc0, pc1 = fw.get("pcs", (None, None))
+    d = (_lib.LstmDesc * 1)(_desc(H, gates, fw["cstash"], fw["hseq"], pb0, pb1, d_utt, layer, d_hseq, fw.get("xchg"), T + 2, pc0, pc1))
     check(lib.mmda_lstm_bwd(MODE[mode], 1, d, B, T, ptr(fw["len_dev"]), stream_ptr()), "lstm_bwd")
     return gates
 
