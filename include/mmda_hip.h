@@ -250,6 +250,9 @@ int64_t mmda_misa_tensor_offset(const mmda_misa* m, const char* name);
 int mmda_misa_set_mode(mmda_misa* m, int mode);
 /* bf16 recurrences: 1 (default) = W_hh resident in LDS across a cluster of workgroups, 0 = streamed from L2 every step */
 int mmda_misa_set_recurrence(mmda_misa* m, int resident_weights);
+/* 1 (default) = weight-gradient GEMMs run on an internal side stream underneath the recurrent kernels (joined before
+ * mmda_misa_backward returns control of `stream`); 0 = everything on `stream` */
+int mmda_misa_set_overlap(mmda_misa* m, int side_stream);
 /* *aborted_host = 1 if a cluster exchange ever timed out (results after that are invalid); synchronous D2H, off the step path */
 int mmda_misa_cluster_status(const mmda_misa* m, int* aborted_host);
 

@@ -114,6 +114,7 @@ SIGNATURES = {
     "mmda_misa_set_workspace": (_I, [_P, _P, _I64, _I, _I]),
     "mmda_misa_tensor_offset": (_I64, [_P, C.c_char_p]),
     "mmda_misa_set_mode": (_I, [_P, _I]),
+    "mmda_misa_set_overlap": (_I, [_P, _I]),
     "mmda_misa_set_recurrence": (_I, [_P, _I]),
     "mmda_misa_cluster_status": (_I, [_P, C.POINTER(_I)]),
     "mmda_misa_forward": (_I, [_P, _P, _P, _P, _P, _I, _U64, _P]),

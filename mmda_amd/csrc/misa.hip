@@ -54,6 +54,9 @@ struct mmda_misa {
   int training = 0; uint64_t seed = 0;
   // optional per-launch timing of the four recurrent kernels (bench.py roofline leg)
   unsigned epoch = 1;              // monotonic cluster-exchange epoch (never reset; see lstm_cluster.hip)
+  hipStream_t side = nullptr;      // second stream for weight-gradient GEMMs (created lazily; no device memory)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int side_pending = 0, use_side = 1;
   int use_cluster = 1, packed_c_valid = 0;
   std::vector<hipEvent_t> ev;      // [step][slot][start/stop]
   int ev_steps = 0, ev_fwd = 0, ev_bwd = 0;
@@ -228,7 +231,11 @@ int64_t layout(mmda_misa* m, int B, int T, bool commit) {
 }
 
 // ---------------------------------------------------------------------------------------------- GEMM shorthands
-struct Ctx { mmda_misa* m; void* s; int rc = 0; bool grouping = false; std::vector<mmda_gemm_args> pending; };
+struct Ctx {
+  mmda_misa* m; void* s; int rc = 0;
+  bool grouping = false; std::vector<mmda_gemm_args> pending;
+  bool deferring = false; std::vector<mmda_gemm_args> deferred;   // weight-gradient GEMMs: off the critical path, run on the side stream
+};
 
 // independent GEMMs issued between group_begin/group_end go out as ONE grouped launch
 void group_begin(Ctx& c) { c.grouping = true; c.pending.clear(); }
@@ -247,9 +254,15 @@ void gemm(Ctx& c, int mode, int tA, int tB, int M, int N, int K, const float* A,
   g.mode = mode; g.transA = tA; g.transB = tB; g.M = M; g.N = N; g.K = K; g.batch = batch;
   g.A = A; g.lda = lda; g.strideA = sA; g.B = Bp; g.ldb = ldb; g.strideB = sB; g.C = C; g.ldc = ldc; g.strideC = sC;
   g.bias = bias; g.bias2 = bias2; g.strideBias = sBias; g.accumulate = acc; g.act = act;
-  if (c.grouping) c.pending.push_back(g);
+  if (c.deferring && tA && acc) c.deferred.push_back(g);       // TN + accumulate == a weight gradient
+  else if (c.grouping) c.pending.push_back(g);
   else c.rc = mmda_gemm(&g, c.s);
 }
+
+// Fork/join with the side stream: everything in `list` only has to be finished before the optimizer step, so it runs
+// concurrently with the recurrent kernels (which occupy ~10 % of the CUs while they walk the serial chain).
+int side_launch(mmda_misa* m, std::vector<mmda_gemm_args>& list, void* main_stream);
+int side_join(mmda_misa* m, void* main_stream);
 // y(M,N) = x(M,K) W(N,K)^T + b
 void lin_fwd(Ctx& c, int mode, int M, int N, int K, const float* x, const float* W, const float* b, float* y, int act = 0) {
   gemm(c, mode, 0, 1, M, N, K, x, K, W, K, y, N, b, nullptr, 0, act);
@@ -277,6 +290,30 @@ void ev_rec(mmda_misa* m, int step, int slot, int which, void* stream) {
   (void)hipEventRecord(m->ev[(step * 4 + slot) * 2 + which], (hipStream_t)stream);
 }
 
+int side_launch(mmda_misa* m, std::vector<mmda_gemm_args>& list, void* main_stream) {
+  if (list.empty()) return MMDA_OK;
+  int rc;
+  if (!m->use_side) { rc = mmda_gemm_grouped(list.data(), (int)list.size(), main_stream); list.clear(); return rc; }
+  if (!m->side) {
+    if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess) return MMDA_ELAUNCH;
+    if (hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess) return MMDA_ELAUNCH;
+    if (hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess) return MMDA_ELAUNCH;
+  }
+  if (hipEventRecord(m->ev_fork, (hipStream_t)main_stream) != hipSuccess) return MMDA_ELAUNCH;
+  if (hipStreamWaitEvent(m->side, m->ev_fork, 0) != hipSuccess) return MMDA_ELAUNCH;
+  rc = mmda_gemm_grouped(list.data(), (int)list.size(), m->side);
+  list.clear();
+  m->side_pending = 1;
+  return rc;
+}
+int side_join(mmda_misa* m, void* main_stream) {
+  if (!m->side_pending) return MMDA_OK;
+  if (hipEventRecord(m->ev_join, m->side) != hipSuccess) return MMDA_ELAUNCH;
+  if (hipStreamWaitEvent((hipStream_t)main_stream, m->ev_join, 0) != hipSuccess) return MMDA_ELAUNCH;
+  m->side_pending = 0;
+  return MMDA_OK;
+}
+
 #define WS(off) (m->ws + (off))
 #define PP(off) (m->P + (off))
 #define GG(off) (m->G + (off))
@@ -300,7 +337,14 @@ extern "C" int mmda_misa_create(const mmda_misa_config* cfg, mmda_misa** out) {
   *out = m;
   return MMDA_OK;
 }
-extern "C" void mmda_misa_destroy(mmda_misa* m) { delete m; }
+extern "C" void mmda_misa_destroy(mmda_misa* m) {
+  if (!m) return;
+  if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+  if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+  if (m->side) (void)hipStreamDestroy(m->side);
+  for (hipEvent_t e : m->ev) (void)hipEventDestroy(e);
+  delete m;
+}
 extern "C" int mmda_misa_num_params(const mmda_misa* m) { return m ? (int)m->params.size() : MMDA_EINVAL; }
 extern "C" int mmda_misa_param_info(const mmda_misa* m, int i, const char** name, int64_t* offset, int* rows, int* cols) {
   if (!m || i < 0 || i >= (int)m->params.size()) return MMDA_EINVAL;
@@ -342,6 +386,11 @@ extern "C" int64_t mmda_misa_tensor_offset(const mmda_misa* m, const char* name)
 extern "C" int mmda_misa_set_mode(mmda_misa* m, int mode) {
   if (!m || (mode != MMDA_F32 && mode != MMDA_BF16)) return MMDA_EINVAL;
   m->cfg.mode = mode;
+  return MMDA_OK;
+}
+extern "C" int mmda_misa_set_overlap(mmda_misa* m, int side_stream) {
+  if (!m) return MMDA_EINVAL;
+  m->use_side = side_stream ? 1 : 0;
   return MMDA_OK;
 }
 extern "C" int mmda_misa_set_recurrence(mmda_misa* m, int resident_weights) {
@@ -545,6 +594,9 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
   const int training = m->training; const uint64_t seed = m->seed;
   const float p_tf = training ? c.fusion_dropout : 0.f, p_cls = training ? c.dropout : 0.f;
 
+  // Weight-gradient GEMMs of the fusion block are collected and issued as one grouped launch on the side stream once
+  // the dX chain (the critical path into the encoders) is through; their inputs are not modified afterwards.
+  x.deferring = true;
   // heads
   x.rc = mmda_heads_bwd(WS(m->tcp), WS(m->scores), WS(m->d_tcp), WS(m->d_scores), B, c.ncls, WS(m->d_logits), p_cls, seed, SITE_CLS,
                         stream);
@@ -624,6 +676,9 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
     lin_dw(x, fmode, B, hs, 4 * md.H, WS(m->d_z + i * BH), WS(md.utt), GG(md.pw), GG(md.pb));
   }
   if (x.rc) return x.rc;
+  x.deferring = false;
+  x.rc = side_launch(m, x.deferred, stream);
+  if (x.rc) return x.rc;
   // encoders, top layer first
   const float* xin[3] = {WS(m->mod[0].x), v, a};
   for (int l = 1; l >= 0; --l) {
@@ -642,7 +697,9 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
     x.rc = mmda_lstm_bwd(mode, 3, desc, B, T, lengths, stream);
     ev_rec(m, m->ev_bwd, l == 1 ? 2 : 3, 1, stream);
     if (x.rc) return x.rc;
-    // all weight / input gradient GEMMs of this layer (three modalities) are independent: one grouped launch
+    // All weight / input gradient GEMMs of this layer (three modalities) are independent.  Layer 2: d(normed) feeds the
+    // next recurrent kernel (main stream); its weight gradients run on the side stream underneath that kernel.
+    x.deferring = (l == 1);
     group_begin(x);
     for (int i = 0; i < 3; ++i) {
       Mod& md = m->mod[i]; Rnn& r = md.rnn[l];
@@ -667,6 +724,8 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
       else if (i == 0) gemm(x, mode, 0, 0, R, r.D, G8, dG, G8, PP(r.w_ih), r.D, WS(md.d_x), r.D);
     }
     group_end(x);
+    x.deferring = false;
+    if (!x.rc) x.rc = side_launch(m, x.deferred, stream);
     for (int i = 0; i < 3 && !x.rc; ++i) {
       Mod& md = m->mod[i]; Rnn& r = md.rnn[l];
       const int H = r.H;
@@ -684,6 +743,7 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
     if (x.rc) return x.rc;
   }
   if (!m->ev.empty()) m->ev_bwd++;
+  if (!x.rc) x.rc = side_join(m, stream);      // every gradient is complete on `stream` when backward returns
   return x.rc;
 }
 
