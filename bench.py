@@ -118,8 +118,19 @@ def main():
     k = max(range(4), key=lambda i: ms[i])
     peak = 2500.0 if args.precision == "bf16" else 157.3
     achieved = flops_per_launch / (ms[k] * 1e-3) / 1e12 if ms[k] > 0 else 0.0
+    # HBM bytes per launch of that kernel from the PMC counters (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes, see
+    # profiles/): only valid for the configuration the profile was taken on, otherwise null
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tfile):
+        try:
+            tj = json.load(open(tfile))
+            if (tj.get("batch"), tj.get("seq_len"), tj.get("precision")) == (args.batch, args.seq_len, args.precision) and not args.ragged:
+                traffic = tj["bytes_per_launch"].get(names[k].split("(")[0])
+        except Exception:
+            traffic = None
     roofline = {"bound": "mfma", "kernel": names[k], "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 6), "traffic": None, "launch_ms": round(ms[k], 4),
+                "frac": round(achieved / peak, 6), "traffic": traffic, "launch_ms": round(ms[k], 4),
                 "all_launch_ms": {n: round(m, 4) for n, m in zip(names, ms)},
                 "recurrent_share_of_step": round(sum(ms) / (elapsed / args.steps * 1e3), 3), "timed_steps": nst.value}
 

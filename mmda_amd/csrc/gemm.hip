@@ -12,7 +12,7 @@ constexpr int BM = 64, BN = 64, BK = 32;
 constexpr int LDS_F32_LD = 34;   // floats per LDS row: (2*row + k) % 32 distinct for the 16x16x4 operand reads
 constexpr int LDS_BF16_LD = 40;  // shorts per LDS row (80 B, 16-B aligned rows for ds_read_b128)
 
-template <int MODE>
+template <int MODE, int PF>
 __device__ __forceinline__ void gemm_body(const mmda_gemm_args& g, int splitk, unsigned char* smem, int bx, int by, int bzz) {
   float* As_f = reinterpret_cast<float*>(smem);
   float* Bs_f = As_f + BM * LDS_F32_LD;
@@ -50,8 +50,8 @@ __device__ __forceinline__ void gemm_body(const mmda_gemm_args& g, int splitk, u
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  float ra[8], rb[8];
-  auto load_tile = [&](int k0) {
+  float rap[PF][8], rbp[PF][8];
+  auto load_tile = [&](float (&ra)[8], float (&rb)[8], int k0) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       int m = row0 + a_r[i], k = k0 + a_k[i];
@@ -70,7 +70,7 @@ __device__ __forceinline__ void gemm_body(const mmda_gemm_args& g, int splitk, u
       rb[i] = u;
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](const float (&ra)[8], const float (&rb)[8]) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       if (MODE == MMDA_BF16) {
@@ -89,12 +89,30 @@ __device__ __forceinline__ void gemm_body(const mmda_gemm_args& g, int splitk, u
   const int kt0 = sp * per;
   const int nk = min(nk_all, kt0 + per);
   if (splitk > 1 && kt0 >= nk) return;
-  load_tile(kt0 * BK);
+  // PF == 1: one k-tile of register prefetch under the MFMAs (long k-loops, many workgroups in flight).
+  // PF == 4: tiny problems (<= 4 k-tiles per block, a handful of blocks): issue ALL global loads up front so the block pays
+  //          one first-touch memory latency instead of one per k-tile.
+  if (PF > 1) {
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+      if (kt0 + p < nk) load_tile(rap[p], rbp[p], (kt0 + p) * BK);
+  } else {
+    load_tile(rap[0], rbp[0], kt0 * BK);
+  }
+#pragma unroll 1
   for (int kt = kt0; kt < nk; ++kt) {
     __syncthreads();            // previous tile's fragment reads are done
-    store_tile();
+    if (PF > 1) {
+      const int p = kt - kt0;
+      if (p == 0) store_tile(rap[0], rbp[0]);
+      else if (p == 1) store_tile(rap[PF > 1 ? 1 : 0], rbp[PF > 1 ? 1 : 0]);
+      else if (p == 2) store_tile(rap[PF > 2 ? 2 : 0], rbp[PF > 2 ? 2 : 0]);
+      else store_tile(rap[PF > 3 ? 3 : 0], rbp[PF > 3 ? 3 : 0]);
+    } else {
+      store_tile(rap[0], rbp[0]);
+    }
     __syncthreads();
-    if (kt + 1 < nk) load_tile((kt + 1) * BK);   // global loads fly under the MFMAs below
+    if (PF == 1 && kt + 1 < nk) load_tile(rap[0], rbp[0], (kt + 1) * BK);   // global loads fly under the MFMAs below
     const int fr = lane & 15, fq = lane >> 4;
     if (MODE == MMDA_BF16) {
       bf16x8 a[2], b[2];
@@ -170,10 +188,10 @@ __device__ __forceinline__ void gemm_body(const mmda_gemm_args& g, int splitk, u
 }
 
 
-template <int MODE>
+template <int MODE, int PF>
 __global__ __launch_bounds__(256) void gemm_kernel(mmda_gemm_args g, int splitk) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BM * LDS_F32_LD * 4];
-  gemm_body<MODE>(g, splitk, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+  gemm_body<MODE, PF>(g, splitk, smem, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Grouped launch: up to GROUP_MAX independent GEMMs (different shapes, layouts, modes) in ONE grid, so that the many small
@@ -196,8 +214,8 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(GroupLaunch G) {
   const int bx = local % G.tx[i], by = (local / G.tx[i]) % G.ty[i], bzz = local / (G.tx[i] * G.ty[i]);
   const mmda_gemm_args g = G.p[i];      // one copy into SGPRs; indexing the kernarg array inside the k-loop would re-load fields
   const int sk = G.splitk[i];
-  if (g.mode == MMDA_BF16) gemm_body<MMDA_BF16>(g, sk, smem, bx, by, bzz);
-  else gemm_body<MMDA_F32>(g, sk, smem, bx, by, bzz);
+  if (g.mode == MMDA_BF16) gemm_body<MMDA_BF16, 1>(g, sk, smem, bx, by, bzz);
+  else gemm_body<MMDA_F32, 1>(g, sk, smem, bx, by, bzz);
 }
 
 // ------------------------------------------------------------------------------------------------ 128x128 bf16 tile
@@ -401,8 +419,15 @@ extern "C" int mmda_gemm(const mmda_gemm_args* a, void* stream) {
   }
   dim3 grid(ceil_div(Neff, BN), ceil_div(a->M, BM), a->batch * splitk);
   if (grid.y > 65535 || grid.z > 65535) return MMDA_EINVAL;
-  if (a->mode == MMDA_BF16) hipLaunchKernelGGL(gemm_kernel<MMDA_BF16>, grid, dim3(256), 0, s, *a, splitk);
-  else hipLaunchKernelGGL(gemm_kernel<MMDA_F32>, grid, dim3(256), 0, s, *a, splitk);
+  const int per_split = ceil_div(nk, splitk);
+  const bool tiny = per_split <= 4 && (int)(grid.x * grid.y * grid.z) <= 1024;
+  if (a->mode == MMDA_BF16) {
+    if (tiny) hipLaunchKernelGGL((gemm_kernel<MMDA_BF16, 4>), grid, dim3(256), 0, s, *a, splitk);
+    else hipLaunchKernelGGL((gemm_kernel<MMDA_BF16, 1>), grid, dim3(256), 0, s, *a, splitk);
+  } else {
+    if (tiny) hipLaunchKernelGGL((gemm_kernel<MMDA_F32, 4>), grid, dim3(256), 0, s, *a, splitk);
+    else hipLaunchKernelGGL((gemm_kernel<MMDA_F32, 1>), grid, dim3(256), 0, s, *a, splitk);
+  }
   MMDA_CHECK_LAUNCH("mmda_gemm");
   return MMDA_OK;
 }
