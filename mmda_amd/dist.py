@@ -26,11 +26,26 @@ class DataParallelSync:
 
     def broadcast_parameters(self, model):
         """Rank 0's weights everywhere (one broadcast of the flat bucket when the model has one)."""
-        if hasattr(model, "flat_buckets") and model.flat_buckets()[0] is not None:
-            dist.broadcast(model.flat_buckets()[0], src=0, group=self.group)
-        else:
-            for p in model.parameters():
-                dist.broadcast(p.data, src=0, group=self.group)
+        gloo_cuda = dist.get_backend(self.group) == "gloo"
+        ts = [model.flat_buckets()[0]] if (hasattr(model, "flat_buckets") and model.flat_buckets()[0] is not None) \
+            else [p.data for p in model.parameters()]
+        for t in ts:
+            if t.is_cuda and gloo_cuda:
+                h = t.cpu()
+                dist.broadcast(h, src=0, group=self.group)
+                t.copy_(h)
+            else:
+                dist.broadcast(t, src=0, group=self.group)
+
+    def _all_reduce(self, t: torch.Tensor, async_op: bool = False):
+        """all-reduce(sum) in place.  With the gloo backend (CPU tests, or a 2-rank rehearsal on one GPU) device tensors are
+        staged through host memory; with nccl (= RCCL) the tensor is reduced in place over xGMI."""
+        if t.is_cuda and dist.get_backend(self.group) == "gloo":
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+            return None
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
     def sync(self, flat_grads: torch.Tensor, dense_floats: int) -> float:
         """All-reduce(sum) the gradient bucket in place; returns the scale (1/world) the optimizer applies.
@@ -40,12 +55,12 @@ class DataParallelSync:
             return 1.0
         n = flat_grads.numel()
         if self.bucket_floats <= 0 or self.bucket_floats >= n:
-            dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=self.group)
+            self._all_reduce(flat_grads)
         else:
             works = []
             for s in range(0, n, self.bucket_floats):
-                works.append(dist.all_reduce(flat_grads[s:s + self.bucket_floats], op=dist.ReduceOp.SUM, group=self.group,
-                                             async_op=True))
+                works.append(self._all_reduce(flat_grads[s:s + self.bucket_floats], async_op=True))
             for w in works:
-                w.wait()
+                if w is not None:
+                    w.wait()
         return 1.0 / self.world
