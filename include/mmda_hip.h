@@ -70,6 +70,59 @@ int mmda_gemm(const mmda_gemm_args* args, void* stream);
 /* n independent GEMMs (any mix of shapes / layouts / modes) in one launch; results as n mmda_gemm calls in any order */
 int mmda_gemm_grouped(const mmda_gemm_args* args, int n, void* stream);
 
+/* ---------------------------------------------------------------------------------------------- bf16-operand GEMM
+ * The LSTM-sized GEMMs of the bf16 mode read bf16 operands that are K-MAJOR (rows of A and of B are contiguous along k):
+ *   C[M,N] (+)= alpha * A[M,K] * B[N,K]^T + bias + bias2,  fp32 accumulate and output.
+ * Leading dimensions are in bf16 elements and must be multiples of 8 (16-byte rows); K may be ragged (k >= K reads as 0 as
+ * long as the copies are zero-padded up to a multiple of 8, which mmda_convert_bf16 guarantees).  bias_grad[m] += sum_k A[m,k]
+ * (a virtual all-ones row of B).  Operand copies come from mmda_convert_bf16 (plain and/or transposed).  Up to 16 problems go
+ * out as one grouped launch; few-tile/long-K problems are split along K with float atomics (C zeroed first if !accumulate). */
+typedef struct mmda_gemm_bf16_args {
+  int M, N, K;
+  const void* A; int lda;            /* bf16 (M, lda) */
+  const void* B; int ldb;            /* bf16 (N, ldb) */
+  float* C; int ldc;
+  const float* bias; const float* bias2;
+  float* bias_grad; float* bias_grad2;
+  int accumulate; float alpha;       /* alpha 0 is read as 1 */
+} mmda_gemm_bf16_args;
+int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, void* stream);
+/* fp32 (rows, cols) matrix with leading dim ld -> bf16 copies: `plain` (rows, ldp) and/or `transposed` (cols, ldt); either may be
+ * NULL.  ldp >= round_up(cols,8), ldt >= round_up(rows,8); the padding columns are written as zero.  `gather` (optional int64
+ * row ids) reads row ids[r] of `src` instead of row r (embedding lookup).  Up to 16 jobs per launch. */
+typedef struct mmda_convert_job {
+  const float* src; int ld; int rows, cols;
+  const int64_t* gather;
+  void* plain; int ldp;
+  void* transposed; int ldt;
+} mmda_convert_job;
+int mmda_convert_bf16(const mmda_convert_job* jobs, int n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------- row-skinny f32 GEMM
+ * The fusion block's GEMMs have M = B or 6B rows (models.py:63-153,243-249 and their input gradients): one workgroup per
+ * 32 x 16 output tile whose eight waves split K, exact f32 MFMA, operands straight from global memory, fixed-order reduction
+ * (bitwise reproducible), fused epilogue.  Up to 8 independent problems per launch.
+ *   raw   = alpha * ( (A (+A2)) * op(B)  +  A_2nd * op(B_2nd) )          op(B) = B^T (transB=1: B is (N, ldb), y = x W^T)
+ *                                                                               or B   (transB=0: B is (K, ldb), dx = dy W)
+ *   C[m,n]  = dsig( gate( dropout( act( raw + bias[n] (+ C[m,n] if accumulate) ) ) ) )
+ *   C2[m,n] = dsig2( raw (+ C2[m,n] if accumulate) )                        (optional second destination of the same product)
+ * gate: v *= gate[m,n] > 0 ? gate_scale : 0 (relu/dropout mask of a stored activation); dsig: v *= s (1 - s), s = dsig[m,n].
+ * float4 operand loads are used when the bases are 16-B aligned, ld % 4 == 0 and K % 4 == 0; otherwise scalar loads. */
+typedef struct mmda_skinny_args {
+  int M, N, K, transB;
+  const float* A; const float* A2; int lda;
+  const float* B; int ldb;
+  int K2; const float* A_2nd; int lda_2nd; const float* B_2nd; int ldb_2nd;   /* optional second product (K2 = 0: none) */
+  float* C; int ldc;
+  float* C2; int ldc2;
+  const float* bias;
+  int accumulate; float alpha; int act;                                        /* alpha 0 is read as 1 */
+  float drop_p; uint64_t drop_seed; int drop_site;                             /* element index m * N + n */
+  const float* gate; int ldgate; float gate_scale;
+  const float* dsig; const float* dsig2; int lddsig;
+} mmda_skinny_args;
+int mmda_gemm_skinny(const mmda_skinny_args* args, int n, void* stream);
+
 /* column sums: out[n] += sum_m X[m*ld + n] (and out2[n] += the same, if out2 != NULL)   (bias gradients; atomics) */
 int mmda_colsum(const float* X, int ld, int M, int N, float* out, float* out2, void* stream);
 

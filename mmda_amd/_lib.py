@@ -32,6 +32,28 @@ class GemmArgs(C.Structure):
                 ("alpha", C.c_float), ("bias_grad", C.c_void_p), ("bias_grad2", C.c_void_p)]
 
 
+class GemmBf16Args(C.Structure):
+    _fields_ = [("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("A", C.c_void_p), ("lda", C.c_int), ("B", C.c_void_p), ("ldb", C.c_int),
+                ("C", C.c_void_p), ("ldc", C.c_int), ("bias", C.c_void_p), ("bias2", C.c_void_p), ("bias_grad", C.c_void_p),
+                ("bias_grad2", C.c_void_p), ("accumulate", C.c_int), ("alpha", C.c_float)]
+
+
+class ConvertJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("ld", C.c_int), ("rows", C.c_int), ("cols", C.c_int), ("gather", C.c_void_p),
+                ("plain", C.c_void_p), ("ldp", C.c_int), ("transposed", C.c_void_p), ("ldt", C.c_int)]
+
+
+class SkinnyArgs(C.Structure):
+    _fields_ = [("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("transB", C.c_int),
+                ("A", C.c_void_p), ("A2", C.c_void_p), ("lda", C.c_int), ("B", C.c_void_p), ("ldb", C.c_int),
+                ("K2", C.c_int), ("A_2nd", C.c_void_p), ("lda_2nd", C.c_int), ("B_2nd", C.c_void_p), ("ldb_2nd", C.c_int),
+                ("C", C.c_void_p), ("ldc", C.c_int), ("C2", C.c_void_p), ("ldc2", C.c_int), ("bias", C.c_void_p),
+                ("accumulate", C.c_int), ("alpha", C.c_float), ("act", C.c_int),
+                ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_site", C.c_int),
+                ("gate", C.c_void_p), ("ldgate", C.c_int), ("gate_scale", C.c_float),
+                ("dsig", C.c_void_p), ("dsig2", C.c_void_p), ("lddsig", C.c_int)]
+
+
 class LnArgs(C.Structure):
     _fields_ = [("rows", C.c_int), ("n", C.c_int), ("x", C.c_void_p), ("res", C.c_void_p), ("gamma", C.c_void_p),
                 ("beta", C.c_void_p), ("y", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("act", C.c_int),
@@ -70,6 +92,9 @@ SIGNATURES = {
     "mmda_abi_version": (_I, []),
     "mmda_gemm": (_I, [C.POINTER(GemmArgs), _P]),
     "mmda_gemm_grouped": (_I, [C.POINTER(GemmArgs), _I, _P]),
+    "mmda_gemm_bf16_grouped": (_I, [C.POINTER(GemmBf16Args), _I, _P]),
+    "mmda_convert_bf16": (_I, [C.POINTER(ConvertJob), _I, _P]),
+    "mmda_gemm_skinny": (_I, [C.POINTER(SkinnyArgs), _I, _P]),
     "mmda_colsum": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "mmda_embed_gather": (_I, [_P, _P, _I, _I, _P, _P]),
     "mmda_embed_scatter_add": (_I, [_P, _P, _I, _I, _P, _P]),

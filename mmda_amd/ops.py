@@ -16,7 +16,8 @@ MODE = {"fp32": F32, "bf16": BF16, F32: F32, BF16: BF16}
 
 
 def _f(t):
-    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), "expect contiguous fp32 CUDA tensors"
+    assert t.is_cuda and t.dtype == torch.float32 and (t.is_contiguous() or (t.dim() == 2 and t.stride(1) == 1)), \
+        "expect contiguous (or row-strided 2-D) fp32 CUDA tensors"
     return t
 
 
@@ -57,6 +58,86 @@ def gemm(A, B, *, mode="fp32", transA=False, transB=True, bias=None, bias2=None,
     check(lib.mmda_gemm(C.byref(g), stream_ptr()), "mmda_gemm")
     return out
 
+
+
+def convert_bf16(jobs):
+    """jobs: list of (src[rows, cols] fp32, gather or None, want_plain, want_transposed) -> list of (plain, transposed) bf16 tensors.
+
+    plain is [rows, round_up(cols, 8)], transposed is [cols, round_up(rows, 8)], both zero padded; one launch for all jobs."""
+    lib = load()
+    arr = (_lib.ConvertJob * len(jobs))()
+    outs = []
+    for j, (src, gather, want_p, want_t) in zip(arr, jobs):
+        rows = gather.numel() if gather is not None else src.shape[0]
+        cols = src.shape[1]
+        ldp, ldt = (cols + 7) // 8 * 8, (rows + 7) // 8 * 8
+        # filled with NaN patterns so that a padding element the kernel forgot shows up in the tests
+        P = torch.full((rows, ldp), float("nan"), device=src.device, dtype=torch.bfloat16) if want_p else None
+        T = torch.full((cols, ldt), float("nan"), device=src.device, dtype=torch.bfloat16) if want_t else None
+        j.src = ptr(_f(src)); j.ld = src.shape[1]; j.rows = rows; j.cols = cols; j.gather = ptr(gather)
+        j.plain = ptr(P); j.ldp = ldp; j.transposed = ptr(T); j.ldt = ldt
+        outs.append((P, T))
+    check(lib.mmda_convert_bf16(arr, len(jobs), stream_ptr()), "mmda_convert_bf16")
+    return outs
+
+
+def gemm_bf16_grouped(problems):
+    """problems: list of dicts A[M, lda] bf16, B[N, ldb] bf16 (both K-major), K, optional out/bias/bias2/bias_grad/bias_grad2/accumulate/alpha.
+    C = alpha * A[:, :K] @ B[:, :K]^T + bias + bias2 (+C); bias_grad[m] += sum_k A[m, k].  One launch per 16 problems."""
+    lib = load()
+    arr = (_lib.GemmBf16Args * len(problems))()
+    outs = []
+    for g, p in zip(arr, problems):
+        A, B = p["A"], p["B"]
+        assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and A.is_contiguous() and B.is_contiguous()
+        M, N, K = A.shape[0], B.shape[0], p["K"]
+        out = p.get("out")
+        if out is None:
+            out = torch.zeros((M, N), device=A.device, dtype=torch.float32)
+        g.M = M; g.N = N; g.K = K; g.A = ptr(A); g.lda = A.shape[1]; g.B = ptr(B); g.ldb = B.shape[1]
+        g.C = ptr(_f(out)); g.ldc = N
+        g.bias = ptr(p.get("bias")); g.bias2 = ptr(p.get("bias2"))
+        g.bias_grad = ptr(p.get("bias_grad")); g.bias_grad2 = ptr(p.get("bias_grad2"))
+        g.accumulate = int(p.get("accumulate", False)); g.alpha = p.get("alpha", 1.0)
+        outs.append(out)
+    check(lib.mmda_gemm_bf16_grouped(arr, len(problems), stream_ptr()), "mmda_gemm_bf16_grouped")
+    return outs
+
+
+def gemm_skinny(problems):
+    """Row-skinny exact-f32 GEMMs, up to 8 problems per launch.  Each problem is a dict: A[M,K], B ([N,K] if transB else [K,N]),
+    optional A2, second product (A_2nd, B_2nd), out/out2, bias, accumulate, alpha, act, drop_p/seed/site, gate/gate_scale,
+    dsig/dsig2.  Returns the list of outputs (out2 tensors are updated in place)."""
+    lib = load()
+    arr = (_lib.SkinnyArgs * len(problems))()
+    outs = []
+    for g, p in zip(arr, problems):
+        A, B = _f(p["A"]), _f(p["B"])
+        tb = bool(p.get("transB", True))
+        M, K = A.shape
+        N = B.shape[0] if tb else B.shape[1]
+        out = p.get("out")
+        if out is None:
+            out = torch.zeros((M, N), device=A.device, dtype=torch.float32)
+        g.M = M; g.N = N; g.K = K; g.transB = int(tb)
+        g.A = ptr(A); g.A2 = ptr(p.get("A2")); g.lda = A.stride(0); g.B = ptr(B); g.ldb = B.stride(0)
+        if p.get("A_2nd") is not None:
+            A2n, B2n = p["A_2nd"], p["B_2nd"]
+            g.K2 = A2n.shape[1]; g.A_2nd = ptr(A2n); g.lda_2nd = A2n.stride(0); g.B_2nd = ptr(B2n); g.ldb_2nd = B2n.stride(0)
+        g.C = ptr(out); g.ldc = out.stride(0)
+        if p.get("out2") is not None:
+            g.C2 = ptr(p["out2"]); g.ldc2 = p["out2"].stride(0)
+        g.bias = ptr(p.get("bias")); g.accumulate = int(p.get("accumulate", False)); g.alpha = p.get("alpha", 1.0)
+        g.act = ACT[p.get("act", "none")]
+        g.drop_p = p.get("drop_p", 0.0); g.drop_seed = p.get("seed", 0); g.drop_site = p.get("site", 0)
+        if p.get("gate") is not None:
+            g.gate = ptr(p["gate"]); g.ldgate = p["gate"].stride(0); g.gate_scale = p.get("gate_scale", 1.0)
+        if p.get("dsig") is not None:
+            g.dsig = ptr(p["dsig"]); g.lddsig = p["dsig"].stride(0)
+        g.dsig2 = ptr(p.get("dsig2"))
+        outs.append(out)
+    check(lib.mmda_gemm_skinny(arr, len(problems), stream_ptr()), "mmda_gemm_skinny")
+    return outs
 
 def colsum(X, out=None, out2=None):
     lib = load()

@@ -53,6 +53,146 @@ def test_gemm_nn_tn_accumulate_alpha(mode):
     assert relerr(out, C0 - 0.5 * dY.t() @ X) < TOL[mode]
 
 
+# ------------------------------------------------------------------------------------------------ bf16-operand GEMM + conversion
+def test_convert_bf16_plain_transposed_gather_padding():
+    """fp32 -> bf16 copies (plain / transposed / gathered) are the round-to-nearest-even values with zero padding."""
+    from mmda_amd import ops
+    torch.manual_seed(3)
+    X = torch.randn(130, 37); W = torch.randn(1200, 300); E = torch.randn(50, 300)
+    ids = torch.randint(0, 50, (77,))
+    (Xp, Xt), (Wp, Wt), (Gp, Gt), (_, Tt) = ops.convert_bf16([
+        (X.to(dev()), None, True, True), (W.to(dev()), None, True, True), (E.to(dev()), ids.to(dev()), True, True),
+        (X.to(dev()), None, False, True)])
+    for src, P, T in ((X, Xp, Xt), (W, Wp, Wt), (E[ids], Gp, Gt), (X, None, Tt)):
+        ref = src.to(torch.bfloat16)
+        r, c = src.shape
+        if P is not None:
+            assert torch.equal(P.cpu()[:, :c], ref) and bool((P.cpu()[:, c:] == 0).all())
+        assert torch.equal(T.cpu()[:, :r], ref.t()) and bool((T.cpu()[:, r:] == 0).all())
+
+
+@pytest.mark.parametrize("M,N,K", [(1600, 2400, 300), (1600, 1200, 300), (128, 128, 64), (33, 70, 35), (7, 12, 768), (1600, 140, 40),
+                                   (300, 128, 1600)])
+def test_gemm_bf16_operands_nt_bias(M, N, K):
+    """C = A B^T + b + b2 on bf16 K-major operands: exact against fp32 matmul of the same bf16-rounded values (up to fp32
+    summation order), so the bar is the fp32 one."""
+    from mmda_amd import ops
+    torch.manual_seed(4)
+    A = torch.randn(M, K); W = torch.randn(N, K) / math.sqrt(K); b = torch.randn(N); b2 = torch.randn(N)
+    (Ap, _), (Wp, _) = ops.convert_bf16([(A.to(dev()), None, True, False), (W.to(dev()), None, True, False)])
+    ref = A.bfloat16().float() @ W.bfloat16().float().t() + b + b2
+    out, = ops.gemm_bf16_grouped([dict(A=Ap, B=Wp, K=K, bias=b.to(dev()), bias2=b2.to(dev()))])
+    assert relerr(out, ref) < TOL["fp32"]
+
+
+def test_gemm_bf16_grouped_backward_forms_bias_grad_accumulate():
+    """The three products of one LSTM layer's backward in one grouped launch, all in NT form on converted copies:
+    dX = dG W (B = W^T copy), dW += dG^T X (A = dG^T copy, B = X^T copy, bias gradient as the ones row, accumulate, alpha),
+    and a sub-matrix (row offset) operand as used by the time-shifted dW_hh product."""
+    from mmda_amd import ops
+    torch.manual_seed(5)
+    R, G4, I = 1600, 280, 35
+    dG = torch.randn(R, G4); W = torch.randn(G4, I) / 6; X = torch.randn(R, I); C0 = torch.randn(G4, I)
+    (dGp, dGt), (_, Wt), (_, Xt) = ops.convert_bf16([(dG.to(dev()), None, True, True), (W.to(dev()), None, False, True),
+                                                     (X.to(dev()), None, False, True)])
+    dGb, Wb, Xb = dG.bfloat16().float(), W.bfloat16().float(), X.bfloat16().float()
+    bg = torch.zeros(G4, device=dev()); bg2 = torch.ones(G4, device=dev())
+    shift = 64                                        # rows [shift, R) of dG against rows [0, R - shift) of X
+    outs = ops.gemm_bf16_grouped([
+        dict(A=dGp, B=Wt, K=G4),
+        dict(A=dGt, B=Xt, K=R, out=C0.clone().to(dev()), accumulate=True, alpha=-0.5, bias_grad=bg, bias_grad2=bg2),
+        dict(A=dGt[:, shift:].contiguous(), B=Xt[:, :Xt.shape[1] - shift].contiguous(), K=R - shift),
+    ])
+    assert relerr(outs[0], dGb @ Wb) < TOL["fp32"]
+    assert relerr(outs[1], C0 - 0.5 * dGb.t() @ Xb) < TOL["fp32"]
+    assert relerr(bg, dGb.sum(0)) < TOL["fp32"] and relerr(bg2, 1 + dGb.sum(0)) < TOL["fp32"]
+    assert relerr(outs[2], dGb[shift:].t() @ Xb[:R - shift]) < TOL["fp32"]
+
+
+def test_gemm_bf16_rejects_misaligned_operands():
+    from mmda_amd import ops, _lib
+    A = torch.zeros(16, 24, device=dev(), dtype=torch.bfloat16); B = torch.zeros(16, 24, device=dev(), dtype=torch.bfloat16)
+    with pytest.raises(_lib.MMDAError):
+        ops.gemm_bf16_grouped([dict(A=A, B=B, K=30)])            # K beyond the padded leading dimension
+
+
+
+# ------------------------------------------------------------------------------------------------ row-skinny f32 GEMM (fusion block)
+@pytest.mark.parametrize("M,N,K", [(32, 128, 1200), (32, 128, 140), (32, 128, 296), (96, 128, 128), (192, 384, 128), (192, 2048, 128),
+                                   (192, 128, 2048), (32, 12, 768), (7, 5, 3), (33, 17, 70), (1, 128, 16)])
+def test_gemm_skinny_nt_bias_act(M, N, K):
+    """y = act(x W^T + b): every forward Linear of the fusion block, plus ragged shapes that take the scalar-load path."""
+    from mmda_amd import ops
+    torch.manual_seed(6)
+    A = torch.randn(M, K); W = torch.randn(N, K) / math.sqrt(K); b = torch.randn(N)
+    for act, f in (("none", lambda t: t), ("sigmoid", torch.sigmoid), ("relu", torch.relu)):
+        out, = ops.gemm_skinny([dict(A=A.to(dev()), B=W.to(dev()), bias=b.to(dev()), act=act)])
+        assert relerr(out, f(A @ W.t() + b)) < TOL["fp32"], act
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 768, 12), (192, 2048, 128), (192, 128, 2048), (192, 128, 384), (32, 1200, 128), (96, 128, 3),
+                                   (33, 70, 17)])
+def test_gemm_skinny_nn_accumulate_alpha(M, N, K):
+    """dx (+)= alpha * dy W (W is (K, N), n contiguous): every input gradient of the fusion block."""
+    from mmda_amd import ops
+    torch.manual_seed(7)
+    dY = torch.randn(M, K); W = torch.randn(K, N) / math.sqrt(K); C0 = torch.randn(M, N)
+    out, = ops.gemm_skinny([dict(A=dY.to(dev()), B=W.to(dev()), transB=False)])
+    assert relerr(out, dY @ W) < TOL["fp32"]
+    out, = ops.gemm_skinny([dict(A=dY.to(dev()), B=W.to(dev()), transB=False, out=C0.clone().to(dev()), accumulate=True, alpha=-0.25)])
+    assert relerr(out, C0 - 0.25 * dY @ W) < TOL["fp32"]
+
+
+def test_gemm_skinny_grouped_epilogues():
+    """One launch, several problems: A + A2 operand, two products into one output, second destination with its own sigmoid
+    factor, relu gate, unaligned operand bases (scalar path) next to aligned ones; the launch is bitwise reproducible."""
+    from mmda_amd import ops
+    torch.manual_seed(8)
+    B_, hs = 32, 128
+    priv = torch.rand(B_, hs); shared = torch.rand(B_, hs); Wr = torch.randn(hs, hs) / 11; br = torch.randn(hs)
+    d1 = torch.randn(B_, hs); W1 = torch.randn(hs, hs) / 11; d2 = torch.randn(B_, hs); W2 = torch.randn(hs, hs) / 11; C0 = torch.randn(B_, hs)
+    dr = torch.randn(B_, hs); s1 = torch.rand(B_, hs); s2 = torch.rand(B_, hs); ca = torch.randn(B_, hs); cb = torch.randn(B_, hs)
+    df2 = torch.randn(192, hs); W_l2 = torch.randn(hs, 2048) / 11; f1 = torch.relu(torch.randn(192, 2048))
+    big = torch.randn(hs * hs + 1, device=dev())
+    W_un = big[1:].view(hs, hs)                          # 4-byte aligned only: scalar-load path
+    xs = torch.randn(B_, hs)
+
+    def run():
+        ca_d, cb_d = ca.clone().to(dev()), cb.clone().to(dev())
+        outs = ops.gemm_skinny([
+            dict(A=priv.to(dev()), A2=shared.to(dev()), B=Wr.to(dev()), bias=br.to(dev())),
+            dict(A=d1.to(dev()), B=W1.to(dev()), A_2nd=d2.to(dev()), B_2nd=W2.to(dev()), transB=False, out=C0.clone().to(dev()),
+                 accumulate=True),
+            dict(A=dr.to(dev()), B=Wr.to(dev()), transB=False, out=ca_d, out2=cb_d, accumulate=True, dsig=s1.to(dev()), dsig2=s2.to(dev())),
+            dict(A=df2.to(dev()), B=W_l2.to(dev()), transB=False, gate=f1.to(dev()), gate_scale=1.25),
+            dict(A=xs.to(dev()), B=W_un),
+        ])
+        return outs + [cb_d]
+
+    o = run()
+    assert relerr(o[0], (priv + shared) @ Wr.t() + br) < TOL["fp32"]
+    assert relerr(o[1], C0 + d1 @ W1 + d2 @ W2) < TOL["fp32"]
+    assert relerr(o[2], (ca + dr @ Wr) * s1 * (1 - s1)) < TOL["fp32"]
+    assert relerr(o[5], (cb + dr @ Wr) * s2 * (1 - s2)) < TOL["fp32"]
+    assert relerr(o[3], (df2 @ W_l2) * (f1 > 0) * 1.25) < TOL["fp32"]
+    assert relerr(o[4], xs @ W_un.cpu().t()) < TOL["fp32"]
+    o2 = run()
+    for x, y in zip(o, o2):
+        assert torch.equal(x, y), "fixed-order reduction must be bitwise reproducible"
+
+
+def test_gemm_skinny_dropout_matches_generic_kernel_mask():
+    """Same (seed, site, m*N+n) stream as mmda_gemm: the FFN's dropout mask does not depend on which kernel computed it."""
+    from mmda_amd import ops
+    torch.manual_seed(9)
+    x = torch.randn(192, 128, device=dev()); W = torch.randn(2048, 128, device=dev()) / 11; b = torch.randn(2048, device=dev())
+    a = ops.gemm(x, W, mode="fp32", bias=b, act="relu", drop_p=0.1, seed=77, site=3)
+    s, = ops.gemm_skinny([dict(A=x, B=W, bias=b, act="relu", drop_p=0.1, seed=77, site=3)])
+    assert torch.equal(a == 0, s == 0)
+    assert relerr(s, a) < TOL["fp32"]
+
+
+
 @pytest.mark.parametrize("shape", ["tn_dwih", "nn_dx", "tn_dwhh_offsets", "nt_small_k"])
 def test_gemm_128_tile_kernel_lstm_shapes(shape):
     """The aligned bf16 fast kernel (128x128 tile, 16-byte staging) on the LSTM-sized GEMMs of the backward pass,

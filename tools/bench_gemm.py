@@ -31,3 +31,28 @@ for name, s in shapes:
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / n
         print(f"{name:26s} M={M:5d} N={N:5d} K={K:5d} {mode}: {us:8.1f} us  {2.0*M*N*K/us/1e6:8.1f} TFLOP/s")
+    # bf16-operand NT kernel on pre-converted copies (conversion timed separately below)
+    Kp = (K + 7) // 8 * 8
+    Ab = torch.randn(M, Kp, device=d).bfloat16(); Bb = torch.randn(N, Kp, device=d).bfloat16()
+    prob = [dict(A=Ab, B=Bb, K=K, out=out, accumulate=True)]
+    for _ in range(3):
+        ops.gemm_bf16_grouped(prob)
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        ops.gemm_bf16_grouped(prob)
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / 20
+    print(f"{name:26s} M={M:5d} N={N:5d} K={K:5d} bf16-operands: {us:8.1f} us  {2.0*M*N*K/us/1e6:8.1f} TFLOP/s")
+for rows, cols in ((R, 300), (R, 2400), (2400, 300), (R, 600)):
+    X = torch.randn(rows, cols, device=d)
+    for _ in range(3):
+        ops.convert_bf16([(X, None, True, True)])
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        ops.convert_bf16([(X, None, True, True)])
+    e1.record(); torch.cuda.synchronize()
+    print(f"convert {rows}x{cols} plain+transposed: {e0.elapsed_time(e1) * 1e3 / 20:8.1f} us (includes torch.full fills)")
