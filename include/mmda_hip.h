@@ -160,6 +160,13 @@ typedef struct mmda_ln_bwd_args {
   int permute_S, permute_B;
 } mmda_ln_bwd_args;
 int mmda_layernorm_bwd(const mmda_ln_bwd_args* a, void* stream);
+/* Several independent LayerNorms in one launch (the three modalities'): results as n single calls. */
+int mmda_layernorm_fwd_multi(const mmda_ln_args* args, int n, void* stream);
+int mmda_layernorm_bwd_multi(const mmda_ln_bwd_args* args, int n, void* stream);
+/* dgamma / dbeta alone (same argument struct; d_x / d_res are ignored).  With dgamma = dbeta = NULL mmda_layernorm_bwd computes
+ * only the input gradients, so the parameter gradients of the large inter-layer LayerNorms (rows = T*B) can run on another
+ * stream, off the path into the next recurrent kernel. */
+int mmda_layernorm_param_grads(const mmda_ln_bwd_args* args, int n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- biLSTM
  * Recurrent part of nn.LSTM(bidirectional=True) on a packed sequence (models.py:48-55 via extract_features

@@ -100,6 +100,9 @@ SIGNATURES = {
     "mmda_embed_scatter_add": (_I, [_P, _P, _I, _I, _P, _P]),
     "mmda_layernorm_fwd": (_I, [C.POINTER(LnArgs), _P]),
     "mmda_layernorm_bwd": (_I, [C.POINTER(LnBwdArgs), _P]),
+    "mmda_layernorm_fwd_multi": (_I, [C.POINTER(LnArgs), _I, _P]),
+    "mmda_layernorm_bwd_multi": (_I, [C.POINTER(LnBwdArgs), _I, _P]),
+    "mmda_layernorm_param_grads": (_I, [C.POINTER(LnBwdArgs), _I, _P]),
     "mmda_lstm_packed_bytes": (_I64, [_I, _I, _I]),
     "mmda_lstm_xchg_bytes": (_I64, [_I, _I]),
     "mmda_debug_set_lstm_stamps": (_I, [_P]),

@@ -261,6 +261,7 @@ void gemm(Ctx& c, int mode, int tA, int tB, int M, int N, int K, const float* A,
 
 // Fork/join with the side stream: everything in `list` only has to be finished before the optimizer step, so it runs
 // concurrently with the recurrent kernels (which occupy ~10 % of the CUs while they walk the serial chain).
+int side_fork(mmda_misa* m, void* main_stream, void** out);
 int side_launch(mmda_misa* m, std::vector<mmda_gemm_args>& list, void* main_stream);
 int side_join(mmda_misa* m, void* main_stream);
 // y(M,N) = x(M,K) W(N,K)^T + b
@@ -278,6 +279,24 @@ void lin_dw(Ctx& c, int mode, int M, int N, int K, const float* dy, const float*
   gemm(c, mode, 1, 0, N, K, M, dy, N, x, K, dW, K, nullptr, nullptr, 1, 0, 1, 0, 0, 0, 0, &e);
 }
 
+// ---- row-skinny forms (fusion block at B <= SKINNY_MAX_B): see gemm_skinny.hip
+constexpr int SKINNY_MAX_B = 64;
+// y(M,N) = act(x(M,K) W(N,K)^T + b)
+mmda_skinny_args sk_nt(int M, int N, int K, const float* x, int ldx, const float* W, const float* b, float* y, int ldy, int act = 0) {
+  mmda_skinny_args g = {};
+  g.M = M; g.N = N; g.K = K; g.transB = 1; g.A = x; g.lda = ldx; g.B = W; g.ldb = K; g.C = y; g.ldc = ldy; g.bias = b; g.act = act;
+  return g;
+}
+// dx(M,K) (+)= dy(M,N) W(N,K)
+mmda_skinny_args sk_nn(int M, int N, int K, const float* dy, int lddy, const float* W, float* dx, int lddx, int acc) {
+  mmda_skinny_args g = {};
+  g.M = M; g.N = K; g.K = N; g.transB = 0; g.A = dy; g.lda = lddy; g.B = W; g.ldb = K; g.C = dx; g.ldc = lddx; g.accumulate = acc;
+  return g;
+}
+void sk_launch(Ctx& c, const mmda_skinny_args* p, int n) {
+  if (!c.rc) c.rc = mmda_gemm_skinny(p, n, c.s);
+}
+
 __global__ void total_loss_kernel(float* L, float dw, float sw, float rw, float cw, int use_conf) {
   // L: cls, diff, sim, recon, conf, total   (solver.py:175-181)
   float t = L[0] + dw * L[1] + sw * L[2] + rw * L[3];
@@ -290,10 +309,11 @@ void ev_rec(mmda_misa* m, int step, int slot, int which, void* stream) {
   (void)hipEventRecord(m->ev[(step * 4 + slot) * 2 + which], (hipStream_t)stream);
 }
 
-int side_launch(mmda_misa* m, std::vector<mmda_gemm_args>& list, void* main_stream) {
-  if (list.empty()) return MMDA_OK;
-  int rc;
-  if (!m->use_side) { rc = mmda_gemm_grouped(list.data(), (int)list.size(), main_stream); list.clear(); return rc; }
+// Fork: work issued on the returned stream starts after everything already on `main_stream` and runs beside what follows
+// there; side_join() makes `main_stream` wait for it.  Without overlap the main stream itself is returned.
+int side_fork(mmda_misa* m, void* main_stream, void** out) {
+  *out = main_stream;
+  if (!m->use_side) return MMDA_OK;
   if (!m->side) {
     if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess) return MMDA_ELAUNCH;
     if (hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess) return MMDA_ELAUNCH;
@@ -301,9 +321,16 @@ int side_launch(mmda_misa* m, std::vector<mmda_gemm_args>& list, void* main_stre
   }
   if (hipEventRecord(m->ev_fork, (hipStream_t)main_stream) != hipSuccess) return MMDA_ELAUNCH;
   if (hipStreamWaitEvent(m->side, m->ev_fork, 0) != hipSuccess) return MMDA_ELAUNCH;
-  rc = mmda_gemm_grouped(list.data(), (int)list.size(), m->side);
-  list.clear();
   m->side_pending = 1;
+  *out = m->side;
+  return MMDA_OK;
+}
+int side_launch(mmda_misa* m, std::vector<mmda_gemm_args>& list, void* main_stream) {
+  if (list.empty()) return MMDA_OK;
+  void* ss = nullptr;
+  int rc = side_fork(m, main_stream, &ss);
+  if (!rc) rc = mmda_gemm_grouped(list.data(), (int)list.size(), ss);
+  list.clear();
   return rc;
 }
 int side_join(mmda_misa* m, void* main_stream) {
@@ -425,7 +452,8 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
   m->training = training; m->seed = seed;
   const float p_tf = training ? c.fusion_dropout : 0.f, p_cls = training ? c.dropout : 0.f;
 
-  // W_hh -> MFMA fragment order (weights changed since the last step): all twelve matrices in one launch
+  // W_hh -> MFMA fragment order (weights changed since the last step): all twelve matrices in one launch, on the side stream
+  // underneath the embedding gather and the first input GEMM; joined before the first recurrent kernel.
   {
     int Hs[12]; const float* Wp[12]; void* Fp[12]; void* Bp[12]; void* Cp[12];
     int k = 0;
@@ -436,7 +464,9 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
           Hs[k] = r.H; Wp[k] = PP(r.w_hh[d]); Fp[k] = WS(r.pack_f[d]); Bp[k] = WS(r.pack_b[d]); Cp[k] = WS(r.pack_c[d]);
         }
     const bool want_c = m->use_cluster && mode == MMDA_BF16;
-    x.rc = mmda_lstm_pack_whh_multi(mode, 12, Hs, Wp, Fp, Bp, want_c ? Cp : nullptr, stream);
+    void* ss = nullptr;
+    x.rc = side_fork(m, stream, &ss);
+    if (!x.rc) x.rc = mmda_lstm_pack_whh_multi(mode, 12, Hs, Wp, Fp, Bp, want_c ? Cp : nullptr, ss);
     m->packed_c_valid = want_c ? 1 : 0;
   }
   if (x.rc) return x.rc;
@@ -459,77 +489,144 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
     }
     m->epoch += (unsigned)T + 2u;
     group_end(x);
+    if (!x.rc && l == 0) x.rc = side_join(m, stream);       // packed W_hh ready
     if (x.rc) return x.rc;
     ev_rec(m, m->ev_fwd, l, 0, stream);
     x.rc = mmda_lstm_fwd(mode, 3, desc, B, T, lengths, stream);
     ev_rec(m, m->ev_fwd, l, 1, stream);
     if (x.rc) return x.rc;
-    if (l == 0)
-      for (int i = 0; i < 3 && !x.rc; ++i) {
+    if (l == 0) {
+      mmda_ln_args ln[3];
+      for (int i = 0; i < 3; ++i) {
         Mod& md = m->mod[i];
-        mmda_ln_args ln = {};
-        ln.rows = R; ln.n = 2 * md.H; ln.x = WS(md.hseq[0]); ln.gamma = PP(md.ln_w); ln.beta = PP(md.ln_b);
-        ln.y = WS(md.normed); ln.mean = WS(md.ln_mean); ln.rstd = WS(md.ln_rstd); ln.eps = 1e-5f;
-        x.rc = mmda_layernorm_fwd(&ln, stream);
+        ln[i] = mmda_ln_args{};
+        ln[i].rows = R; ln[i].n = 2 * md.H; ln[i].x = WS(md.hseq[0]); ln[i].gamma = PP(md.ln_w); ln[i].beta = PP(md.ln_b);
+        ln[i].y = WS(md.normed); ln[i].mean = WS(md.ln_mean); ln[i].rstd = WS(md.ln_rstd); ln[i].eps = 1e-5f;
       }
+      x.rc = mmda_layernorm_fwd_multi(ln, 3, stream);
+    }
   }
   if (x.rc) return x.rc;
   // shared_private (models.py:265-279)
   const int64_t BH = (int64_t)B * hs;
-  for (int i = 0; i < 3 && !x.rc; ++i) {
-    Mod& md = m->mod[i];
-    lin_fwd(x, fmode, B, hs, 4 * md.H, WS(md.utt), PP(md.pw), PP(md.pb), WS(m->z + i * BH));
-    if (x.rc) break;
-    mmda_ln_args ln = {};
-    ln.rows = B; ln.n = hs; ln.x = WS(m->z + i * BH); ln.gamma = PP(md.plw); ln.beta = PP(md.plb); ln.y = WS(m->orig + i * BH);
-    ln.mean = WS(m->pmean + i * B); ln.rstd = WS(m->prstd + i * B); ln.act = c.act; ln.eps = 1e-5f;
-    x.rc = mmda_layernorm_fwd(&ln, stream);
+  if (B <= SKINNY_MAX_B) {
+    // ---- few rows: row-skinny GEMMs, independent ones grouped per launch (12 launches for the whole block)
+    mmda_skinny_args g[8];
+    mmda_ln_args ln[3];
+    for (int i = 0; i < 3; ++i) {
+      Mod& md = m->mod[i];
+      g[i] = sk_nt(B, hs, 4 * md.H, WS(md.utt), 4 * md.H, PP(md.pw), PP(md.pb), WS(m->z + i * BH), hs);
+      ln[i] = mmda_ln_args{};
+      ln[i].rows = B; ln[i].n = hs; ln[i].x = WS(m->z + i * BH); ln[i].gamma = PP(md.plw); ln[i].beta = PP(md.plb);
+      ln[i].y = WS(m->orig + i * BH); ln[i].mean = WS(m->pmean + i * B); ln[i].rstd = WS(m->prstd + i * B); ln[i].act = c.act;
+      ln[i].eps = 1e-5f;
+    }
+    sk_launch(x, g, 3);
+    if (!x.rc) x.rc = mmda_layernorm_fwd_multi(ln, 3, stream);
+    // private x3 and shared (one weight over the stacked 3B rows), sigmoid epilogue
+    for (int i = 0; i < 3; ++i)
+      g[i] = sk_nt(B, hs, hs, WS(m->orig + i * BH), hs, PP(m->priv_w + (int64_t)i * hs * hs), PP(m->priv_b + i * hs), WS(m->x6 + i * BH), hs,
+                   MMDA_ACT_SIGMOID);
+    g[3] = sk_nt(3 * B, hs, hs, WS(m->orig), hs, PP(m->sh_w), PP(m->sh_b), WS(m->x6 + 3 * BH), hs, MMDA_ACT_SIGMOID);
+    sk_launch(x, g, 4);
+    // reconstruct from private + shared (models.py:254-262), the q/k/v projection of the six tokens (models.py:243) and the
+    // discriminator's first layer all read x6 only
+    int n = 0;
+    for (int i = 0; i < 3; ++i) {
+      g[n] = sk_nt(B, hs, hs, WS(m->x6 + i * BH), hs, PP(m->rec_w + (int64_t)i * hs * hs), PP(m->rec_b + i * hs), WS(m->recon + i * BH), hs);
+      g[n++].A2 = WS(m->x6 + (3 + i) * BH);
+    }
+    g[n++] = sk_nt(6 * B, 3 * hs, hs, WS(m->x6), hs, PP(m->in_w), PP(m->in_b), WS(m->qkv), 3 * hs);
+    if (!c.use_cmd_sim) g[n++] = sk_nt(3 * B, hs, hs, WS(m->x6 + 3 * BH), hs, PP(m->d1_w), PP(m->d1_b), WS(m->dom_z), hs);
+    sk_launch(x, g, n);
+    if (!c.use_cmd_sim && !x.rc)
+      x.rc = mmda_act_dropout_fwd(WS(m->dom_z), WS(m->dom_h), 3 * BH, c.act, p_cls, seed, SITE_DISC, stream);
+    if (!x.rc) x.rc = mmda_attn_fwd(WS(m->qkv), S6, B, hs, NHEAD, WS(m->ctx), WS(m->probs), p_tf, seed, SITE_ATTN, stream);
+    n = 0;
+    g[n++] = sk_nt(6 * B, hs, hs, WS(m->ctx), hs, PP(m->out_w), PP(m->out_b), WS(m->attn_out), hs);
+    if (!c.use_cmd_sim) g[n++] = sk_nt(3 * B, 3, hs, WS(m->dom_h), hs, PP(m->d2_w), PP(m->d2_b), WS(m->dom), 3);
+    sk_launch(x, g, n);
+    if (!x.rc) {
+      mmda_ln_args l1 = {};
+      l1.rows = 6 * B; l1.n = hs; l1.x = WS(m->x6); l1.res = WS(m->attn_out); l1.gamma = PP(m->n1_w); l1.beta = PP(m->n1_b);
+      l1.y = WS(m->x1); l1.mean = WS(m->ln1_mean); l1.rstd = WS(m->ln1_rstd); l1.drop_p = p_tf; l1.drop_seed = seed;
+      l1.drop_site = SITE_DROP1; l1.eps = 1e-5f;
+      x.rc = mmda_layernorm_fwd(&l1, stream);
+    }
+    g[0] = sk_nt(6 * B, FFN, hs, WS(m->x1), hs, PP(m->l1_w), PP(m->l1_b), WS(m->f1), FFN, MMDA_ACT_RELU);
+    g[0].drop_p = p_tf; g[0].drop_seed = seed; g[0].drop_site = SITE_FFN;
+    sk_launch(x, g, 1);
+    g[0] = sk_nt(6 * B, hs, FFN, WS(m->f1), FFN, PP(m->l2_w), PP(m->l2_b), WS(m->f2), hs);
+    sk_launch(x, g, 1);
+    if (!x.rc) {
+      mmda_ln_args l2 = {};
+      l2.rows = 6 * B; l2.n = hs; l2.x = WS(m->x1); l2.res = WS(m->f2); l2.gamma = PP(m->n2_w); l2.beta = PP(m->n2_b);
+      l2.y = WS(m->hfused); l2.mean = WS(m->ln2_mean); l2.rstd = WS(m->ln2_rstd); l2.drop_p = p_tf; l2.drop_seed = seed;
+      l2.drop_site = SITE_DROP2; l2.permute_S = S6; l2.permute_B = B; l2.eps = 1e-5f;   // emits h = cat(h[0..5], dim=1)
+      x.rc = mmda_layernorm_fwd(&l2, stream);
+    }
+    g[0] = sk_nt(B, NC, 6 * hs, WS(m->hfused), 6 * hs, PP(m->head_w), PP(m->head_b), WS(m->logits), NC);
+    sk_launch(x, g, 1);
+    if (!x.rc)
+      x.rc = mmda_heads_fwd(WS(m->logits), B, c.ncls, c.threshold, WS(m->tcp), WS(m->scores), WS(m->labels), p_cls, seed, SITE_CLS,
+                            stream);
+  } else {
+    // ---- many rows: the tiled generic kernel
+    for (int i = 0; i < 3 && !x.rc; ++i) {
+      Mod& md = m->mod[i];
+      lin_fwd(x, fmode, B, hs, 4 * md.H, WS(md.utt), PP(md.pw), PP(md.pb), WS(m->z + i * BH));
+      if (x.rc) break;
+      mmda_ln_args ln = {};
+      ln.rows = B; ln.n = hs; ln.x = WS(m->z + i * BH); ln.gamma = PP(md.plw); ln.beta = PP(md.plb); ln.y = WS(m->orig + i * BH);
+      ln.mean = WS(m->pmean + i * B); ln.rstd = WS(m->prstd + i * B); ln.act = c.act; ln.eps = 1e-5f;
+      x.rc = mmda_layernorm_fwd(&ln, stream);
+    }
+    // private (three weights, batched) and shared (one weight over the stacked 3B rows), sigmoid epilogue
+    gemm(x, fmode, 0, 1, B, hs, hs, WS(m->orig), hs, PP(m->priv_w), hs, WS(m->x6), hs, PP(m->priv_b), nullptr, 0, MMDA_ACT_SIGMOID, 3,
+         BH, (int64_t)hs * hs, BH, hs);
+    gemm(x, fmode, 0, 1, 3 * B, hs, hs, WS(m->orig), hs, PP(m->sh_w), hs, WS(m->x6 + 3 * BH), hs, PP(m->sh_b), nullptr, 0,
+         MMDA_ACT_SIGMOID);
+    // reconstruct (models.py:254-262)
+    if (!x.rc) x.rc = mmda_add(WS(m->x6), WS(m->x6 + 3 * BH), WS(m->rsum), 3 * BH, stream);
+    gemm(x, fmode, 0, 1, B, hs, hs, WS(m->rsum), hs, PP(m->rec_w), hs, WS(m->recon), hs, PP(m->rec_b), nullptr, 0, 0, 3, BH,
+         (int64_t)hs * hs, BH, hs);
+    // adversarial discriminator behind the gradient-reversal layer (models.py:219-227); identity in forward
+    if (!c.use_cmd_sim) {
+      lin_fwd(x, fmode, 3 * B, hs, hs, WS(m->x6 + 3 * BH), PP(m->d1_w), PP(m->d1_b), WS(m->dom_z));
+      if (!x.rc) x.rc = mmda_act_dropout_fwd(WS(m->dom_z), WS(m->dom_h), 3 * BH, c.act, p_cls, seed, SITE_DISC, stream);
+      lin_fwd(x, fmode, 3 * B, 3, hs, WS(m->dom_h), PP(m->d2_w), PP(m->d2_b), WS(m->dom));
+    }
+    // 1-layer transformer fusion over the six tokens (models.py:243-245; torch post-norm encoder layer)
+    lin_fwd(x, fmode, 6 * B, 3 * hs, hs, WS(m->x6), PP(m->in_w), PP(m->in_b), WS(m->qkv));
+    if (!x.rc) x.rc = mmda_attn_fwd(WS(m->qkv), S6, B, hs, NHEAD, WS(m->ctx), WS(m->probs), p_tf, seed, SITE_ATTN, stream);
+    lin_fwd(x, fmode, 6 * B, hs, hs, WS(m->ctx), PP(m->out_w), PP(m->out_b), WS(m->attn_out));
+    if (!x.rc) {
+      mmda_ln_args ln = {};
+      ln.rows = 6 * B; ln.n = hs; ln.x = WS(m->x6); ln.res = WS(m->attn_out); ln.gamma = PP(m->n1_w); ln.beta = PP(m->n1_b);
+      ln.y = WS(m->x1); ln.mean = WS(m->ln1_mean); ln.rstd = WS(m->ln1_rstd); ln.drop_p = p_tf; ln.drop_seed = seed;
+      ln.drop_site = SITE_DROP1; ln.eps = 1e-5f;
+      x.rc = mmda_layernorm_fwd(&ln, stream);
+    }
+    {
+      mmda_gemm_args e = {};
+      e.drop_p = p_tf; e.drop_seed = seed; e.drop_site = SITE_FFN;
+      gemm(x, fmode, 0, 1, 6 * B, FFN, hs, WS(m->x1), hs, PP(m->l1_w), hs, WS(m->f1), FFN, PP(m->l1_b), nullptr, 0, MMDA_ACT_RELU, 1, 0,
+           0, 0, 0, &e);
+    }
+    lin_fwd(x, fmode, 6 * B, hs, FFN, WS(m->f1), PP(m->l2_w), PP(m->l2_b), WS(m->f2));
+    if (!x.rc) {
+      mmda_ln_args ln = {};
+      ln.rows = 6 * B; ln.n = hs; ln.x = WS(m->x1); ln.res = WS(m->f2); ln.gamma = PP(m->n2_w); ln.beta = PP(m->n2_b);
+      ln.y = WS(m->hfused); ln.mean = WS(m->ln2_mean); ln.rstd = WS(m->ln2_rstd); ln.drop_p = p_tf; ln.drop_seed = seed;
+      ln.drop_site = SITE_DROP2; ln.permute_S = S6; ln.permute_B = B; ln.eps = 1e-5f;   // emits h = cat(h[0..5], dim=1)
+      x.rc = mmda_layernorm_fwd(&ln, stream);
+    }
+    // heads (models.py:247-249)
+    lin_fwd(x, fmode, B, NC, 6 * hs, WS(m->hfused), PP(m->head_w), PP(m->head_b), WS(m->logits));
+    if (!x.rc)
+      x.rc = mmda_heads_fwd(WS(m->logits), B, c.ncls, c.threshold, WS(m->tcp), WS(m->scores), WS(m->labels), p_cls, seed, SITE_CLS,
+                            stream);
   }
-  // private (three weights, batched) and shared (one weight over the stacked 3B rows), sigmoid epilogue
-  gemm(x, fmode, 0, 1, B, hs, hs, WS(m->orig), hs, PP(m->priv_w), hs, WS(m->x6), hs, PP(m->priv_b), nullptr, 0, MMDA_ACT_SIGMOID, 3,
-       BH, (int64_t)hs * hs, BH, hs);
-  gemm(x, fmode, 0, 1, 3 * B, hs, hs, WS(m->orig), hs, PP(m->sh_w), hs, WS(m->x6 + 3 * BH), hs, PP(m->sh_b), nullptr, 0,
-       MMDA_ACT_SIGMOID);
-  // reconstruct (models.py:254-262)
-  if (!x.rc) x.rc = mmda_add(WS(m->x6), WS(m->x6 + 3 * BH), WS(m->rsum), 3 * BH, stream);
-  gemm(x, fmode, 0, 1, B, hs, hs, WS(m->rsum), hs, PP(m->rec_w), hs, WS(m->recon), hs, PP(m->rec_b), nullptr, 0, 0, 3, BH,
-       (int64_t)hs * hs, BH, hs);
-  // adversarial discriminator behind the gradient-reversal layer (models.py:219-227); identity in forward
-  if (!c.use_cmd_sim) {
-    lin_fwd(x, fmode, 3 * B, hs, hs, WS(m->x6 + 3 * BH), PP(m->d1_w), PP(m->d1_b), WS(m->dom_z));
-    if (!x.rc) x.rc = mmda_act_dropout_fwd(WS(m->dom_z), WS(m->dom_h), 3 * BH, c.act, p_cls, seed, SITE_DISC, stream);
-    lin_fwd(x, fmode, 3 * B, 3, hs, WS(m->dom_h), PP(m->d2_w), PP(m->d2_b), WS(m->dom));
-  }
-  // 1-layer transformer fusion over the six tokens (models.py:243-245; torch post-norm encoder layer)
-  lin_fwd(x, fmode, 6 * B, 3 * hs, hs, WS(m->x6), PP(m->in_w), PP(m->in_b), WS(m->qkv));
-  if (!x.rc) x.rc = mmda_attn_fwd(WS(m->qkv), S6, B, hs, NHEAD, WS(m->ctx), WS(m->probs), p_tf, seed, SITE_ATTN, stream);
-  lin_fwd(x, fmode, 6 * B, hs, hs, WS(m->ctx), PP(m->out_w), PP(m->out_b), WS(m->attn_out));
-  if (!x.rc) {
-    mmda_ln_args ln = {};
-    ln.rows = 6 * B; ln.n = hs; ln.x = WS(m->x6); ln.res = WS(m->attn_out); ln.gamma = PP(m->n1_w); ln.beta = PP(m->n1_b);
-    ln.y = WS(m->x1); ln.mean = WS(m->ln1_mean); ln.rstd = WS(m->ln1_rstd); ln.drop_p = p_tf; ln.drop_seed = seed;
-    ln.drop_site = SITE_DROP1; ln.eps = 1e-5f;
-    x.rc = mmda_layernorm_fwd(&ln, stream);
-  }
-  {
-    mmda_gemm_args e = {};
-    e.drop_p = p_tf; e.drop_seed = seed; e.drop_site = SITE_FFN;
-    gemm(x, fmode, 0, 1, 6 * B, FFN, hs, WS(m->x1), hs, PP(m->l1_w), hs, WS(m->f1), FFN, PP(m->l1_b), nullptr, 0, MMDA_ACT_RELU, 1, 0,
-         0, 0, 0, &e);
-  }
-  lin_fwd(x, fmode, 6 * B, hs, FFN, WS(m->f1), PP(m->l2_w), PP(m->l2_b), WS(m->f2));
-  if (!x.rc) {
-    mmda_ln_args ln = {};
-    ln.rows = 6 * B; ln.n = hs; ln.x = WS(m->x1); ln.res = WS(m->f2); ln.gamma = PP(m->n2_w); ln.beta = PP(m->n2_b);
-    ln.y = WS(m->hfused); ln.mean = WS(m->ln2_mean); ln.rstd = WS(m->ln2_rstd); ln.drop_p = p_tf; ln.drop_seed = seed;
-    ln.drop_site = SITE_DROP2; ln.permute_S = S6; ln.permute_B = B; ln.eps = 1e-5f;   // emits h = cat(h[0..5], dim=1)
-    x.rc = mmda_layernorm_fwd(&ln, stream);
-  }
-  // heads (models.py:247-249)
-  lin_fwd(x, fmode, B, NC, 6 * hs, WS(m->hfused), PP(m->head_w), PP(m->head_b), WS(m->logits));
-  if (!x.rc)
-    x.rc = mmda_heads_fwd(WS(m->logits), B, c.ncls, c.threshold, WS(m->tcp), WS(m->scores), WS(m->labels), p_cls, seed, SITE_CLS,
-                          stream);
   if (!m->ev.empty()) m->ev_fwd++;
   return x.rc;
 }
@@ -597,87 +694,192 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
   // Weight-gradient GEMMs of the fusion block are collected and issued as one grouped launch on the side stream once
   // the dX chain (the critical path into the encoders) is through; their inputs are not modified afterwards.
   x.deferring = true;
-  // heads
-  x.rc = mmda_heads_bwd(WS(m->tcp), WS(m->scores), WS(m->d_tcp), WS(m->d_scores), B, c.ncls, WS(m->d_logits), p_cls, seed, SITE_CLS,
-                        stream);
-  lin_dx(x, fmode, B, NC, 6 * hs, WS(m->d_logits), PP(m->head_w), WS(m->d_hfused), 0);
-  lin_dw(x, fmode, B, NC, 6 * hs, WS(m->d_logits), WS(m->hfused), GG(m->head_w), GG(m->head_b));
-  // norm2 + FFN
-  if (!x.rc) {
-    mmda_ln_bwd_args l = {};
-    l.rows = 6 * B; l.n = hs; l.dy = WS(m->d_hfused); l.x = WS(m->x1); l.res = WS(m->f2); l.gamma = PP(m->n2_w);
-    l.mean = WS(m->ln2_mean); l.rstd = WS(m->ln2_rstd); l.d_x = WS(m->d_x1); l.d_res = WS(m->d_f2);
-    l.dgamma = GG(m->n2_w); l.dbeta = GG(m->n2_b); l.drop_p = p_tf; l.drop_seed = seed; l.drop_site = SITE_DROP2;
-    l.permute_S = S6; l.permute_B = B;
-    x.rc = mmda_layernorm_bwd(&l, stream);
-  }
-  {
+  if (B <= SKINNY_MAX_B) {
+    // ---- few rows: the dX chain on row-skinny GEMMs (13 launches); weight gradients deferred exactly as below
+    mmda_skinny_args g[8];
+    x.rc = mmda_heads_bwd(WS(m->tcp), WS(m->scores), WS(m->d_tcp), WS(m->d_scores), B, c.ncls, WS(m->d_logits), p_cls, seed, SITE_CLS,
+                          stream);
+    g[0] = sk_nn(B, NC, 6 * hs, WS(m->d_logits), NC, PP(m->head_w), WS(m->d_hfused), 6 * hs, 0);
+    sk_launch(x, g, 1);
+    lin_dw(x, fmode, B, NC, 6 * hs, WS(m->d_logits), WS(m->hfused), GG(m->head_w), GG(m->head_b));
+    // norm2 + FFN
+    if (!x.rc) {
+      mmda_ln_bwd_args l = {};
+      l.rows = 6 * B; l.n = hs; l.dy = WS(m->d_hfused); l.x = WS(m->x1); l.res = WS(m->f2); l.gamma = PP(m->n2_w);
+      l.mean = WS(m->ln2_mean); l.rstd = WS(m->ln2_rstd); l.d_x = WS(m->d_x1); l.d_res = WS(m->d_f2);
+      l.dgamma = GG(m->n2_w); l.dbeta = GG(m->n2_b); l.drop_p = p_tf; l.drop_seed = seed; l.drop_site = SITE_DROP2;
+      l.permute_S = S6; l.permute_B = B;
+      x.rc = mmda_layernorm_bwd(&l, stream);
+    }
     // d f1 = (d f2 W2) * [f1 > 0] / (1-p): f1 is stored post-relu, post-dropout, so f1 > 0 <=> kept and pre-activation > 0
-    mmda_gemm_args e = {};
-    e.gate = WS(m->f1); e.ldgate = FFN; e.gate_scale = p_tf > 0.f ? 1.f / (1.f - p_tf) : 1.f;
-    gemm(x, fmode, 0, 0, 6 * B, FFN, hs, WS(m->d_f2), hs, PP(m->l2_w), FFN, WS(m->d_f1), FFN, nullptr, nullptr, 0, 0, 1, 0, 0, 0, 0, &e);
-  }
-  lin_dw(x, fmode, 6 * B, hs, FFN, WS(m->d_f2), WS(m->f1), GG(m->l2_w), GG(m->l2_b));
-  lin_dx(x, fmode, 6 * B, FFN, hs, WS(m->d_f1), PP(m->l1_w), WS(m->d_x1), 1);
-  lin_dw(x, fmode, 6 * B, FFN, hs, WS(m->d_f1), WS(m->x1), GG(m->l1_w), GG(m->l1_b));
-  // norm1 + self-attention
-  if (!x.rc) {
-    mmda_ln_bwd_args l = {};
-    l.rows = 6 * B; l.n = hs; l.dy = WS(m->d_x1); l.x = WS(m->x6); l.res = WS(m->attn_out); l.gamma = PP(m->n1_w);
-    l.mean = WS(m->ln1_mean); l.rstd = WS(m->ln1_rstd); l.d_x = WS(m->d_x6); l.accumulate_dx = 1; l.d_res = WS(m->d_attn_out);
-    l.dgamma = GG(m->n1_w); l.dbeta = GG(m->n1_b); l.drop_p = p_tf; l.drop_seed = seed; l.drop_site = SITE_DROP1;
-    x.rc = mmda_layernorm_bwd(&l, stream);
-  }
-  lin_dx(x, fmode, 6 * B, hs, hs, WS(m->d_attn_out), PP(m->out_w), WS(m->d_ctx), 0);
-  lin_dw(x, fmode, 6 * B, hs, hs, WS(m->d_attn_out), WS(m->ctx), GG(m->out_w), GG(m->out_b));
-  if (!x.rc) x.rc = mmda_attn_bwd(WS(m->qkv), WS(m->probs), WS(m->d_ctx), S6, B, hs, NHEAD, WS(m->d_qkv), p_tf, seed, SITE_ATTN, stream);
-  lin_dx(x, fmode, 6 * B, 3 * hs, hs, WS(m->d_qkv), PP(m->in_w), WS(m->d_x6), 1);
-  lin_dw(x, fmode, 6 * B, 3 * hs, hs, WS(m->d_qkv), WS(m->x6), GG(m->in_w), GG(m->in_b));
-  // adversarial branch: discriminator grads, then the REVERSED gradient into the shared codes (functions.py:17-21)
-  if (!c.use_cmd_sim) {
-    lin_dx(x, fmode, 3 * B, 3, hs, WS(m->d_dom), PP(m->d2_w), WS(m->d_dom_h), 0);
-    lin_dw(x, fmode, 3 * B, 3, hs, WS(m->d_dom), WS(m->dom_h), GG(m->d2_w), GG(m->d2_b));
-    if (!x.rc) x.rc = mmda_act_dropout_bwd(WS(m->d_dom_h), WS(m->dom_z), WS(m->d_dom_z), 3 * BH, c.act, p_cls, seed, SITE_DISC, stream);
-    lin_dw(x, fmode, 3 * B, hs, hs, WS(m->d_dom_z), WS(m->x6 + 3 * BH), GG(m->d1_w), GG(m->d1_b));
-    mmda_gemm_args e = {};
-    e.alpha = -c.reverse_grad_weight;
-    gemm(x, fmode, 0, 0, 3 * B, hs, hs, WS(m->d_dom_z), hs, PP(m->d1_w), hs, WS(m->d_x6 + 3 * BH), hs, nullptr, nullptr, 1, 0, 1, 0, 0, 0, 0, &e);
-  }
-  // reconstruct: d(private+shared) goes to both halves of d_x6
-  gemm(x, fmode, 0, 0, B, hs, hs, WS(m->d_recon), hs, PP(m->rec_w), hs, WS(m->d_x6), hs, nullptr, nullptr, 1, 0, 3, BH, (int64_t)hs * hs, BH);
-  gemm(x, fmode, 0, 0, B, hs, hs, WS(m->d_recon), hs, PP(m->rec_w), hs, WS(m->d_x6 + 3 * BH), hs, nullptr, nullptr, 1, 0, 3, BH,
-       (int64_t)hs * hs, BH);
-  {
-    mmda_gemm_args e = {};
-    e.bias_grad = GG(m->rec_b);      // strideBias = hs: one bias gradient per batched problem
-    gemm(x, fmode, 1, 0, hs, hs, B, WS(m->d_recon), hs, WS(m->rsum), hs, GG(m->rec_w), hs, nullptr, nullptr, 1, 0, 3, BH, BH, (int64_t)hs * hs,
-         hs, &e);
-  }
-  // sigmoid of private/shared
-  if (!x.rc) x.rc = mmda_sigmoid_bwd_inplace(WS(m->d_x6), WS(m->x6), 6 * BH, stream);
-  gemm(x, fmode, 0, 0, B, hs, hs, WS(m->d_x6), hs, PP(m->priv_w), hs, WS(m->d_orig), hs, nullptr, nullptr, 1, 0, 3, BH, (int64_t)hs * hs, BH);
-  {
-    mmda_gemm_args e = {};
-    e.bias_grad = GG(m->priv_b);
-    gemm(x, fmode, 1, 0, hs, hs, B, WS(m->d_x6), hs, WS(m->orig), hs, GG(m->priv_w), hs, nullptr, nullptr, 1, 0, 3, BH, BH, (int64_t)hs * hs,
-         hs, &e);
-  }
-  lin_dx(x, fmode, 3 * B, hs, hs, WS(m->d_x6 + 3 * BH), PP(m->sh_w), WS(m->d_orig), 1);
-  lin_dw(x, fmode, 3 * B, hs, hs, WS(m->d_x6 + 3 * BH), WS(m->orig), GG(m->sh_w), GG(m->sh_b));
-  // projections
-  for (int i = 0; i < 3 && !x.rc; ++i) {
-    Mod& md = m->mod[i];
-    mmda_ln_bwd_args l = {};
-    l.rows = B; l.n = hs; l.dy = WS(m->d_orig + i * BH); l.x = WS(m->z + i * BH); l.gamma = PP(md.plw);
-    l.mean = WS(m->pmean + i * B); l.rstd = WS(m->prstd + i * B); l.d_x = WS(m->d_z + i * BH);
-    l.dgamma = GG(md.plw); l.dbeta = GG(md.plb); l.act = c.act;
-    x.rc = mmda_layernorm_bwd(&l, stream);
-    lin_dx(x, fmode, B, hs, 4 * md.H, WS(m->d_z + i * BH), PP(md.pw), WS(md.d_utt), 0);
-    lin_dw(x, fmode, B, hs, 4 * md.H, WS(m->d_z + i * BH), WS(md.utt), GG(md.pw), GG(md.pb));
+    g[0] = sk_nn(6 * B, hs, FFN, WS(m->d_f2), hs, PP(m->l2_w), WS(m->d_f1), FFN, 0);
+    g[0].gate = WS(m->f1); g[0].ldgate = FFN; g[0].gate_scale = p_tf > 0.f ? 1.f / (1.f - p_tf) : 1.f;
+    sk_launch(x, g, 1);
+    lin_dw(x, fmode, 6 * B, hs, FFN, WS(m->d_f2), WS(m->f1), GG(m->l2_w), GG(m->l2_b));
+    g[0] = sk_nn(6 * B, FFN, hs, WS(m->d_f1), FFN, PP(m->l1_w), WS(m->d_x1), hs, 1);
+    sk_launch(x, g, 1);
+    lin_dw(x, fmode, 6 * B, FFN, hs, WS(m->d_f1), WS(m->x1), GG(m->l1_w), GG(m->l1_b));
+    // norm1 + self-attention
+    if (!x.rc) {
+      mmda_ln_bwd_args l = {};
+      l.rows = 6 * B; l.n = hs; l.dy = WS(m->d_x1); l.x = WS(m->x6); l.res = WS(m->attn_out); l.gamma = PP(m->n1_w);
+      l.mean = WS(m->ln1_mean); l.rstd = WS(m->ln1_rstd); l.d_x = WS(m->d_x6); l.accumulate_dx = 1; l.d_res = WS(m->d_attn_out);
+      l.dgamma = GG(m->n1_w); l.dbeta = GG(m->n1_b); l.drop_p = p_tf; l.drop_seed = seed; l.drop_site = SITE_DROP1;
+      x.rc = mmda_layernorm_bwd(&l, stream);
+    }
+    int n = 0;
+    g[n++] = sk_nn(6 * B, hs, hs, WS(m->d_attn_out), hs, PP(m->out_w), WS(m->d_ctx), hs, 0);
+    if (!c.use_cmd_sim) g[n++] = sk_nn(3 * B, 3, hs, WS(m->d_dom), 3, PP(m->d2_w), WS(m->d_dom_h), hs, 0);
+    sk_launch(x, g, n);
+    lin_dw(x, fmode, 6 * B, hs, hs, WS(m->d_attn_out), WS(m->ctx), GG(m->out_w), GG(m->out_b));
+    if (!x.rc) x.rc = mmda_attn_bwd(WS(m->qkv), WS(m->probs), WS(m->d_ctx), S6, B, hs, NHEAD, WS(m->d_qkv), p_tf, seed, SITE_ATTN, stream);
+    lin_dw(x, fmode, 6 * B, 3 * hs, hs, WS(m->d_qkv), WS(m->x6), GG(m->in_w), GG(m->in_b));
+    // adversarial branch: discriminator grads, then the REVERSED gradient into the shared codes (functions.py:17-21)
+    if (!c.use_cmd_sim) {
+      lin_dw(x, fmode, 3 * B, 3, hs, WS(m->d_dom), WS(m->dom_h), GG(m->d2_w), GG(m->d2_b));
+      if (!x.rc) x.rc = mmda_act_dropout_bwd(WS(m->d_dom_h), WS(m->dom_z), WS(m->d_dom_z), 3 * BH, c.act, p_cls, seed, SITE_DISC, stream);
+      lin_dw(x, fmode, 3 * B, hs, hs, WS(m->d_dom_z), WS(m->x6 + 3 * BH), GG(m->d1_w), GG(m->d1_b));
+      g[0] = sk_nn(3 * B, hs, hs, WS(m->d_dom_z), hs, PP(m->d1_w), WS(m->d_x6 + 3 * BH), hs, 1);
+      g[0].alpha = -c.reverse_grad_weight;
+      sk_launch(x, g, 1);
+    }
+    // d_x6[token j] = (d_x6 + d_qkv[j] W_in + d_recon[j % 3] W_rec[j % 3]) * s (1 - s): the q/k/v projection's and the
+    // reconstruction's input gradients (the latter flows into BOTH private and shared) and the sigmoid backward, six problems
+    for (int j = 0; j < 6; ++j) {
+      const int i = j % 3;
+      g[j] = sk_nn(B, 3 * hs, hs, WS(m->d_qkv + (int64_t)j * B * 3 * hs), 3 * hs, PP(m->in_w), WS(m->d_x6 + j * BH), hs, 1);
+      g[j].K2 = hs; g[j].A_2nd = WS(m->d_recon + i * BH); g[j].lda_2nd = hs; g[j].B_2nd = PP(m->rec_w + (int64_t)i * hs * hs); g[j].ldb_2nd = hs;
+      g[j].dsig = WS(m->x6 + j * BH); g[j].lddsig = hs;
+    }
+    sk_launch(x, g, 6);
+    {
+      mmda_gemm_args e = {};
+      e.bias_grad = GG(m->rec_b);      // strideBias = hs: one bias gradient per batched problem
+      gemm(x, fmode, 1, 0, hs, hs, B, WS(m->d_recon), hs, WS(m->rsum), hs, GG(m->rec_w), hs, nullptr, nullptr, 1, 0, 3, BH, BH, (int64_t)hs * hs,
+           hs, &e);
+    }
+    // d_orig[i] += d_private[i] W_priv[i] + d_shared[i] W_shared
+    for (int i = 0; i < 3; ++i) {
+      g[i] = sk_nn(B, hs, hs, WS(m->d_x6 + i * BH), hs, PP(m->priv_w + (int64_t)i * hs * hs), WS(m->d_orig + i * BH), hs, 1);
+      g[i].K2 = hs; g[i].A_2nd = WS(m->d_x6 + (3 + i) * BH); g[i].lda_2nd = hs; g[i].B_2nd = PP(m->sh_w); g[i].ldb_2nd = hs;
+    }
+    sk_launch(x, g, 3);
+    {
+      mmda_gemm_args e = {};
+      e.bias_grad = GG(m->priv_b);
+      gemm(x, fmode, 1, 0, hs, hs, B, WS(m->d_x6), hs, WS(m->orig), hs, GG(m->priv_w), hs, nullptr, nullptr, 1, 0, 3, BH, BH, (int64_t)hs * hs,
+           hs, &e);
+    }
+    lin_dw(x, fmode, 3 * B, hs, hs, WS(m->d_x6 + 3 * BH), WS(m->orig), GG(m->sh_w), GG(m->sh_b));
+    // projections
+    if (!x.rc) {
+      mmda_ln_bwd_args l[3];
+      for (int i = 0; i < 3; ++i) {
+        Mod& md = m->mod[i];
+        l[i] = mmda_ln_bwd_args{};
+        l[i].rows = B; l[i].n = hs; l[i].dy = WS(m->d_orig + i * BH); l[i].x = WS(m->z + i * BH); l[i].gamma = PP(md.plw);
+        l[i].mean = WS(m->pmean + i * B); l[i].rstd = WS(m->prstd + i * B); l[i].d_x = WS(m->d_z + i * BH);
+        l[i].dgamma = GG(md.plw); l[i].dbeta = GG(md.plb); l[i].act = c.act;
+      }
+      x.rc = mmda_layernorm_bwd_multi(l, 3, stream);
+    }
+    for (int i = 0; i < 3; ++i) {
+      Mod& md = m->mod[i];
+      g[i] = sk_nn(B, hs, 4 * md.H, WS(m->d_z + i * BH), hs, PP(md.pw), WS(md.d_utt), 4 * md.H, 0);
+      lin_dw(x, fmode, B, hs, 4 * md.H, WS(m->d_z + i * BH), WS(md.utt), GG(md.pw), GG(md.pb));
+    }
+    sk_launch(x, g, 3);
+  } else {
+    // heads
+    x.rc = mmda_heads_bwd(WS(m->tcp), WS(m->scores), WS(m->d_tcp), WS(m->d_scores), B, c.ncls, WS(m->d_logits), p_cls, seed, SITE_CLS,
+                          stream);
+    lin_dx(x, fmode, B, NC, 6 * hs, WS(m->d_logits), PP(m->head_w), WS(m->d_hfused), 0);
+    lin_dw(x, fmode, B, NC, 6 * hs, WS(m->d_logits), WS(m->hfused), GG(m->head_w), GG(m->head_b));
+    // norm2 + FFN
+    if (!x.rc) {
+      mmda_ln_bwd_args l = {};
+      l.rows = 6 * B; l.n = hs; l.dy = WS(m->d_hfused); l.x = WS(m->x1); l.res = WS(m->f2); l.gamma = PP(m->n2_w);
+      l.mean = WS(m->ln2_mean); l.rstd = WS(m->ln2_rstd); l.d_x = WS(m->d_x1); l.d_res = WS(m->d_f2);
+      l.dgamma = GG(m->n2_w); l.dbeta = GG(m->n2_b); l.drop_p = p_tf; l.drop_seed = seed; l.drop_site = SITE_DROP2;
+      l.permute_S = S6; l.permute_B = B;
+      x.rc = mmda_layernorm_bwd(&l, stream);
+    }
+    {
+      // d f1 = (d f2 W2) * [f1 > 0] / (1-p): f1 is stored post-relu, post-dropout, so f1 > 0 <=> kept and pre-activation > 0
+      mmda_gemm_args e = {};
+      e.gate = WS(m->f1); e.ldgate = FFN; e.gate_scale = p_tf > 0.f ? 1.f / (1.f - p_tf) : 1.f;
+      gemm(x, fmode, 0, 0, 6 * B, FFN, hs, WS(m->d_f2), hs, PP(m->l2_w), FFN, WS(m->d_f1), FFN, nullptr, nullptr, 0, 0, 1, 0, 0, 0, 0, &e);
+    }
+    lin_dw(x, fmode, 6 * B, hs, FFN, WS(m->d_f2), WS(m->f1), GG(m->l2_w), GG(m->l2_b));
+    lin_dx(x, fmode, 6 * B, FFN, hs, WS(m->d_f1), PP(m->l1_w), WS(m->d_x1), 1);
+    lin_dw(x, fmode, 6 * B, FFN, hs, WS(m->d_f1), WS(m->x1), GG(m->l1_w), GG(m->l1_b));
+    // norm1 + self-attention
+    if (!x.rc) {
+      mmda_ln_bwd_args l = {};
+      l.rows = 6 * B; l.n = hs; l.dy = WS(m->d_x1); l.x = WS(m->x6); l.res = WS(m->attn_out); l.gamma = PP(m->n1_w);
+      l.mean = WS(m->ln1_mean); l.rstd = WS(m->ln1_rstd); l.d_x = WS(m->d_x6); l.accumulate_dx = 1; l.d_res = WS(m->d_attn_out);
+      l.dgamma = GG(m->n1_w); l.dbeta = GG(m->n1_b); l.drop_p = p_tf; l.drop_seed = seed; l.drop_site = SITE_DROP1;
+      x.rc = mmda_layernorm_bwd(&l, stream);
+    }
+    lin_dx(x, fmode, 6 * B, hs, hs, WS(m->d_attn_out), PP(m->out_w), WS(m->d_ctx), 0);
+    lin_dw(x, fmode, 6 * B, hs, hs, WS(m->d_attn_out), WS(m->ctx), GG(m->out_w), GG(m->out_b));
+    if (!x.rc) x.rc = mmda_attn_bwd(WS(m->qkv), WS(m->probs), WS(m->d_ctx), S6, B, hs, NHEAD, WS(m->d_qkv), p_tf, seed, SITE_ATTN, stream);
+    lin_dx(x, fmode, 6 * B, 3 * hs, hs, WS(m->d_qkv), PP(m->in_w), WS(m->d_x6), 1);
+    lin_dw(x, fmode, 6 * B, 3 * hs, hs, WS(m->d_qkv), WS(m->x6), GG(m->in_w), GG(m->in_b));
+    // adversarial branch: discriminator grads, then the REVERSED gradient into the shared codes (functions.py:17-21)
+    if (!c.use_cmd_sim) {
+      lin_dx(x, fmode, 3 * B, 3, hs, WS(m->d_dom), PP(m->d2_w), WS(m->d_dom_h), 0);
+      lin_dw(x, fmode, 3 * B, 3, hs, WS(m->d_dom), WS(m->dom_h), GG(m->d2_w), GG(m->d2_b));
+      if (!x.rc) x.rc = mmda_act_dropout_bwd(WS(m->d_dom_h), WS(m->dom_z), WS(m->d_dom_z), 3 * BH, c.act, p_cls, seed, SITE_DISC, stream);
+      lin_dw(x, fmode, 3 * B, hs, hs, WS(m->d_dom_z), WS(m->x6 + 3 * BH), GG(m->d1_w), GG(m->d1_b));
+      mmda_gemm_args e = {};
+      e.alpha = -c.reverse_grad_weight;
+      gemm(x, fmode, 0, 0, 3 * B, hs, hs, WS(m->d_dom_z), hs, PP(m->d1_w), hs, WS(m->d_x6 + 3 * BH), hs, nullptr, nullptr, 1, 0, 1, 0, 0, 0, 0, &e);
+    }
+    // reconstruct: d(private+shared) goes to both halves of d_x6
+    gemm(x, fmode, 0, 0, B, hs, hs, WS(m->d_recon), hs, PP(m->rec_w), hs, WS(m->d_x6), hs, nullptr, nullptr, 1, 0, 3, BH, (int64_t)hs * hs, BH);
+    gemm(x, fmode, 0, 0, B, hs, hs, WS(m->d_recon), hs, PP(m->rec_w), hs, WS(m->d_x6 + 3 * BH), hs, nullptr, nullptr, 1, 0, 3, BH,
+         (int64_t)hs * hs, BH);
+    {
+      mmda_gemm_args e = {};
+      e.bias_grad = GG(m->rec_b);      // strideBias = hs: one bias gradient per batched problem
+      gemm(x, fmode, 1, 0, hs, hs, B, WS(m->d_recon), hs, WS(m->rsum), hs, GG(m->rec_w), hs, nullptr, nullptr, 1, 0, 3, BH, BH, (int64_t)hs * hs,
+           hs, &e);
+    }
+    // sigmoid of private/shared
+    if (!x.rc) x.rc = mmda_sigmoid_bwd_inplace(WS(m->d_x6), WS(m->x6), 6 * BH, stream);
+    gemm(x, fmode, 0, 0, B, hs, hs, WS(m->d_x6), hs, PP(m->priv_w), hs, WS(m->d_orig), hs, nullptr, nullptr, 1, 0, 3, BH, (int64_t)hs * hs, BH);
+    {
+      mmda_gemm_args e = {};
+      e.bias_grad = GG(m->priv_b);
+      gemm(x, fmode, 1, 0, hs, hs, B, WS(m->d_x6), hs, WS(m->orig), hs, GG(m->priv_w), hs, nullptr, nullptr, 1, 0, 3, BH, BH, (int64_t)hs * hs,
+           hs, &e);
+    }
+    lin_dx(x, fmode, 3 * B, hs, hs, WS(m->d_x6 + 3 * BH), PP(m->sh_w), WS(m->d_orig), 1);
+    lin_dw(x, fmode, 3 * B, hs, hs, WS(m->d_x6 + 3 * BH), WS(m->orig), GG(m->sh_w), GG(m->sh_b));
+    // projections
+    for (int i = 0; i < 3 && !x.rc; ++i) {
+      Mod& md = m->mod[i];
+      mmda_ln_bwd_args l = {};
+      l.rows = B; l.n = hs; l.dy = WS(m->d_orig + i * BH); l.x = WS(m->z + i * BH); l.gamma = PP(md.plw);
+      l.mean = WS(m->pmean + i * B); l.rstd = WS(m->prstd + i * B); l.d_x = WS(m->d_z + i * BH);
+      l.dgamma = GG(md.plw); l.dbeta = GG(md.plb); l.act = c.act;
+      x.rc = mmda_layernorm_bwd(&l, stream);
+      lin_dx(x, fmode, B, hs, 4 * md.H, WS(m->d_z + i * BH), PP(md.pw), WS(md.d_utt), 0);
+      lin_dw(x, fmode, B, hs, 4 * md.H, WS(m->d_z + i * BH), WS(md.utt), GG(md.pw), GG(md.pb));
+    }
   }
   if (x.rc) return x.rc;
   x.deferring = false;
-  x.rc = side_launch(m, x.deferred, stream);
+  {
+    // side stream: private + shared (the reconstruction's input, needed only by its weight gradient) and every deferred
+    // weight-gradient GEMM of the block
+    void* ss = nullptr;
+    x.rc = side_fork(m, stream, &ss);
+    if (!x.rc && B <= SKINNY_MAX_B) x.rc = mmda_add(WS(m->x6), WS(m->x6 + 3 * BH), WS(m->rsum), 3 * BH, ss);
+    if (!x.rc && !x.deferred.empty()) x.rc = mmda_gemm_grouped(x.deferred.data(), (int)x.deferred.size(), ss);
+    x.deferred.clear();
+  }
   if (x.rc) return x.rc;
   // encoders, top layer first
   const float* xin[3] = {WS(m->mod[0].x), v, a};
@@ -725,20 +927,26 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
     }
     group_end(x);
     x.deferring = false;
-    if (!x.rc) x.rc = side_launch(m, x.deferred, stream);
-    for (int i = 0; i < 3 && !x.rc; ++i) {
-      Mod& md = m->mod[i]; Rnn& r = md.rnn[l];
-      const int H = r.H;
-      if (l == 1) {
-        // the inter-layer LayerNorm backward gives d(hseq of layer 1)
-        mmda_ln_bwd_args lb = {};
-        lb.rows = R; lb.n = 2 * H; lb.dy = WS(md.d_normed); lb.x = WS(md.hseq[0]); lb.gamma = PP(md.ln_w);
-        lb.mean = WS(md.ln_mean); lb.rstd = WS(md.ln_rstd); lb.d_x = WS(md.d_hseq1); lb.dgamma = GG(md.ln_w); lb.dbeta = GG(md.ln_b);
-        x.rc = mmda_layernorm_bwd(&lb, stream);
-      } else if (i == 0) {
-        // text: gradient w.r.t. the embedding rows, scattered densely into embed.weight.grad (sparse=False)
-        x.rc = mmda_embed_scatter_add(GG(m->embed), t_ids, R, c.d_t, WS(md.d_x), stream);
+    if (l == 1 && !x.rc) {
+      // the inter-layer LayerNorm backward gives d(hseq of layer 1): input gradients on the main stream (they feed the next
+      // recurrent kernel); gamma/beta gradients and this layer's weight-gradient GEMMs on the side stream underneath it
+      mmda_ln_bwd_args lb[3];
+      for (int i = 0; i < 3; ++i) {
+        Mod& md = m->mod[i];
+        lb[i] = mmda_ln_bwd_args{};
+        lb[i].rows = R; lb[i].n = 2 * md.H; lb[i].dy = WS(md.d_normed); lb[i].x = WS(md.hseq[0]); lb[i].gamma = PP(md.ln_w);
+        lb[i].mean = WS(md.ln_mean); lb[i].rstd = WS(md.ln_rstd); lb[i].d_x = WS(md.d_hseq1);
       }
+      void* ss = nullptr;
+      x.rc = side_fork(m, stream, &ss);
+      if (!x.rc) x.rc = mmda_layernorm_bwd_multi(lb, 3, stream);
+      for (int i = 0; i < 3; ++i) { lb[i].dgamma = GG(m->mod[i].ln_w); lb[i].dbeta = GG(m->mod[i].ln_b); lb[i].d_x = nullptr; }
+      if (!x.rc) x.rc = mmda_layernorm_param_grads(lb, 3, ss);
+      if (!x.rc && !x.deferred.empty()) x.rc = mmda_gemm_grouped(x.deferred.data(), (int)x.deferred.size(), ss);
+      x.deferred.clear();
+    } else if (!x.rc) {
+      // text: gradient w.r.t. the embedding rows, scattered densely into embed.weight.grad (sparse=False)
+      x.rc = mmda_embed_scatter_add(GG(m->embed), t_ids, R, c.d_t, WS(m->mod[0].d_x), stream);
     }
     if (x.rc) return x.rc;
   }
@@ -788,7 +996,13 @@ extern "C" int mmda_misa_adam_step(mmda_misa* m, float lr, float clip, float gra
 extern "C" int mmda_misa_train_step(mmda_misa* m, const int64_t* t_ids, const float* v, const float* a, const int32_t* lengths,
                                     const float* emo, int training, uint64_t seed, int do_adam, float lr, float clip, int step,
                                     void* stream) {
-  int rc = mmda_misa_zero_grad(m, stream);
+  // the gradient bucket is cleared on the side stream underneath the first kernels of the forward pass; forward() joins the
+  // side stream (W_hh packing) before its first recurrent kernel, long before any gradient is accumulated
+  if (check_ready(m)) return MMDA_EINVAL;
+  void* ss = nullptr;
+  int rc = side_fork(m, stream, &ss);
+  if (rc) return rc;
+  rc = mmda_misa_zero_grad(m, ss);
   if (rc) return rc;
   rc = mmda_misa_forward(m, t_ids, v, a, lengths, training, seed, stream);
   if (rc) return rc;

@@ -13,9 +13,18 @@ __device__ __forceinline__ int64_t perm_row(int row, int S, int Bp) {
   return (int64_t)b * S + s;
 }
 
-__global__ __launch_bounds__(256) void ln_fwd_kernel(mmda_ln_args a) {
+constexpr int LN_MAXP = 4;      // problems per launch (the three modalities' LayerNorms go out together)
+struct LnMulti { mmda_ln_args a[LN_MAXP]; int start[LN_MAXP + 1]; int n; };
+struct LnBwdMulti { mmda_ln_bwd_args a[LN_MAXP]; int start[LN_MAXP + 1]; int nblk[LN_MAXP]; int n; };
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(LnMulti L) {
+  int pi = 0;
+#pragma unroll
+  for (int k = 1; k < LN_MAXP; ++k)
+    if (k < L.n && (int)blockIdx.x >= L.start[k]) pi = k;
+  const mmda_ln_args& a = L.a[pi];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row = blockIdx.x * 4 + wave;
+  const int row = ((int)blockIdx.x - L.start[pi]) * 4 + wave;
   if (row >= a.rows) return;
   const int n = a.n;
   float v[LN_MAXQ];
@@ -54,14 +63,21 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(mmda_ln_args a) {
   }
 }
 
-__global__ __launch_bounds__(256) void ln_bwd_kernel(mmda_ln_bwd_args a) {
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdMulti L) {
   __shared__ float red[2][4][LN_MAXQ * 64];
+  int pi = 0;
+#pragma unroll
+  for (int k = 1; k < LN_MAXP; ++k)
+    if (k < L.n && (int)blockIdx.x >= L.start[k]) pi = k;
+  const mmda_ln_bwd_args& a = L.a[pi];
+  const int blk = (int)blockIdx.x - L.start[pi], nblk = L.nblk[pi];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = a.n;
+  const bool want_pg = a.dgamma != nullptr || a.dbeta != nullptr;
   float dg[LN_MAXQ], db[LN_MAXQ];
 #pragma unroll
   for (int q = 0; q < LN_MAXQ; ++q) { dg[q] = 0.f; db[q] = 0.f; }
-  for (int row = blockIdx.x * 4 + wave; row < a.rows; row += gridDim.x * 4) {
+  for (int row = blk * 4 + wave; row < a.rows; row += nblk * 4) {
     const float mean = a.mean[row], rstd = a.rstd[row];
     const int64_t drow = perm_row(row, a.permute_S, a.permute_B);
     float xh[LN_MAXQ], gdy[LN_MAXQ];
@@ -99,6 +115,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(mmda_ln_bwd_args a) {
       }
     }
   }
+  if (!want_pg) return;            // block-uniform: parameter gradients come from mmda_layernorm_param_grads instead
   // reduce the per-wave column partials across the block's 4 waves, then one atomic per column per block
   const int nq = (n + 63) / 64;
 #pragma unroll
@@ -109,6 +126,45 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(mmda_ln_bwd_args a) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     float g = red[0][0][i] + red[0][1][i] + red[0][2][i] + red[0][3][i];
     float b = red[1][0][i] + red[1][1][i] + red[1][2][i] + red[1][3][i];
+    if (a.dgamma) atomicAdd(&a.dgamma[i], g);
+    if (a.dbeta) atomicAdd(&a.dbeta[i], b);
+  }
+}
+
+// dgamma / dbeta alone, parallel over column strips x row chunks: lane = column (coalesced 256-B rows), no wave reductions,
+// rows/chunk atomics per column instead of one per row-block.  For the three big inter-layer LayerNorms (rows = T*B) the
+// fused form above spends most of its time in ~200-way contended atomics; this pass runs off the critical path instead.
+__global__ __launch_bounds__(256) void ln_param_grads_kernel(LnBwdMulti L) {
+  __shared__ float red[2][4][64];
+  int pi = 0;
+#pragma unroll
+  for (int k = 1; k < LN_MAXP; ++k)
+    if (k < L.n && (int)blockIdx.x >= L.start[k]) pi = k;
+  const mmda_ln_bwd_args& a = L.a[pi];
+  const int blk = (int)blockIdx.x - L.start[pi];
+  const int n = a.n, strips = (n + 63) / 64;
+  const int strip = blk % strips, chunk = blk / strips, nchunk = L.nblk[pi];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = strip * 64 + lane;
+  const int ic = min(i, n - 1);
+  const int per = (a.rows + nchunk - 1) / nchunk;
+  const int r0 = chunk * per, r1 = min(a.rows, r0 + per);
+  float dg = 0.f, db = 0.f;
+  for (int row = r0 + wave; row < r1; row += 4) {
+    const float mean = a.mean[row], rstd = a.rstd[row];
+    const int64_t drow = perm_row(row, a.permute_S, a.permute_B);
+    const int64_t idx = (int64_t)row * n + ic;
+    float x = act_fwd(a.act, a.x[idx]);
+    if (a.res) x += a.res[idx] * drop_mul(a.drop_p, a.drop_seed, a.drop_site, (uint64_t)idx);
+    const float dy = a.dy[drow * n + ic];
+    dg += dy * (x - mean) * rstd;
+    db += dy;
+  }
+  red[0][wave][lane] = dg; red[1][wave][lane] = db;
+  __syncthreads();
+  if (wave == 0 && i < n) {
+    const float g = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
+    const float b = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
     if (a.dgamma) atomicAdd(&a.dgamma[i], g);
     if (a.dbeta) atomicAdd(&a.dbeta[i], b);
   }
@@ -156,24 +212,88 @@ int ew_blocks(int64_t n) {
 
 }  // namespace
 
-extern "C" int mmda_layernorm_fwd(const mmda_ln_args* a, void* stream) {
-  if (!a || !a->x || !a->y || !a->gamma || !a->beta || a->rows < 0 || a->n <= 0 || a->n > LN_MAXQ * 64) return MMDA_EINVAL;
+namespace {
+int ln_check(const mmda_ln_args* a) {
+  if (!a->x || !a->y || !a->gamma || !a->beta || a->rows < 0 || a->n <= 0 || a->n > LN_MAXQ * 64) return MMDA_EINVAL;
   if (a->permute_S > 0 && (a->permute_B <= 0 || a->permute_S * a->permute_B != a->rows)) return MMDA_EINVAL;
-  if (a->rows == 0) return MMDA_OK;
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3(ceil_div(a->rows, 4)), dim3(256), 0, (hipStream_t)stream, *a);
-  MMDA_CHECK_LAUNCH("mmda_layernorm_fwd");
   return MMDA_OK;
 }
-
-extern "C" int mmda_layernorm_bwd(const mmda_ln_bwd_args* a, void* stream) {
-  if (!a || !a->dy || !a->x || !a->gamma || !a->mean || !a->rstd || a->rows < 0 || a->n <= 0 || a->n > LN_MAXQ * 64) return MMDA_EINVAL;
+int ln_bwd_check(const mmda_ln_bwd_args* a) {
+  if (!a->dy || !a->x || !a->gamma || !a->mean || !a->rstd || a->rows < 0 || a->n <= 0 || a->n > LN_MAXQ * 64) return MMDA_EINVAL;
   if (a->permute_S > 0 && (a->permute_B <= 0 || a->permute_S * a->permute_B != a->rows)) return MMDA_EINVAL;
-  if (a->rows == 0) return MMDA_OK;
-  int blocks = ceil_div(a->rows, 4 * 2);          // 2 rows per wave: enough blocks to fill the chip at rows ~ T*B = 1600
-  if (blocks < 1) blocks = 1;
-  if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *a);
-  MMDA_CHECK_LAUNCH("mmda_layernorm_bwd");
+  return MMDA_OK;
+}
+}  // namespace
+
+extern "C" int mmda_layernorm_fwd_multi(const mmda_ln_args* a, int n, void* stream) {
+  if (!a || n < 0) return MMDA_EINVAL;
+  for (int i = 0; i < n; ++i)
+    if (ln_check(a + i)) return MMDA_EINVAL;
+  for (int base = 0; base < n; base += LN_MAXP) {
+    LnMulti L;
+    L.n = 0;
+    int blocks = 0;
+    for (int i = base; i < n && i < base + LN_MAXP; ++i) {
+      if (a[i].rows == 0) continue;
+      L.a[L.n] = a[i]; L.start[L.n] = blocks; blocks += ceil_div(a[i].rows, 4); L.n++;
+    }
+    for (int k = L.n; k <= LN_MAXP; ++k) L.start[k] = blocks;
+    for (int k = L.n; k < LN_MAXP; ++k) L.a[k] = L.a[0];
+    if (blocks == 0) continue;
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
+    MMDA_CHECK_LAUNCH("mmda_layernorm_fwd");
+  }
+  return MMDA_OK;
+}
+extern "C" int mmda_layernorm_fwd(const mmda_ln_args* a, void* stream) { return mmda_layernorm_fwd_multi(a, a ? 1 : -1, stream); }
+
+extern "C" int mmda_layernorm_bwd_multi(const mmda_ln_bwd_args* a, int n, void* stream) {
+  if (!a || n < 0) return MMDA_EINVAL;
+  for (int i = 0; i < n; ++i)
+    if (ln_bwd_check(a + i)) return MMDA_EINVAL;
+  for (int base = 0; base < n; base += LN_MAXP) {
+    LnBwdMulti L;
+    L.n = 0;
+    int blocks = 0;
+    for (int i = base; i < n && i < base + LN_MAXP; ++i) {
+      if (a[i].rows == 0) continue;
+      const bool pg = a[i].dgamma || a[i].dbeta;
+      // with parameter gradients: 2 rows per wave keeps the per-column atomics at rows/8 adders; without: one row per wave
+      int nb = ceil_div(a[i].rows, pg ? 8 : 4);
+      if (nb > 1024) nb = 1024;
+      L.a[L.n] = a[i]; L.start[L.n] = blocks; L.nblk[L.n] = nb; blocks += nb; L.n++;
+    }
+    for (int k = L.n; k <= LN_MAXP; ++k) L.start[k] = blocks;
+    for (int k = L.n; k < LN_MAXP; ++k) { L.a[k] = L.a[0]; L.nblk[k] = 1; }
+    if (blocks == 0) continue;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
+    MMDA_CHECK_LAUNCH("mmda_layernorm_bwd");
+  }
+  return MMDA_OK;
+}
+extern "C" int mmda_layernorm_bwd(const mmda_ln_bwd_args* a, void* stream) { return mmda_layernorm_bwd_multi(a, a ? 1 : -1, stream); }
+
+extern "C" int mmda_layernorm_param_grads(const mmda_ln_bwd_args* a, int n, void* stream) {
+  if (!a || n < 0) return MMDA_EINVAL;
+  for (int i = 0; i < n; ++i)
+    if (ln_bwd_check(a + i) || (!a[i].dgamma && !a[i].dbeta)) return MMDA_EINVAL;
+  for (int base = 0; base < n; base += LN_MAXP) {
+    LnBwdMulti L;
+    L.n = 0;
+    int blocks = 0;
+    for (int i = base; i < n && i < base + LN_MAXP; ++i) {
+      if (a[i].rows == 0) continue;
+      const int strips = ceil_div(a[i].n, 64);
+      int chunks = ceil_div(a[i].rows, 32);          // 8 rows per wave
+      if (chunks * strips > 1024) chunks = (1024 + strips - 1) / strips;
+      L.a[L.n] = a[i]; L.start[L.n] = blocks; L.nblk[L.n] = chunks; blocks += chunks * strips; L.n++;
+    }
+    for (int k = L.n; k <= LN_MAXP; ++k) L.start[k] = blocks;
+    for (int k = L.n; k < LN_MAXP; ++k) { L.a[k] = L.a[0]; L.nblk[k] = 1; }
+    if (blocks == 0) continue;
+    hipLaunchKernelGGL(ln_param_grads_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
+    MMDA_CHECK_LAUNCH("mmda_layernorm_param_grads");
+  }
   return MMDA_OK;
 }
 

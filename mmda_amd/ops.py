@@ -199,6 +199,29 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, *, res=None, act="none", drop_p=0.0,
     return dx, dres, dg, db
 
 
+
+def layernorm_multi(xs, gammas, betas, dys):
+    """Several LayerNorms through the multi-problem launches: forward, input gradients (no parameter gradients) and the
+    separate parameter-gradient pass.  Returns per problem (y, dx, dgamma, dbeta)."""
+    lib = load()
+    k = len(xs)
+    fa = (_lib.LnArgs * k)(); ba = (_lib.LnBwdArgs * k)()
+    keep = []
+    for a, b, x, g, be, dy in zip(fa, ba, xs, gammas, betas, dys):
+        rows, n = x.shape
+        y = torch.empty_like(x); mean = torch.empty(rows, device=x.device); rstd = torch.empty(rows, device=x.device)
+        dx = torch.empty_like(x); dg = torch.zeros(n, device=x.device); db = torch.zeros(n, device=x.device)
+        a.rows = rows; a.n = n; a.x = ptr(_f(x)); a.gamma = ptr(g); a.beta = ptr(be); a.y = ptr(y); a.mean = ptr(mean); a.rstd = ptr(rstd)
+        a.eps = 1e-5
+        b.rows = rows; b.n = n; b.dy = ptr(_f(dy)); b.x = ptr(x); b.gamma = ptr(g); b.mean = ptr(mean); b.rstd = ptr(rstd); b.d_x = ptr(dx)
+        keep.append((y, dx, dg, db, mean, rstd))
+    check(lib.mmda_layernorm_fwd_multi(fa, k, stream_ptr()), "layernorm_fwd_multi")
+    check(lib.mmda_layernorm_bwd_multi(ba, k, stream_ptr()), "layernorm_bwd_multi")      # dgamma/dbeta NULL: dx only
+    for b, (y, dx, dg, db, mean, rstd) in zip(ba, keep):
+        b.dgamma = ptr(dg); b.dbeta = ptr(db); b.d_x = None
+    check(lib.mmda_layernorm_param_grads(ba, k, stream_ptr()), "layernorm_param_grads")
+    return [(y, dx, dg, db) for (y, dx, dg, db, _, _) in keep]
+
 def lstm_pack(whh, mode):
     """Returns (packed_fwd, packed_bwd) byte tensors for one direction's W_hh (4H,H)."""
     lib = load()

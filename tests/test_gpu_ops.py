@@ -340,6 +340,25 @@ def test_layernorm_act_residual_permute():
     assert relerr(dx, x.grad) < 1e-4 and relerr(dres, r.grad) < 1e-4 and relerr(dg, g.grad) < 1e-4 and relerr(db, b.grad) < 1e-4
 
 
+def test_layernorm_multi_launch_and_split_param_grads():
+    """The three inter-layer LayerNorms (rows = T*B, n = 2H = 600/70/148) in one launch each way; input gradients without
+    parameter gradients, parameter gradients from the separate column-strip pass."""
+    from mmda_amd import ops
+    torch.manual_seed(15)
+    shapes = [(1600, 600), (1600, 70), (1600, 148), (33, 128), (5, 1024)]
+    xs = [torch.randn(r, n, requires_grad=True) for r, n in shapes]
+    gs = [torch.randn(n, requires_grad=True) for _, n in shapes]; bs = [torch.randn(n, requires_grad=True) for _, n in shapes]
+    dys = [torch.randn(r, n) for r, n in shapes]
+    d = dev()
+    got = ops.layernorm_multi([x.detach().to(d) for x in xs], [g.detach().to(d) for g in gs], [b.detach().to(d) for b in bs],
+                              [t.to(d) for t in dys])
+    for x, g, b, dy, (y, dx, dg, db) in zip(xs, gs, bs, dys, got):
+        ref = torch.nn.functional.layer_norm(x, x.shape[-1:], g, b, 1e-5)
+        ref.backward(dy)
+        assert relerr(y, ref) < 1e-5
+        assert relerr(dx, x.grad) < 1e-4 and relerr(dg, g.grad) < 1e-4 and relerr(db, b.grad) < 1e-4
+
+
 # ------------------------------------------------------------------------------------------------ LSTM
 def _lstm_case(T, B, H, D, ragged, seed):
     torch.manual_seed(seed)
