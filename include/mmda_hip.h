@@ -310,6 +310,9 @@ int64_t mmda_misa_tensor_offset(const mmda_misa* m, const char* name);
 int mmda_misa_set_mode(mmda_misa* m, int mode);
 /* bf16 recurrences: 1 (default) = W_hh resident in LDS across a cluster of workgroups, 0 = streamed from L2 every step */
 int mmda_misa_set_recurrence(mmda_misa* m, int resident_weights);
+/* bf16 mode only: 1 (default) = the LSTM-sized GEMMs read bf16 operand copies made by mmda_convert_bf16 (gemm_bf16.hip);
+ * 0 = they stage the fp32 tensors through the generic kernel (same rounding of the operands, different summation order). */
+int mmda_misa_set_gemm_operands(mmda_misa* m, int bf16_copies);
 /* 1 (default) = weight-gradient GEMMs run on an internal side stream underneath the recurrent kernels (joined before
  * mmda_misa_backward returns control of `stream`); 0 = everything on `stream` */
 int mmda_misa_set_overlap(mmda_misa* m, int side_stream);

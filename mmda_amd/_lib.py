@@ -144,6 +144,7 @@ SIGNATURES = {
     "mmda_misa_set_mode": (_I, [_P, _I]),
     "mmda_misa_set_overlap": (_I, [_P, _I]),
     "mmda_misa_set_recurrence": (_I, [_P, _I]),
+    "mmda_misa_set_gemm_operands": (_I, [_P, _I]),
     "mmda_misa_cluster_status": (_I, [_P, C.POINTER(_I)]),
     "mmda_misa_forward": (_I, [_P, _P, _P, _P, _P, _I, _U64, _P]),
     "mmda_misa_losses": (_I, [_P, _P, _I, _P]),

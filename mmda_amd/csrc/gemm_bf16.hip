@@ -21,69 +21,74 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 struct Bf16Group {
   mmda_gemm_bf16_args p[GROUP_MAX];
   int start[GROUP_MAX + 1];
-  int tx[GROUP_MAX], ty[GROUP_MAX], splitk[GROUP_MAX];
+  int tx[GROUP_MAX], ty[GROUP_MAX], splitk[GROUP_MAX], tile[GROUP_MAX];
   int n;
 };
 
 __device__ __forceinline__ u32x4 ld_chunk(const unsigned short* base, int row, int nrows, int ld, int k, int Kp) {
-  // 8 bf16 = 16 B; rows past the matrix and k past the (8-padded) depth read as zero
-  if (row < nrows && k < Kp) return *reinterpret_cast<const u32x4*>(base + (int64_t)row * ld + k);
-  return u32x4{0u, 0u, 0u, 0u};
+  // 8 bf16 = 16 B; rows past the matrix and k past the (8-padded) depth read as zero.  The load itself is unconditional from a
+  // clamped (always valid) address: a load under a lane-dependent branch costs a full s_waitcnt vmcnt(0) per chunk.
+  // The zeroing happens when the chunk is STORED to LDS (store_tile), not here: a select on the loaded value right after the
+  // load would make the compiler wait for it at once and the two-tile prefetch would be gone.
+  const int rc = min(row, nrows - 1), kc = min(k, Kp - 8);
+  return *reinterpret_cast<const u32x4*>(base + (int64_t)rc * ld + kc);
 }
 
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(Bf16Group G) {
-  __shared__ __attribute__((aligned(16))) unsigned short As[TM * LDT];
-  __shared__ __attribute__((aligned(16))) unsigned short Bs[TN * LDT];
-  int pi = 0;
-#pragma unroll
-  for (int k = 1; k < GROUP_MAX; ++k)
-    if (k < G.n && (int)blockIdx.x >= G.start[k]) pi = k;
-  const mmda_gemm_bf16_args g = G.p[pi];
-  const int splitk = G.splitk[pi];
-  const int local = blockIdx.x - G.start[pi];
-  const int bx = local % G.tx[pi], by = (local / G.tx[pi]) % G.ty[pi], sp = local / (G.tx[pi] * G.ty[pi]);
-
+// One output tile of T x T (T = 128: 4 waves of 64 x 64; T = 64: 4 waves of 32 x 32), k-tiles of 64, two register stages of
+// global prefetch.  128 x 128 when the output alone fills the chip; 64 x 64 for the long-K / small-output gradient GEMMs,
+// where four times as many workgroups matter more than operand reuse.
+template <int T>
+__device__ __forceinline__ void gemm_bf16_tile(const mmda_gemm_bf16_args& g, int splitk, int bx, int by, int sp, unsigned short* As,
+                                               unsigned short* Bs) {
+  constexpr int W = T / 32;                  // MFMA tiles per wave per dimension
+  constexpr int CH = T / 32;                 // 16-B chunks per thread per operand and k-tile (T rows x 8 chunks / 256 threads)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w >> 1, wn = w & 1;
-  const int row0 = by * TM, col0 = bx * TN;
+  const int row0 = by * T, col0 = bx * T;
   const int M = g.M, N = g.N, K = g.K;
   const int Kp = (K + 7) & ~7;
   const unsigned short* A = reinterpret_cast<const unsigned short*>(g.A);
   const unsigned short* Bm = reinterpret_cast<const unsigned short*>(g.B);
   const bool ones_row = g.bias_grad != nullptr;        // virtual all-ones row n == N of B: its output column is sum_k A[m,k]
 
-  f32x4 acc[4][4];
+  f32x4 acc[W][W];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < W; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < W; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // staging: 128 rows x 64 k = 1024 chunks of 8 bf16 per operand -> 4 per thread; chunk c: row = c >> 3, k = (c & 7) * 8
-  u32x4 ra[2][4], rb[2][4];
-  auto load_tile = [&](u32x4 (&a)[4], u32x4 (&b)[4], int k0) {
+  // staging: T rows x 64 k = T*8 chunks of 8 bf16 per operand; chunk c: row = c >> 3, k = (c & 7) * 8
+  u32x4 ra[2][CH], rb[2][CH];
+  auto load_tile = [&](u32x4 (&a)[CH], u32x4 (&b)[CH], int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < CH; ++i) {
       const int c = tid + 256 * i;
       const int r = c >> 3, k = k0 + (c & 7) * 8;
       a[i] = ld_chunk(A, row0 + r, M, g.lda, k, Kp);
-      u32x4 v = ld_chunk(Bm, col0 + r, N, g.ldb, k, Kp);
-      if (ones_row && col0 + r == N) {
+      b[i] = ld_chunk(Bm, col0 + r, N, g.ldb, k, Kp);
+    }
+  };
+  // the virtual all-ones row n == N of B (bias gradient) is written straight into the LDS tile that holds column N: it never
+  // touches the global-load path (a lane-dependent branch there serialises the loads behind s_waitcnt vmcnt(0))
+  const bool tile_has_ones = ones_row && col0 <= N && N < col0 + T;       // block-uniform
+  auto store_tile = [&](const u32x4 (&a)[CH], const u32x4 (&b)[CH], int k0) {
+    const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = tid + 256 * i;
+      const int r = c >> 3, k = (c & 7) * 8;
+      const bool k_ok = k0 + k < Kp;
+      *reinterpret_cast<u32x4*>(&As[r * LDT + k]) = (k_ok && row0 + r < M) ? a[i] : z;
+      u32x4 v = (k_ok && col0 + r < N) ? b[i] : z;
+      if (tile_has_ones) {                                     // block-uniform
         // bf16 1.0 = 0x3F80; elements past K stay zero so the sum runs over the real depth only
         unsigned e[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) e[q] = (k + q < K) ? 0x3F80u : 0u;
-        v = u32x4{e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
+        for (int q = 0; q < 8; ++q) e[q] = (k0 + k + q < K) ? 0x3F80u : 0u;
+        const u32x4 ones = {e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
+        v = (r == N - col0) ? ones : v;
       }
-      b[i] = v;
-    }
-  };
-  auto store_tile = [&](const u32x4 (&a)[4], const u32x4 (&b)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + 256 * i;
-      const int r = c >> 3, k = (c & 7) * 8;
-      *reinterpret_cast<u32x4*>(&As[r * LDT + k]) = a[i];
-      *reinterpret_cast<u32x4*>(&Bs[r * LDT + k]) = b[i];
+      *reinterpret_cast<u32x4*>(&Bs[r * LDT + k]) = v;
     }
   };
 
@@ -99,28 +104,28 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(Bf16Group G) {
   auto compute = [&]() {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 a[4], b[4];
+      bf16x8 a[W], b[W];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        a[i] = *reinterpret_cast<const bf16x8*>(&As[(wm * 64 + i * 16 + fr) * LDT + ks * 32 + fq * 8]);
-        b[i] = *reinterpret_cast<const bf16x8*>(&Bs[(wn * 64 + i * 16 + fr) * LDT + ks * 32 + fq * 8]);
+      for (int i = 0; i < W; ++i) {
+        a[i] = *reinterpret_cast<const bf16x8*>(&As[(wm * (T / 2) + i * 16 + fr) * LDT + ks * 32 + fq * 8]);
+        b[i] = *reinterpret_cast<const bf16x8*>(&Bs[(wn * (T / 2) + i * 16 + fr) * LDT + ks * 32 + fq * 8]);
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < W; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < W; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   };
   // unrolled by two so that the two register stages are addressed statically
   for (int kt = kt0; kt < nk; kt += 2) {
     __syncthreads();
-    store_tile(ra[0], rb[0]);
+    store_tile(ra[0], rb[0], kt * TK);
     __syncthreads();
     if (kt + 2 < nk) load_tile(ra[0], rb[0], (kt + 2) * TK);
     compute();
     if (kt + 1 < nk) {
       __syncthreads();
-      store_tile(ra[1], rb[1]);
+      store_tile(ra[1], rb[1], (kt + 1) * TK);
       __syncthreads();
       if (kt + 3 < nk) load_tile(ra[1], rb[1], (kt + 3) * TK);
       compute();
@@ -128,37 +133,72 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(Bf16Group G) {
   }
 
   const float alpha = g.alpha == 0.f ? 1.f : g.alpha;
+  if (tile_has_ones && wn == (N - col0) / (T / 2)) {
+    // the column n == N holds sum_k A[m,k]: bias gradient(s)
+    const int j = ((N - col0) % (T / 2)) / 16;
+    if ((lane & 15) == (N - col0) % 16) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = col0 + wn * 64 + j * 16 + (lane & 15);
-      if (ones_row && n == N) {
+      for (int i = 0; i < W; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int m = row0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+          const int m = row0 + wm * (T / 2) + i * 16 + (lane >> 4) * 4 + r;
+          float v = 0.f;
+#pragma unroll
+          for (int jj = 0; jj < W; ++jj) v = (jj == j) ? acc[i][jj][r] : v;
           if (m < M) {
-            atomicAdd(&g.bias_grad[m], acc[i][j][r]);
-            if (g.bias_grad2) atomicAdd(&g.bias_grad2[m], acc[i][j][r]);
+            atomicAdd(&g.bias_grad[m], v);
+            if (g.bias_grad2) atomicAdd(&g.bias_grad2[m], v);
           }
         }
-        continue;
-      }
-      if (n >= N) continue;
-      float bsum = 0.f;
-      if (g.bias) bsum += g.bias[n];
-      if (g.bias2) bsum += g.bias2[n];
+    }
+  }
+  // Accumulating without split-K reads C first: all loads are issued from clamped addresses before the first add (a load
+  // under the m < M / n < N branches would be waited for one by one).
+#pragma unroll
+  for (int i = 0; i < W; ++i) {
+    float oldc[W][4];
+    const bool rmw = g.accumulate && splitk == 1;              // block-uniform
+#pragma unroll
+    for (int j = 0; j < W; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = row0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
-        if (m >= M) continue;
+        const int nc = min(col0 + wn * (T / 2) + j * 16 + (lane & 15), N - 1);
+        const int mc = min(row0 + wm * (T / 2) + i * 16 + (lane >> 4) * 4 + r, M - 1);
+        oldc[j][r] = rmw ? g.C[(int64_t)mc * g.ldc + nc] : 0.f;
+      }
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      const int n = col0 + wn * (T / 2) + j * 16 + (lane & 15);
+      const bool n_ok = n < N;
+      const int nc = min(n, N - 1);
+      float bsum = 0.f;
+      if (g.bias) bsum += g.bias[nc];
+      if (g.bias2) bsum += g.bias2[nc];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = row0 + wm * (T / 2) + i * 16 + (lane >> 4) * 4 + r;
+        if (!n_ok || m >= M) continue;
         const int64_t ci = (int64_t)m * g.ldc + n;
-        if (splitk > 1) { atomicAdd(&g.C[ci], alpha * acc[i][j][r] + (sp == 0 ? bsum : 0.f)); continue; }
-        float v = alpha * acc[i][j][r] + bsum;
-        if (g.accumulate) v += g.C[ci];
-        g.C[ci] = v;
+        if (splitk > 1) atomicAdd(&g.C[ci], alpha * acc[i][j][r] + (sp == 0 ? bsum : 0.f));
+        else g.C[ci] = alpha * acc[i][j][r] + bsum + oldc[j][r];
       }
     }
+  }
+}
+
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(Bf16Group G) {
+  __shared__ __attribute__((aligned(16))) unsigned short As[TM * LDT];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[TN * LDT];
+  int pi = 0;
+#pragma unroll
+  for (int k = 1; k < GROUP_MAX; ++k)
+    if (k < G.n && (int)blockIdx.x >= G.start[k]) pi = k;
+  const mmda_gemm_bf16_args& g = G.p[pi];
+  const int splitk = G.splitk[pi];
+  const int local = blockIdx.x - G.start[pi];
+  const int bx = local % G.tx[pi], by = (local / G.tx[pi]) % G.ty[pi], sp = local / (G.tx[pi] * G.ty[pi]);
+  if (G.tile[pi] == 128) gemm_bf16_tile<128>(g, splitk, bx, by, sp, As, Bs);
+  else gemm_bf16_tile<64>(g, splitk, bx, by, sp, As, Bs);
 }
 
 // ------------------------------------------------------------------------------------------------ conversion
@@ -185,14 +225,22 @@ __global__ __launch_bounds__(256) void convert_kernel(ConvLaunch L) {
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   unsigned short* P = reinterpret_cast<unsigned short*>(J.plain);
   unsigned short* Tt = reinterpret_cast<unsigned short*>(J.transposed);
-  for (int rr = ty; rr < 64; rr += 4) {
+  // all 16 loads of a thread are issued from clamped addresses before the first use (no load under a lane-dependent branch)
+  const int cc0 = min(c0 + tx, J.cols - 1);
+  int64_t srow[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int rc = min(r0 + ty + 4 * i, J.rows - 1);
+    srow[i] = J.gather ? J.gather[rc] : (int64_t)rc;
+  }
+  float v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = J.src[srow[i] * J.ld + cc0];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int rr = ty + 4 * i;
     const int r = r0 + rr, c = c0 + tx;
-    float v = 0.f;
-    if (r < J.rows && c < J.cols) {
-      const int64_t sr = J.gather ? J.gather[r] : r;
-      v = J.src[sr * J.ld + c];
-    }
-    const unsigned short h = f2bf(v);
+    const unsigned short h = f2bf((r < J.rows && c < J.cols) ? v[i] : 0.f);
     tile[rr][tx] = h;
     if (P && r < J.rows && c < J.ldp) P[(int64_t)r * J.ldp + c] = h;      // c in [cols, ldp) writes the zero padding
   }
@@ -213,13 +261,11 @@ extern "C" int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, vo
     const int cnt = (n - base) < GROUP_MAX ? (n - base) : GROUP_MAX;
     Bf16Group G;
     G.n = 0;
-    int tiles_total = 0;
     for (int i = 0; i < cnt; ++i) {
       const mmda_gemm_bf16_args& a = args[base + i];
-      if (!a.A || !a.B || !a.C || a.M < 0 || a.N < 0 || a.K < 0) return MMDA_EINVAL;
+      if (!a.A || !a.B || !a.C || a.M < 0 || a.N < 0 || a.K <= 0) return MMDA_EINVAL;
       if ((a.lda & 7) || (a.ldb & 7) || (((uintptr_t)a.A | (uintptr_t)a.B) & 15)) return MMDA_EINVAL;
       if (a.lda < ((a.K + 7) & ~7) || a.ldb < ((a.K + 7) & ~7)) return MMDA_EINVAL;
-      tiles_total += ceil_div(a.N + (a.bias_grad ? 1 : 0), TN) * ceil_div(a.M, TM);
     }
     int blocks = 0;
     for (int i = 0; i < cnt; ++i) {
@@ -227,13 +273,23 @@ extern "C" int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, vo
       if (a.M == 0 || a.N == 0) continue;
       const int k = G.n++;
       G.p[k] = a;
-      G.tx[k] = ceil_div(a.N + (a.bias_grad ? 1 : 0), TN); G.ty[k] = ceil_div(a.M, TM);
+      const int Ne = a.N + (a.bias_grad ? 1 : 0);
+      // 128 x 128 tiles when they alone give ~2/3 of a chip-wide wave; else 64 x 64 (4x the workgroups)
+      const int t128 = ceil_div(Ne, 128) * ceil_div(a.M, 128);
+      const int T = t128 >= 160 ? 128 : 64;
+      G.tile[k] = T;
+      G.tx[k] = ceil_div(Ne, T); G.ty[k] = ceil_div(a.M, T);
+      const int tiles = G.tx[k] * G.ty[k];
       const int nk = ceil_div(a.K, TK);
+      // split-K combines through float atomics, which the chip retires at ~1.3 TB/s of added bytes: split only while the
+      // added bytes stay small (<= 6 MB, ~5 us) and every slice keeps >= 4 k-tiles
       int sk = 1;
-      if (nk >= 4 && tiles_total < 512) {            // ~2 workgroups per CU over the whole group
-        sk = (512 + tiles_total - 1) / tiles_total;
-        if (sk > nk / 2) sk = nk / 2;
-        if (sk > 32) sk = 32;
+      if (tiles < 192 && nk >= 8) {
+        sk = ceil_div(256, tiles);
+        if (sk > nk / 4) sk = nk / 4;
+        const double out_mb = (double)a.M * a.N * 4.0 / 1048576.0;
+        while (sk > 1 && sk * out_mb > 6.0) --sk;
+        if (sk > 16) sk = 16;
         if (sk < 1) sk = 1;
       }
       if (sk > 1 && !a.accumulate) {
@@ -242,10 +298,10 @@ extern "C" int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, vo
       }
       G.splitk[k] = sk;
       G.start[k] = blocks;
-      blocks += G.tx[k] * G.ty[k] * sk;
+      blocks += tiles * sk;
     }
     for (int k = G.n; k <= GROUP_MAX; ++k) G.start[k] = blocks;
-    for (int k = G.n; k < GROUP_MAX; ++k) { G.p[k] = G.p[0]; G.tx[k] = G.ty[k] = G.splitk[k] = 1; }
+    for (int k = G.n; k < GROUP_MAX; ++k) { G.p[k] = G.p[0]; G.tx[k] = G.ty[k] = G.splitk[k] = 1; G.tile[k] = 64; }
     if (blocks == 0) continue;
     hipLaunchKernelGGL(gemm_bf16_kernel, dim3(blocks), dim3(256), 0, s, G);
     MMDA_CHECK_LAUNCH("mmda_gemm_bf16_grouped");

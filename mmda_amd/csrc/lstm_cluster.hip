@@ -131,6 +131,8 @@ __device__ __forceinline__ void stf(__amdgpu_buffer_rsrc_t r, unsigned off, floa
 template <int KSC>
 __global__ __launch_bounds__(256, 1) void lstm_fwd_cluster_kernel(CLaunch L) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // the serial chain of this kernel is the critical path of the step: its waves issue ahead of any GEMM waves that share the CU
+  __builtin_amdgcn_s_setprio(3);
   const Where wh = locate(L);
   const CDesc& D = L.d[wh.di];
   const int H = D.H, Hp = D.Hp, Kp = D.Kp, KS = D.KS, nHT = D.nHT, TPW = D.TPW, NC = D.NC;
@@ -350,6 +352,8 @@ constexpr int BPU = 8, BGU = 8;    // publish / gather 16-byte chunks per thread
 template <int NTC>
 __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(CLaunch L) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // the serial chain of this kernel is the critical path of the step: its waves issue ahead of any GEMM waves that share the CU
+  __builtin_amdgcn_s_setprio(3);
   const Where wh = locate(L);
   const CDesc& D = L.d[wh.di];
   const int H = D.H, Hp = D.Hp, nHT = D.nHT, TPW = D.TPW, NC = D.NC;

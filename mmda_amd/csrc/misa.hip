@@ -6,6 +6,7 @@
 #include <map>
 #include <string>
 #include <vector>
+#include <stdlib.h>
 
 namespace {
 
@@ -15,6 +16,12 @@ struct Rnn {           // one bidirectional LSTM layer
   int D, H;
   int64_t w_ih, w_hh[2], b_ih, b_hh;     // w_ih: (8H,D) = [fwd;rev]; b_*: (8H) = [fwd;rev]
   int64_t pack_f[2], pack_b[2], pack_c[2];   // workspace float offsets of the packed W_hh (per direction)
+  // bf16 operand copies for the bf16-mode GEMMs (workspace float offsets; leading dimensions in bf16 elements):
+  int64_t wb, wbT;                           // W_ih (8H, ldD) and W_ih^T (D, ldG)
+  int64_t xb, xbT;                           // layer input (R, ldD) and its transpose (D, ldR)
+  int64_t dgb, dgbT;                         // gate gradients (R, ldG) and transpose (8H, ldR)
+  int64_t hbT;                               // hseq^T (2H, ldR)
+  int ldD, ldG;
 };
 
 struct Mod {           // one modality: two stacked biLSTMs with a LayerNorm between, then a projection
@@ -58,6 +65,8 @@ struct mmda_misa {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int side_pending = 0, use_side = 1;
   int use_cluster = 1, packed_c_valid = 0;
+  int use_bf16_gemm = 1;           // bf16 mode: LSTM-sized GEMMs read bf16 operand copies (gemm_bf16.hip)
+  int ldR = 0;
   std::vector<hipEvent_t> ev;      // [step][slot][start/stop]
   int ev_steps = 0, ev_fwd = 0, ev_bwd = 0;
 };
@@ -176,6 +185,15 @@ int64_t layout(mmda_misa* m, int B, int T, bool commit) {
         r.pack_b[d] = k.take(mmda_lstm_packed_bytes(MMDA_F32, r.H, 1) / 4);
         r.pack_c[d] = k.take(mmda_lstm_packed_bytes(MMDA_BF16, r.H, 2) / 4);
       }
+    }
+    for (int l = 0; l < 2; ++l) {
+      Rnn& r = md.rnn[l];
+      const int ldR = round_up((int)R, 8);
+      r.ldD = round_up(r.D, 8); r.ldG = round_up(8 * r.H, 8);
+      r.wb = k.take((int64_t)8 * r.H * r.ldD / 2); r.wbT = k.take((int64_t)r.D * r.ldG / 2);
+      r.xb = k.take(R * r.ldD / 2); r.xbT = k.take((int64_t)r.D * ldR / 2);
+      r.dgb = k.take(R * r.ldG / 2); r.dgbT = k.take((int64_t)8 * r.H * ldR / 2);
+      r.hbT = k.take((int64_t)2 * r.H * ldR / 2);
     }
     md.xchg_floats = (mmda_lstm_xchg_bytes(md.H, B) + 3) / 4;
     md.xchg = md.xchg_floats > 0 ? k.take(md.xchg_floats) : -1;
@@ -399,7 +417,7 @@ extern "C" int mmda_misa_set_workspace(mmda_misa* m, float* ws, int64_t floats, 
   int64_t need = layout(m, B, T, false);
   if (floats < need) return MMDA_EINVAL;
   layout(m, B, T, true);
-  m->ws = ws; m->ws_floats = floats; m->B = B; m->T = T;
+  m->ws = ws; m->ws_floats = floats; m->B = B; m->T = T; m->ldR = round_up(B * T, 8);
   // cluster-exchange flags must start at zero (setup time, not on the step path)
   for (int i = 0; i < 3; ++i)
     if (m->mod[i].xchg >= 0 && hipMemset(ws + m->mod[i].xchg, 0, sizeof(float) * m->mod[i].xchg_floats) != hipSuccess) return MMDA_ELAUNCH;
@@ -423,6 +441,11 @@ extern "C" int mmda_misa_set_overlap(mmda_misa* m, int side_stream) {
 extern "C" int mmda_misa_set_recurrence(mmda_misa* m, int resident_weights) {
   if (!m) return MMDA_EINVAL;
   m->use_cluster = resident_weights ? 1 : 0;
+  return MMDA_OK;
+}
+extern "C" int mmda_misa_set_gemm_operands(mmda_misa* m, int bf16_copies) {
+  if (!m) return MMDA_EINVAL;
+  m->use_bf16_gemm = bf16_copies ? 1 : 0;
   return MMDA_OK;
 }
 extern "C" int mmda_misa_cluster_status(const mmda_misa* m, int* aborted_host) {
@@ -470,23 +493,51 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
     m->packed_c_valid = want_c ? 1 : 0;
   }
   if (x.rc) return x.rc;
-  // embedding rows (models.py:201)
-  x.rc = mmda_embed_gather(PP(m->embed), t_ids, R, c.d_t, WS(m->mod[0].x), stream);
+  // bf16 mode: the input GEMMs read bf16 operand copies (K-major, 16-B rows): W_ih of both layers (plain for the forward,
+  // transposed for dX) and the layer-1 inputs -- the text rows are gathered from the embedding matrix by the conversion itself
+  // (models.py:201), so no fp32 copy of them is made.
+  const bool bfg = mode == MMDA_BF16 && m->use_bf16_gemm;
+  const int ldR = m->ldR;
   const float* xin[3] = {WS(m->mod[0].x), v, a};
+  if (bfg) {
+    mmda_convert_job cj[9];
+    int n = 0;
+    for (int i = 0; i < 3; ++i) {
+      for (int l = 0; l < 2; ++l) {
+        Rnn& r = m->mod[i].rnn[l];
+        cj[n++] = mmda_convert_job{PP(r.w_ih), r.D, 8 * r.H, r.D, nullptr, WS(r.wb), r.ldD, WS(r.wbT), r.ldG};
+      }
+      Rnn& r0 = m->mod[i].rnn[0];
+      if (i == 0) cj[n++] = mmda_convert_job{PP(m->embed), c.d_t, R, c.d_t, t_ids, WS(r0.xb), r0.ldD, WS(r0.xbT), ldR};
+      else cj[n++] = mmda_convert_job{xin[i], r0.D, R, r0.D, nullptr, WS(r0.xb), r0.ldD, WS(r0.xbT), ldR};
+    }
+    x.rc = mmda_convert_bf16(cj, n, stream);
+  } else {
+    // embedding rows (models.py:201)
+    x.rc = mmda_embed_gather(PP(m->embed), t_ids, R, c.d_t, WS(m->mod[0].x), stream);
+  }
   for (int l = 0; l < 2; ++l) {
     mmda_lstm_desc desc[3];
+    mmda_gemm_bf16_args bg[3];
     group_begin(x);
     for (int i = 0; i < 3; ++i) {
       Mod& md = m->mod[i]; Rnn& r = md.rnn[l];
       const float* in = l == 0 ? xin[i] : WS(md.normed);
       // time-batched input-to-hidden GEMM for both directions: (R, D) x (8H, D)^T + b_ih + b_hh
-      gemm(x, mode, 0, 1, R, 8 * r.H, r.D, in, r.D, PP(r.w_ih), r.D, WS(md.gates[l]), 8 * r.H, PP(r.b_ih), PP(r.b_hh));
+      if (bfg) {
+        bg[i] = mmda_gemm_bf16_args{};
+        bg[i].M = R; bg[i].N = 8 * r.H; bg[i].K = r.D; bg[i].A = WS(r.xb); bg[i].lda = r.ldD; bg[i].B = WS(r.wb); bg[i].ldb = r.ldD;
+        bg[i].C = WS(md.gates[l]); bg[i].ldc = 8 * r.H; bg[i].bias = PP(r.b_ih); bg[i].bias2 = PP(r.b_hh);
+      } else {
+        gemm(x, mode, 0, 1, R, 8 * r.H, r.D, in, r.D, PP(r.w_ih), r.D, WS(md.gates[l]), 8 * r.H, PP(r.b_ih), PP(r.b_hh));
+      }
       desc[i] = mmda_lstm_desc{};
       desc[i].H = r.H; desc[i].gates = WS(md.gates[l]); desc[i].cstash = WS(md.c[l]); desc[i].hseq = WS(md.hseq[l]);
       desc[i].wpack[0] = WS(r.pack_f[0]); desc[i].wpack[1] = WS(r.pack_f[1]);
       desc[i].utt = WS(md.utt); desc[i].layer = l; desc[i].d_hseq = nullptr;
       desc[i].xchg = (m->use_cluster && md.xchg >= 0) ? (void*)WS(md.xchg) : nullptr; desc[i].epoch_base = m->epoch;
     }
+    if (bfg && !x.rc) x.rc = mmda_gemm_bf16_grouped(bg, 3, stream);
     m->epoch += (unsigned)T + 2u;
     group_end(x);
     if (!x.rc && l == 0) x.rc = side_join(m, stream);       // packed W_hh ready
@@ -504,6 +555,26 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
         ln[i].y = WS(md.normed); ln[i].mean = WS(md.ln_mean); ln[i].rstd = WS(md.ln_rstd); ln[i].eps = 1e-5f;
       }
       x.rc = mmda_layernorm_fwd_multi(ln, 3, stream);
+      if (bfg && !x.rc) {
+        // layer-2 inputs (plain for its forward GEMM, transposed for its dW_ih) and hseq^T of layer 1 (for its dW_hh)
+        mmda_convert_job cj[6];
+        for (int i = 0; i < 3; ++i) {
+          Mod& md = m->mod[i]; Rnn& r1 = md.rnn[1]; Rnn& r0 = md.rnn[0];
+          cj[i] = mmda_convert_job{WS(md.normed), 2 * md.H, R, 2 * md.H, nullptr, WS(r1.xb), r1.ldD, WS(r1.xbT), ldR};
+          cj[3 + i] = mmda_convert_job{WS(md.hseq[0]), 2 * md.H, R, 2 * md.H, nullptr, nullptr, 0, WS(r0.hbT), ldR};
+        }
+        x.rc = mmda_convert_bf16(cj, 6, stream);
+      }
+    } else if (bfg && !x.rc) {
+      // hseq^T of layer 2 for its dW_hh: on the side stream, beside the fusion block
+      mmda_convert_job cj[3];
+      for (int i = 0; i < 3; ++i) {
+        Mod& md = m->mod[i];
+        cj[i] = mmda_convert_job{WS(md.hseq[1]), 2 * md.H, R, 2 * md.H, nullptr, nullptr, 0, WS(md.rnn[1].hbT), ldR};
+      }
+      void* ss = nullptr;
+      x.rc = side_fork(m, stream, &ss);
+      if (!x.rc) x.rc = mmda_convert_bf16(cj, 3, ss);
     }
   }
   if (x.rc) return x.rc;
@@ -901,6 +972,21 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
     if (x.rc) return x.rc;
     // All weight / input gradient GEMMs of this layer (three modalities) are independent.  Layer 2: d(normed) feeds the
     // next recurrent kernel (main stream); its weight gradients run on the side stream underneath that kernel.
+    const bool bfg = mode == MMDA_BF16 && m->use_bf16_gemm;
+    const bool bf_hh = bfg && (B % 8) == 0;        // the time-shifted views of dG^T / hseq^T start B elements into a row
+    std::vector<mmda_gemm_bf16_args> bmain, bside;
+    if (bfg) {
+      // gate gradients -> bf16: transposed (A of every dW) and, where an input gradient is needed, plain (A of dX)
+      mmda_convert_job cj[3];
+      for (int i = 0; i < 3; ++i) {
+        Mod& md = m->mod[i]; Rnn& r = md.rnn[l];
+        const bool plain = l == 1 || i == 0;
+        cj[i] = mmda_convert_job{WS(md.gates[l]), 8 * r.H, R, 8 * r.H, nullptr, plain ? WS(r.dgb) : nullptr, plain ? r.ldG : 0, WS(r.dgbT),
+                                 m->ldR};
+      }
+      x.rc = mmda_convert_bf16(cj, 3, stream);
+      if (x.rc) return x.rc;
+    }
     x.deferring = (l == 1);
     group_begin(x);
     for (int i = 0; i < 3; ++i) {
@@ -908,25 +994,51 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
       const int H = r.H, G8 = 8 * H;
       const float* dG = WS(md.gates[l]);
       const float* in = l == 0 ? xin[i] : WS(md.normed);
+      std::vector<mmda_gemm_bf16_args>& wq = (l == 1) ? bside : bmain;      // weight gradients: side stream for layer 2
+      const unsigned short* dgT = reinterpret_cast<const unsigned short*>(WS(r.dgbT));
+      const unsigned short* hT = reinterpret_cast<const unsigned short*>(WS(r.hbT));
       // dW_ih (both directions stacked); db_ih = db_hh = column sums of dG ride along as a virtual ones-column
-      {
+      if (bfg) {
+        mmda_gemm_bf16_args g = {};
+        g.M = G8; g.N = r.D; g.K = R; g.A = dgT; g.lda = m->ldR; g.B = WS(r.xbT); g.ldb = m->ldR; g.C = GG(r.w_ih); g.ldc = r.D;
+        g.accumulate = 1; g.bias_grad = GG(r.b_ih); g.bias_grad2 = GG(r.b_hh);
+        wq.push_back(g);
+      } else {
         mmda_gemm_args e = {};
         e.bias_grad = GG(r.b_ih); e.bias_grad2 = GG(r.b_hh);
         gemm(x, mode, 1, 0, G8, r.D, R, dG, G8, in, r.D, GG(r.w_ih), r.D, nullptr, nullptr, 1, 0, 1, 0, 0, 0, 0, &e);
       }
       // dW_hh: forward direction pairs dG[t] with h[t-1]; reverse direction pairs dG[t] with h[t+1] (zero past len)
       if (T > 1) {
-        const float* hs_ = WS(md.hseq[l]);
-        gemm(x, mode, 1, 0, 4 * H, H, (T - 1) * B, dG + (int64_t)B * G8, G8, hs_, 2 * H, GG(r.w_hh[0]), H, nullptr, nullptr, 1);
-        gemm(x, mode, 1, 0, 4 * H, H, (T - 1) * B, dG + 4 * H, G8, hs_ + (int64_t)B * 2 * H + H, 2 * H, GG(r.w_hh[1]), H, nullptr,
-             nullptr, 1);
+        if (bf_hh) {
+          mmda_gemm_bf16_args g = {};
+          g.M = 4 * H; g.N = H; g.K = (T - 1) * B; g.lda = m->ldR; g.ldb = m->ldR; g.ldc = H; g.accumulate = 1;
+          g.A = dgT + B; g.B = hT; g.C = GG(r.w_hh[0]);
+          wq.push_back(g);
+          g.A = dgT + (int64_t)4 * H * m->ldR; g.B = hT + (int64_t)H * m->ldR + B; g.C = GG(r.w_hh[1]);
+          wq.push_back(g);
+        } else {
+          const float* hs_ = WS(md.hseq[l]);
+          gemm(x, mode, 1, 0, 4 * H, H, (T - 1) * B, dG + (int64_t)B * G8, G8, hs_, 2 * H, GG(r.w_hh[0]), H, nullptr, nullptr, 1);
+          gemm(x, mode, 1, 0, 4 * H, H, (T - 1) * B, dG + 4 * H, G8, hs_ + (int64_t)B * 2 * H + H, 2 * H, GG(r.w_hh[1]), H, nullptr,
+               nullptr, 1);
+        }
       }
       // d(normed) = dG W_ih (layer 2) / d(embedding rows) (text layer 1)
-      if (l == 1) gemm(x, mode, 0, 0, R, r.D, G8, dG, G8, PP(r.w_ih), r.D, WS(md.d_normed), r.D);
-      else if (i == 0) gemm(x, mode, 0, 0, R, r.D, G8, dG, G8, PP(r.w_ih), r.D, WS(md.d_x), r.D);
+      if (l == 1 || i == 0) {
+        float* dst = l == 1 ? WS(md.d_normed) : WS(md.d_x);
+        if (bfg) {
+          mmda_gemm_bf16_args g = {};
+          g.M = R; g.N = r.D; g.K = G8; g.A = WS(r.dgb); g.lda = r.ldG; g.B = WS(r.wbT); g.ldb = r.ldG; g.C = dst; g.ldc = r.D;
+          bmain.push_back(g);
+        } else {
+          gemm(x, mode, 0, 0, R, r.D, G8, dG, G8, PP(r.w_ih), r.D, dst, r.D);
+        }
+      }
     }
     group_end(x);
     x.deferring = false;
+    if (!x.rc && !bmain.empty()) x.rc = mmda_gemm_bf16_grouped(bmain.data(), (int)bmain.size(), stream);
     if (l == 1 && !x.rc) {
       // the inter-layer LayerNorm backward gives d(hseq of layer 1): input gradients on the main stream (they feed the next
       // recurrent kernel); gamma/beta gradients and this layer's weight-gradient GEMMs on the side stream underneath it
@@ -943,6 +1055,7 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
       for (int i = 0; i < 3; ++i) { lb[i].dgamma = GG(m->mod[i].ln_w); lb[i].dbeta = GG(m->mod[i].ln_b); lb[i].d_x = nullptr; }
       if (!x.rc) x.rc = mmda_layernorm_param_grads(lb, 3, ss);
       if (!x.rc && !x.deferred.empty()) x.rc = mmda_gemm_grouped(x.deferred.data(), (int)x.deferred.size(), ss);
+      if (!x.rc && !bside.empty()) x.rc = mmda_gemm_bf16_grouped(bside.data(), (int)bside.size(), ss);
       x.deferred.clear();
     } else if (!x.rc) {
       // text: gradient w.r.t. the embedding rows, scattered densely into embed.weight.grad (sparse=False)

@@ -403,6 +403,10 @@ class MISA(nn.Module):
         """bf16 recurrences: W_hh resident in LDS across a workgroup cluster (default) or streamed from L2 per step."""
         _lib.check(self._lib.mmda_misa_set_recurrence(self._h, int(resident_weights)), "set_recurrence")
 
+    def set_gemm_operands(self, bf16_copies: bool):
+        """bf16 mode: LSTM-sized GEMMs on bf16 operand copies (default) or on fp32 tensors staged through the generic kernel."""
+        _lib.check(self._lib.mmda_misa_set_gemm_operands(self._h, int(bf16_copies)), "set_gemm_operands")
+
     def set_precision(self, precision: str):
         self.precision = precision
         _lib.check(self._lib.mmda_misa_set_mode(self._h, _lib.BF16 if precision == "bf16" else _lib.F32), "set_mode")

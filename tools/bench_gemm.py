@@ -34,7 +34,7 @@ for name, s in shapes:
     # bf16-operand NT kernel on pre-converted copies (conversion timed separately below)
     Kp = (K + 7) // 8 * 8
     Ab = torch.randn(M, Kp, device=d).bfloat16(); Bb = torch.randn(N, Kp, device=d).bfloat16()
-    prob = [dict(A=Ab, B=Bb, K=K, out=out, accumulate=True)]
+    prob = [dict(A=Ab, B=Bb, K=K, out=out, accumulate=name.startswith("dW"))]   # weight gradients accumulate, the others overwrite
     for _ in range(3):
         ops.gemm_bf16_grouped(prob)
     torch.cuda.synchronize()
