@@ -20,6 +20,10 @@
 //   barrier, the grid always drains.  All workgroups of a launch are co-resident: the host caps a launch at 240
 //   single-workgroup-per-CU blocks (LDS > 80 KB each) and chunks larger batches over several launches.
 #include "common.h"
+#include <algorithm>
+#include <stdlib.h>
+#include <utility>
+#include <vector>
 
 namespace {
 
@@ -45,6 +49,8 @@ struct CLaunch {
   const int32_t* lengths;
   unsigned epoch_base;
   unsigned long long* dbg;           // diagnostics only: per-workgroup phase cycle sums (NULL in production)
+  int xcd_local;                     // EXPERIMENT: publish with plain stores (valid only when a cluster shares one XCD)
+  short blk2role[256];               // blockIdx -> linear role (-1: no role, exit at once); roles of one cluster share blockIdx % 8
 };
 
 // xchg layout per descriptor: [0,64) abort word | flags: (dir, group, wg) x 64 B | X: (dir, group, parity) x GROUP x XW bf16
@@ -59,6 +65,7 @@ __host__ __device__ inline size_t xchg_bytes(int ngroups_total, int NC, int Hp) 
 __device__ __forceinline__ void st_rlx(void* p, u64 v) { __hip_atomic_store((gu64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u64 ld_rlx(const void* p) { return __hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_flag(void* p, unsigned v) { __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_flag_plain(void* p, unsigned v) { __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ unsigned ld_flag(const void* p) { return __hip_atomic_load((gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -67,6 +74,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(void* p, unsigned by
   return __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)bytes, 0x00020000);
 }
 __device__ __forceinline__ void st16_sc1(__amdgpu_buffer_rsrc_t r, unsigned off, u32x4 v) { __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 16); }
+__device__ __forceinline__ void st16_plain(__amdgpu_buffer_rsrc_t r, unsigned off, u32x4 v) { __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 0); }
 __device__ __forceinline__ u32x4 ld16_sc1(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16); }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t X_of(unsigned epoch, const __amdgpu_buffer_rsrc_t (&xr)[2]) {
@@ -74,14 +82,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t X_of(unsigned epoch, const __a
 }
 
 struct Where { int di, dir, grp, me; };
-__device__ __forceinline__ Where locate(const CLaunch& L) {
+__device__ __forceinline__ Where locate(const CLaunch& L, int role) {
   Where w;
   w.di = 0;
 #pragma unroll
   for (int i = 1; i < MAXD; ++i)
-    if (i < L.n && (int)blockIdx.x >= L.d[i].wg_begin) w.di = i;
+    if (i < L.n && role >= L.d[i].wg_begin) w.di = i;
   const CDesc& D = L.d[w.di];
-  int local = blockIdx.x - D.wg_begin;
+  int local = role - D.wg_begin;
   w.dir = local / (L.ng * D.NC);
   int rem = local % (L.ng * D.NC);
   w.grp = L.g0 + rem / D.NC;
@@ -133,7 +141,9 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_cluster_kernel(CLaunch L) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // the serial chain of this kernel is the critical path of the step: its waves issue ahead of any GEMM waves that share the CU
   __builtin_amdgcn_s_setprio(3);
-  const Where wh = locate(L);
+  const int role = L.blk2role[blockIdx.x];
+  if (role < 0) return;
+  const Where wh = locate(L, role);
   const CDesc& D = L.d[wh.di];
   const int H = D.H, Hp = D.Hp, Kp = D.Kp, KS = D.KS, nHT = D.nHT, TPW = D.TPW, NC = D.NC;
   const int B = L.B, T = L.T, dir = wh.dir, me = wh.me;
@@ -160,6 +170,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_cluster_kernel(CLaunch L) {
   {
     const uint4* src = reinterpret_cast<const uint4*>(D.wpack[dir]);
     const int per_tile = 4 * KS * 64;
+    if (!(KSC > 0 && KS == KSC))                          // register-resident weights need no LDS copy
     for (int i = tid; i < TPW * per_tile; i += 256) {
       int l2 = i / per_tile, h2 = me * TPW + l2;
       Wl[i] = h2 < nHT ? src[(size_t)h2 * per_tile + (i % per_tile)] : uint4{0, 0, 0, 0};
@@ -185,6 +196,16 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_cluster_kernel(CLaunch L) {
   }
   float c_reg[4] = {0.f, 0.f, 0.f, 0.f}, h_reg[4] = {0.f, 0.f, 0.f, 0.f};
   float pre[2][4][4];                                   // input-to-hidden pre-activations, prefetched TWO steps ahead
+  // register-resident W_hh fragments of this wave's hidden tile (compile-time KS only; see do_step)
+  bf16x8 wreg[4][KSC > 0 ? KSC : 1];
+  if (KSC > 0 && KS == KSC) {
+    const bf16x8* src = reinterpret_cast<const bf16x8*>(D.wpack[dir]);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int k2 = 0; k2 < (KSC > 0 ? KSC : 1); ++k2)
+        wreg[g][k2] = tile_ok ? src[((size_t)(ht * 4 + g) * KSC + k2) * 64 + lane] : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  }
 
   auto load_pre = [&](float (&dst)[4][4], int step) {
     const int t = dir ? T - 1 - step : step;
@@ -232,25 +253,18 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_cluster_kernel(CLaunch L) {
       const unsigned short* hrow = hb + (cur * GROUP + mt * 16 + fr) * ld + fq * 8;
       const bf16x8* wp = reinterpret_cast<const bf16x8*>(Wl) + (size_t)(lt * 4) * KS * 64 + lane;
       if (KSC > 0 && KS == KSC) {
-        // compile-time trip count (text: 10).  The 25 fragment reads of each half are issued first (100 VGPRs), then its 20 MFMAs consume them behind counted lgkmcnt waits: left to
-        // itself hipcc keeps only 2-3 ds_read_b128 in flight and every MFMA eats a full LDS round trip.
-        constexpr int HK = KSC / 2;
+        // compile-time trip count (text: 10): the 40 W_hh fragments of this wave's hidden tile live in REGISTERS for the whole
+        // sequence (wreg, 160 VGPRs; the kernel runs one wave per SIMD, so 512 are available).  Per step only the ten h
+        // fragments come from LDS; re-reading the weights from LDS cost 200 KB of LDS traffic per step and workgroup, which
+        // at 128 B/clk was longer than the MFMAs themselves.
+        bf16x8 af[KSC];
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          bf16x8 af[HK], bfr[HK][4];
+        for (int k2 = 0; k2 < KSC; ++k2) af[k2] = *reinterpret_cast<const bf16x8*>(hrow + k2 * 32);
+        __builtin_amdgcn_sched_barrier(0);           // all ten reads in flight before the first MFMA (else hipcc serialises read -> wait -> 4 MFMAs)
 #pragma unroll
-          for (int k2 = 0; k2 < HK; ++k2) {
-            af[k2] = *reinterpret_cast<const bf16x8*>(hrow + (half * HK + k2) * 32);
+        for (int k2 = 0; k2 < KSC; ++k2) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) bfr[k2][g] = wp[(g * KSC + half * HK + k2) * 64];
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int k2 = 0; k2 < HK; ++k2) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k2], bfr[k2][g], acc[g], 0, 0, 0);
-          }
-          __builtin_amdgcn_sched_barrier(0);
+          for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k2], wreg[g][k2], acc[g], 0, 0, 0);
         }
       } else {
 #pragma unroll 2
@@ -260,6 +274,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_cluster_kernel(CLaunch L) {
           for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wp[(g * KS + ks) * 64], acc[g], 0, 0, 0);
         }
       }
+      if (L.dbg) { asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0])); STAMP(7); }
       // lane-local cell update, branch-free (inactive lanes compute on zeros and are masked by the selects / OOB stores)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -293,12 +308,13 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_cluster_kernel(CLaunch L) {
         int row = i / cpr, cc = c0 + (i % cpr) * 8;
         if (cc >= Hp) continue;                          // last workgroup: tiles past the padded width do not exist
         u32x4 v = *reinterpret_cast<const u32x4*>(&hb[((cur ^ 1) * GROUP + row) * ld + cc]);
-        st16_sc1(X, (unsigned)((row * XW + cc) * 2), v);
+        if (L.xcd_local) st16_plain(X, (unsigned)((row * XW + cc) * 2), v);
+        else st16_sc1(X, (unsigned)((row * XW + cc) * 2), v);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
       STAMP(2);
       __syncthreads();
-      if (tid == 0) st_flag(flags + (size_t)me * 64, epoch);
+      if (tid == 0) { if (L.xcd_local) st_flag_plain(flags + (size_t)me * 64, epoch); else st_flag(flags + (size_t)me * 64, epoch); }
       STAMP(3);
       load_pre(P, step + 2);                             // lands while the cluster is being polled
       ok = wait_cluster(flags, abort_w, NC, me, epoch, &lds_ok);
@@ -329,8 +345,10 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_cluster_kernel(CLaunch L) {
     }
     if (step < T) do_step(step, pre[0], cur);
   }
-  if (L.dbg && tid == 0)
-    for (int i = 0; i < 8; ++i) L.dbg[(size_t)blockIdx.x * 8 + i] = ph[i];
+  if (L.dbg && tid == 0) {
+    for (int i = 0; i < 8; ++i) L.dbg[(size_t)role * 8 + i] = ph[i];
+    if (L.xcd_local < 0) L.dbg[(size_t)role * 8 + 7] = ((unsigned long long)blockIdx.x << 32) | (unsigned)__builtin_amdgcn_s_getreg(6164);   // XCC_ID
+  }
 #undef STAMP
   // final hidden state straight into the utterance layout [h1_fwd, h2_fwd, h1_bwd, h2_bwd] (models.py:203)
 #pragma unroll
@@ -354,7 +372,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(CLaunch L) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // the serial chain of this kernel is the critical path of the step: its waves issue ahead of any GEMM waves that share the CU
   __builtin_amdgcn_s_setprio(3);
-  const Where wh = locate(L);
+  const int role = L.blk2role[blockIdx.x];
+  if (role < 0) return;
+  const Where wh = locate(L, role);
   const CDesc& D = L.d[wh.di];
   const int H = D.H, Hp = D.Hp, nHT = D.nHT, TPW = D.TPW, NC = D.NC;
   const int B = L.B, T = L.T, dir = wh.dir, me = wh.me;
@@ -383,6 +403,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(CLaunch L) {
     // cluster-backward packing: [(ht*nHT + nt)*2 + ks2][lane] x 16 B; the tiles of this workgroup are contiguous blocks
     const uint4* src = reinterpret_cast<const uint4*>(D.wpack_c[dir]);
     const int per_tile = nHT * 2 * 64;
+    if (!(NTC > 0 && nHT <= 2 * NTC))                     // register-resident weights need no LDS copy
     for (int i = tid; i < TPW * per_tile; i += 256) {
       int l2 = i / per_tile, h2 = me * TPW + l2;
       Wl[i] = h2 < nHT ? src[(size_t)h2 * per_tile + (i % per_tile)] : uint4{0, 0, 0, 0};
@@ -412,6 +433,23 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(CLaunch L) {
     d_fin[r] = ldf(ru, inb[r] ? ((unsigned)b * 4u * H + (dir * 2 + D.layer) * H + col) * 4u : OOB);
   }
   float dh_rec[4] = {0.f, 0.f, 0.f, 0.f}, dc[4] = {0.f, 0.f, 0.f, 0.f};
+  // register-resident W_hh fragments (compile-time n-tile count only): this wave's n-tiles nt = (wave>>1) + 2i, four k-steps
+  // (the gate rows of the workgroup's two hidden tiles) -> 40 fragments = 160 VGPRs, loaded once for the whole sequence
+  bf16x8 wreg[NTC > 0 ? NTC : 1][4];
+  const bool use_wreg = NTC > 0 && nHT <= 2 * NTC;      // launch-uniform
+  if (use_wreg) {
+    const bf16x8* src = reinterpret_cast<const bf16x8*>(D.wpack_c[dir]);
+#pragma unroll
+    for (int i = 0; i < (NTC > 0 ? NTC : 1); ++i) {
+      const int nt = (wave >> 1) + 2 * i;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int h2 = me * TPW + (ks >> 1);
+        const bool have = nt < nHT && ks < TPW * 2 && h2 < nHT;
+        wreg[i][ks] = have ? src[((size_t)(h2 * nHT + nt) * 2 + (ks & 1)) * 64 + lane] : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    }
+  }
   struct Stash { float g[4][4], c[4], cp[4], dh[4]; };
   Stash sb[2];                                          // forward stash of the coming steps, prefetched TWO steps ahead
 
@@ -499,16 +537,30 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(CLaunch L) {
       for (int ks = 0; ks < 4; ++ks)
         af[ks] = *reinterpret_cast<const bf16x8*>(&Ab[(mt * 16 + fr) * lda + (ks < TPW * 2 ? ks : 0) * 32 + fq * 8]);
       const bf16x8* wbase = reinterpret_cast<const bf16x8*>(Wl) + lane;
+      if (use_wreg) {
 #pragma unroll
-      for (int i = 0; i < (NTC > 0 ? NTC : MAXNT); ++i) {
-        const int nt = (wave >> 1) + 2 * i;
-        if (nt >= nHT) break;
-        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < (NTC > 0 ? NTC : 1); ++i) {
+          const int nt = (wave >> 1) + 2 * i;
+          f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-          if (ks < TPW * 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], wbase[(((ks >> 1) * nHT + nt) * 2 + (ks & 1)) * 64], acc, 0, 0, 0);
+          for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], wreg[i][ks], acc, 0, 0, 0);
+          if (nt < nHT) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) St[(mt * 16 + fq * 4 + r) * lds + nt * 16 + fr] = f2bf(acc[r]);
+            for (int r = 0; r < 4; ++r) St[(mt * 16 + fq * 4 + r) * lds + nt * 16 + fr] = f2bf(acc[r]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < MAXNT; ++i) {
+          const int nt = (wave >> 1) + 2 * i;
+          if (nt >= nHT) break;
+          f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+            if (ks < TPW * 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], wbase[(((ks >> 1) * nHT + nt) * 2 + (ks & 1)) * 64], acc, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) St[(mt * 16 + fq * 4 + r) * lds + nt * 16 + fr] = f2bf(acc[r]);
+        }
       }
     }
     __syncthreads();                                     // staged partial complete
@@ -518,11 +570,12 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(CLaunch L) {
 #pragma unroll
       for (int u = 0; u < BPU; ++u) {
         u32x4 v = *reinterpret_cast<const u32x4*>(&St[psrc[u]]);
-        st16_sc1(X, poff[u], v);                         // out-of-range offsets (own columns / past the end) are dropped
+        if (L.xcd_local) st16_plain(X, poff[u], v);
+        else st16_sc1(X, poff[u], v);                    // out-of-range offsets (own columns / past the end) are dropped
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid == 0) st_flag(flags + (size_t)me * 64, epoch);
+      if (tid == 0) { if (L.xcd_local) st_flag_plain(flags + (size_t)me * 64, epoch); else st_flag(flags + (size_t)me * 64, epoch); }
       load_stash(S, step + 2);                           // lands while the cluster is being polled
       ok = wait_cluster(flags, abort_w, NC, me, epoch, &lds_ok);
       if (ok) {
@@ -639,10 +692,39 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
       c.wg_begin = wg;
       if (i < n) wg += 2 * L.ng * p.NC;
     }
-    dim3 grid(wg), block(256);
+    // Placement (speed only): blocks b and b + 8 are dealt to the same XCD, so the members of one cluster get block ids that
+    // are equal mod 8; clusters go to the XCD with the fewest members so far.
+    static const int use_place = getenv("MMDA_NO_PLACEMENT") ? 0 : 1;
+    L.xcd_local = getenv("MMDA_XCD_LOCAL") ? 1 : 0;
+    for (int b = 0; b < 256; ++b) L.blk2role[b] = -1;
+    int grid_blocks = wg;
+    {
+      int used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      bool fits = use_place && wg <= 256;
+      std::vector<std::pair<int, int>> clusters;     // (first role, NC)
+      for (int i = 0; i < n; ++i)
+        for (int c2 = 0; c2 < 2 * L.ng; ++c2) clusters.push_back({L.d[i].wg_begin + c2 * plans[i].NC, plans[i].NC});
+      std::stable_sort(clusters.begin(), clusters.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.second > b.second; });
+      short map[256];
+      for (int b = 0; b < 256; ++b) map[b] = -1;
+      int max_slots = 0;
+      for (auto& cl : clusters) {
+        int x = 0;
+        for (int k = 1; k < 8; ++k) if (used[k] < used[x]) x = k;
+        if (used[x] + cl.second > 32) { fits = false; break; }
+        for (int j = 0; j < cl.second; ++j) map[(used[x] + j) * 8 + x] = (short)(cl.first + j);
+        used[x] += cl.second;
+        if (used[x] > max_slots) max_slots = used[x];
+      }
+      if (fits) { for (int b = 0; b < 256; ++b) L.blk2role[b] = map[b]; grid_blocks = 8 * max_slots; }
+      else { for (int b = 0; b < wg && b < 256; ++b) L.blk2role[b] = (short)b; L.xcd_local = 0; }
+    }
+    bool bwd_regs = true;                    // every descriptor's n-tiles fit the register-resident form (<= 10 per wave)
+    for (int i = 0; i < n; ++i) bwd_regs = bwd_regs && L.d[i].nHT <= 20;
+    dim3 grid(grid_blocks), block(256);
 #define LAUNCH_C()                                                                                               \
   do {                                                                                                           \
-    auto kfn = bwd ? lstm_bwd_cluster_kernel<0> : lstm_fwd_cluster_kernel<10>;                                  \
+    auto kfn = bwd ? (bwd_regs ? lstm_bwd_cluster_kernel<10> : lstm_bwd_cluster_kernel<0>) : lstm_fwd_cluster_kernel<10>;   \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,     \
                             (int)lds) != hipSuccess) { (void)hipGetLastError(); }                                \
     hipLaunchKernelGGL(kfn, grid, block, lds, s, L);                                                             \

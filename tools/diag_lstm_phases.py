@@ -12,7 +12,7 @@ pre = torch.randn(T, B, 2, 4 * H, device=d)
 wf = (torch.rand(4 * H, H, device=d) - 0.5) * 0.1; wr = (torch.rand(4 * H, H, device=d) - 0.5) * 0.1
 lengths = torch.full((B,), T)
 dbg = torch.zeros(64 * 8, dtype=torch.int64, device=d)
-names = ["compute+ldswrite", "barrier1", "publish+drain", "barrier2+flag", "poll+barrier3", "gather issue+side traffic", "gather wait+ldswrite", "barrier4"]
+names = ["cell update+stash stores+lds write", "barrier1", "publish+drain", "barrier2+flag", "poll+barrier3", "gather issue+side traffic", "gather wait+ldswrite", "h fragments from LDS + MFMA"]
 for it in range(3):
     lib.mmda_debug_set_lstm_stamps(dbg.data_ptr())
     torch.cuda.synchronize()
@@ -22,7 +22,8 @@ for it in range(3):
     e1.record(); torch.cuda.synchronize()
     lib.mmda_debug_set_lstm_stamps(None)
     print(f"iter {it}: whole op (pack + kernel) {e0.elapsed_time(e1)*1e3:.0f} us; aborted={ops.lstm_aborted(fw)}")
-v = dbg.view(64, 8)[:20].cpu().double()
+raw = dbg.view(64, 8)[:20].cpu()
+v = raw.double()
 tot = v.sum(1)
 print("per-WG total cycles/step:", (tot / T).tolist())
 for i, n in enumerate(names):
