@@ -85,6 +85,11 @@ typedef struct mmda_gemm_bf16_args {
   const float* bias; const float* bias2;
   float* bias_grad; float* bias_grad2;
   int accumulate; float alpha;       /* alpha 0 is read as 1 */
+  /* gate interleave (the LSTM's gate-minor layout, see mmda_lstm_desc.gate_minor): index j of the interleaved axis stands for
+   * torch's index orig(j) = (j / 4H) * 4H + (j % 4) * H + (j % 4H) / 4.   perm_n_H = H: bias/bias2 are read at orig(n)
+   * (forward: B rows were interleaved by mmda_convert_bf16).  perm_m_H = H: C rows and bias_grad entries are written at
+   * orig(m) (weight gradients: A rows are interleaved).  0 = no interleave. */
+  int perm_n_H, perm_m_H;
 } mmda_gemm_bf16_args;
 int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, void* stream);
 /* fp32 (rows, cols) matrix with leading dim ld -> bf16 copies: `plain` (rows, ldp) and/or `transposed` (cols, ldt); either may be
@@ -95,6 +100,7 @@ typedef struct mmda_convert_job {
   const int64_t* gather;
   void* plain; int ldp;
   void* transposed; int ldt;
+  int row_perm_H;                    /* H > 0: output row r reads source row orig(r) (gate interleave, see mmda_gemm_bf16_args) */
 } mmda_convert_job;
 int mmda_convert_bf16(const mmda_convert_job* jobs, int n, void* stream);
 
@@ -199,8 +205,14 @@ typedef struct mmda_lstm_desc {
                           selects the streaming kernels. */
   uint32_t epoch_base; /* cluster kernels: monotonic epoch counter of descs[0] is used for the launch; the caller advances it by
                           at least T+1 between launches that share an xchg buffer (flags are never reset) */
+  int gate_minor;      /* 0: `gates` columns are [dir][gate][unit] (torch's weight_ih row order).  1: [dir][unit][gate], i.e. the four
+                          gates of one hidden unit are 16 contiguous bytes: the resident-weights kernels then move them with one
+                          16-byte access instead of four 4-byte ones (the address unit, shared by the CU's four waves, is what
+                          their per-step stash traffic is bound by).  Only the resident-weights kernels accept 1. */
 } mmda_lstm_desc;
 int64_t mmda_lstm_xchg_bytes(int H, int B);
+/* 1 if mmda_lstm_fwd/bwd would run these descriptors on the resident-weights kernels (so gate_minor = 1 may be used), else 0 */
+int mmda_lstm_resident_applicable(int mode, int n, const mmda_lstm_desc* descs, int B, int T, int backward);
 /* diagnostics only: 8 x uint64 per workgroup, phase cycle sums of the resident-weights forward kernel (NULL disables) */
 int mmda_debug_set_lstm_stamps(void* device_buffer);
 /* up to 4 independent biLSTMs (modalities) in ONE launch; all share B, T and lengths (device int32, B entries) */

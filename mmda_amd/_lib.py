@@ -35,12 +35,12 @@ class GemmArgs(C.Structure):
 class GemmBf16Args(C.Structure):
     _fields_ = [("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("A", C.c_void_p), ("lda", C.c_int), ("B", C.c_void_p), ("ldb", C.c_int),
                 ("C", C.c_void_p), ("ldc", C.c_int), ("bias", C.c_void_p), ("bias2", C.c_void_p), ("bias_grad", C.c_void_p),
-                ("bias_grad2", C.c_void_p), ("accumulate", C.c_int), ("alpha", C.c_float)]
+                ("bias_grad2", C.c_void_p), ("accumulate", C.c_int), ("alpha", C.c_float), ("perm_n_H", C.c_int), ("perm_m_H", C.c_int)]
 
 
 class ConvertJob(C.Structure):
     _fields_ = [("src", C.c_void_p), ("ld", C.c_int), ("rows", C.c_int), ("cols", C.c_int), ("gather", C.c_void_p),
-                ("plain", C.c_void_p), ("ldp", C.c_int), ("transposed", C.c_void_p), ("ldt", C.c_int)]
+                ("plain", C.c_void_p), ("ldp", C.c_int), ("transposed", C.c_void_p), ("ldt", C.c_int), ("row_perm_H", C.c_int)]
 
 
 class SkinnyArgs(C.Structure):
@@ -73,7 +73,7 @@ class LnBwdArgs(C.Structure):
 class LstmDesc(C.Structure):
     _fields_ = [("H", C.c_int), ("gates", C.c_void_p), ("cstash", C.c_void_p), ("hseq", C.c_void_p),
                 ("wpack", C.c_void_p * 2), ("wpack_c", C.c_void_p * 2), ("utt", C.c_void_p), ("layer", C.c_int), ("d_hseq", C.c_void_p),
-                ("xchg", C.c_void_p), ("epoch_base", C.c_uint32)]
+                ("xchg", C.c_void_p), ("epoch_base", C.c_uint32), ("gate_minor", C.c_int)]
 
 
 class MisaConfig(C.Structure):
@@ -105,6 +105,7 @@ SIGNATURES = {
     "mmda_layernorm_param_grads": (_I, [C.POINTER(LnBwdArgs), _I, _P]),
     "mmda_lstm_packed_bytes": (_I64, [_I, _I, _I]),
     "mmda_lstm_xchg_bytes": (_I64, [_I, _I]),
+    "mmda_lstm_resident_applicable": (_I, [_I, _I, C.POINTER(LstmDesc), _I, _I, _I]),
     "mmda_debug_set_lstm_stamps": (_I, [_P]),
     "mmda_lstm_pack_whh": (_I, [_I, _I, _P, _P, _P, _P]),
     "mmda_lstm_pack_whh_multi": (_I, [_I, _I, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),

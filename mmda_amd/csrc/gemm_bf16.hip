@@ -25,6 +25,12 @@ struct Bf16Group {
   int n;
 };
 
+// gate interleave: index j of an interleaved axis stands for torch's index orig(j) (see mmda_gemm_bf16_args)
+__host__ __device__ __forceinline__ int gate_orig(int j, int H) {
+  const int G = 4 * H, d = j / G, q = j - d * G;
+  return d * G + (q & 3) * H + (q >> 2);
+}
+
 __device__ __forceinline__ u32x4 ld_chunk(const unsigned short* base, int row, int nrows, int ld, int k, int Kp) {
   // 8 bf16 = 16 B; rows past the matrix and k past the (8-padded) depth read as zero.  The load itself is unconditional from a
   // clamped (always valid) address: a load under a lane-dependent branch costs a full s_waitcnt vmcnt(0) per chunk.
@@ -146,8 +152,9 @@ __device__ __forceinline__ void gemm_bf16_tile(const mmda_gemm_bf16_args& g, int
 #pragma unroll
           for (int jj = 0; jj < W; ++jj) v = (jj == j) ? acc[i][jj][r] : v;
           if (m < M) {
-            atomicAdd(&g.bias_grad[m], v);
-            if (g.bias_grad2) atomicAdd(&g.bias_grad2[m], v);
+            const int mo = g.perm_m_H > 0 ? gate_orig(m, g.perm_m_H) : m;
+            atomicAdd(&g.bias_grad[mo], v);
+            if (g.bias_grad2) atomicAdd(&g.bias_grad2[mo], v);
           }
         }
     }
@@ -163,7 +170,8 @@ __device__ __forceinline__ void gemm_bf16_tile(const mmda_gemm_bf16_args& g, int
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int nc = min(col0 + wn * (T / 2) + j * 16 + (lane & 15), N - 1);
-        const int mc = min(row0 + wm * (T / 2) + i * 16 + (lane >> 4) * 4 + r, M - 1);
+        int mc = min(row0 + wm * (T / 2) + i * 16 + (lane >> 4) * 4 + r, M - 1);
+        if (g.perm_m_H > 0) mc = gate_orig(mc, g.perm_m_H);
         oldc[j][r] = rmw ? g.C[(int64_t)mc * g.ldc + nc] : 0.f;
       }
 #pragma unroll
@@ -172,13 +180,14 @@ __device__ __forceinline__ void gemm_bf16_tile(const mmda_gemm_bf16_args& g, int
       const bool n_ok = n < N;
       const int nc = min(n, N - 1);
       float bsum = 0.f;
-      if (g.bias) bsum += g.bias[nc];
-      if (g.bias2) bsum += g.bias2[nc];
+      const int nb = g.perm_n_H > 0 ? gate_orig(nc, g.perm_n_H) : nc;
+      if (g.bias) bsum += g.bias[nb];
+      if (g.bias2) bsum += g.bias2[nb];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = row0 + wm * (T / 2) + i * 16 + (lane >> 4) * 4 + r;
         if (!n_ok || m >= M) continue;
-        const int64_t ci = (int64_t)m * g.ldc + n;
+        const int64_t ci = (int64_t)(g.perm_m_H > 0 ? gate_orig(m, g.perm_m_H) : m) * g.ldc + n;
         if (splitk > 1) atomicAdd(&g.C[ci], alpha * acc[i][j][r] + (sp == 0 ? bsum : 0.f));
         else g.C[ci] = alpha * acc[i][j][r] + bsum + oldc[j][r];
       }
@@ -230,7 +239,8 @@ __global__ __launch_bounds__(256) void convert_kernel(ConvLaunch L) {
   int64_t srow[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    const int rc = min(r0 + ty + 4 * i, J.rows - 1);
+    int rc = min(r0 + ty + 4 * i, J.rows - 1);
+    if (J.row_perm_H > 0) rc = gate_orig(rc, J.row_perm_H);
     srow[i] = J.gather ? J.gather[rc] : (int64_t)rc;
   }
   float v[16];
@@ -266,6 +276,7 @@ extern "C" int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, vo
       if (!a.A || !a.B || !a.C || a.M < 0 || a.N < 0 || a.K <= 0) return MMDA_EINVAL;
       if ((a.lda & 7) || (a.ldb & 7) || (((uintptr_t)a.A | (uintptr_t)a.B) & 15)) return MMDA_EINVAL;
       if (a.lda < ((a.K + 7) & ~7) || a.ldb < ((a.K + 7) & ~7)) return MMDA_EINVAL;
+      if (a.perm_n_H < 0 || a.perm_m_H < 0 || (a.perm_n_H && a.N % (4 * a.perm_n_H)) || (a.perm_m_H && a.M % (4 * a.perm_m_H))) return MMDA_EINVAL;
     }
     int blocks = 0;
     for (int i = 0; i < cnt; ++i) {
@@ -322,6 +333,7 @@ extern "C" int mmda_convert_bf16(const mmda_convert_job* jobs, int n, void* stre
       if (!j.src || j.rows < 0 || j.cols < 0 || (!j.plain && !j.transposed)) return MMDA_EINVAL;
       if (j.plain && (j.ldp < ((j.cols + 7) & ~7) || (j.ldp & 7))) return MMDA_EINVAL;
       if (j.transposed && (j.ldt < ((j.rows + 7) & ~7) || (j.ldt & 7))) return MMDA_EINVAL;
+      if (j.row_perm_H < 0 || (j.row_perm_H && (j.gather || j.rows % (4 * j.row_perm_H)))) return MMDA_EINVAL;
       if (j.rows == 0 || j.cols == 0) continue;
       const int k = L.n++;
       L.j[k] = j;

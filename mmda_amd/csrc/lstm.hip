@@ -438,6 +438,8 @@ int lstm_common(int mode, int n, const mmda_lstm_desc* descs, int B, int T, cons
     if (rc != MMDA_OK) return rc;
     if (used) return MMDA_OK;
   }
+  for (int i = 0; i < n; ++i)
+    if (descs[i].gate_minor) return MMDA_EINVAL;       // the streaming kernels only know torch's [dir][gate][unit] column order
   int Hp = round_up(maxH, 16), Kp = round_up(maxH, 32);
   size_t lds;
   if (!bwd) lds = (mode == MMDA_BF16) ? (size_t)2 * 16 * (Kp + 8) * 2 : (size_t)2 * 16 * (Kp + 2) * 4;

@@ -49,6 +49,7 @@ struct CLaunch {
   const int32_t* lengths;
   unsigned epoch_base;
   unsigned long long* dbg;           // diagnostics only: per-workgroup phase cycle sums (NULL in production)
+  int gate_minor;                    // `gates` columns are [dir][unit][gate]: 16-byte accesses (see mmda_lstm_desc)
   int xcd_local;                     // EXPERIMENT: publish with plain stores (valid only when a cluster shares one XCD)
   short blk2role[256];               // blockIdx -> linear role (-1: no role, exit at once); roles of one cluster share blockIdx % 8
 };
@@ -133,10 +134,16 @@ __device__ __forceinline__ float ldf(__amdgpu_buffer_rsrc_t r, unsigned off) {
 __device__ __forceinline__ void stf(__amdgpu_buffer_rsrc_t r, unsigned off, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
 }
+__device__ __forceinline__ f32x4 ldf4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ __forceinline__ void stf4(__amdgpu_buffer_rsrc_t r, unsigned off, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
+}
 
 // ------------------------------------------------------------------------------------------------ forward
 // wave -> (m-tile mt = wave&1 : 16 of the group's 32 samples, local hidden tile lt = wave>>1 < TPW)
-template <int KSC>
+template <int KSC, bool GM>
 __global__ __launch_bounds__(256, 1) void lstm_fwd_cluster_kernel(CLaunch L) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // the serial chain of this kernel is the critical path of the step: its waves issue ahead of any GEMM waves that share the CU
@@ -157,6 +164,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_cluster_kernel(CLaunch L) {
   const int XW = 4 * Hp;
   const int ngt = (B + GROUP - 1) / GROUP;
   const unsigned G4 = 4u * H;
+  constexpr bool gm = GM;                               // layout of `gates` (compile time: both forms in one kernel cost registers)
 
   uint4* Wl = reinterpret_cast<uint4*>(smem);                                            // TPW*4*KS*64 x 16 B
   unsigned short* hb = reinterpret_cast<unsigned short*>(smem + (size_t)TPW * 4 * KS * 1024);   // 2 x GROUP x ld
@@ -190,7 +198,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_cluster_kernel(CLaunch L) {
     inb[r] = tile_ok && col < H && b < B;
     const int lv = L.lengths[min(b, B - 1)];
     len_r[r] = inb[r] ? lv : 0;
-    og[r] = (((unsigned)b * 2u + dir) * G4 + col) * 4u;
+    og[r] = (((unsigned)b * 2u + dir) * G4 + (gm ? col * 4 : col)) * 4u;
     oc[r] = (((unsigned)b * 2u + dir) * H + col) * 4u;
     oh[r] = ((unsigned)b * 2u * H + dir * H + col) * 4u;
   }
@@ -213,8 +221,14 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_cluster_kernel(CLaunch L) {
     for (int r = 0; r < 4; ++r) {
       const bool act = step < T && t < len_r[r];
       const unsigned o = og[r] + (unsigned)t * sg;
+      if (gm) {
+        const f32x4 v = ldf4(rg, act ? o : OOB);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) dst[g][r] = ldf(rg, act ? o + g * H * 4u : OOB);
+        for (int g = 0; g < 4; ++g) dst[g][r] = v[g];
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dst[g][r] = ldf(rg, act ? o + g * H * 4u : OOB);
+      }
     }
   };
   load_pre(pre[0], 0);
@@ -242,10 +256,27 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_cluster_kernel(CLaunch L) {
 #define STAMP(i) do { if (L.dbg && tid == 0) { unsigned long long now_ = __builtin_readcyclecounter(); ph[i] += now_ - last; last = now_; } } while (0)
   if (L.dbg && tid == 0) last = __builtin_readcyclecounter();
 
+  auto store_stash = [&](const float (&sv)[4][6], int t) {
+    if (!tile_ok) return;                                // wave-uniform
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool act = t < len_r[r];
+      const unsigned o = act ? og[r] + (unsigned)t * sg : OOB;
+      if (gm) {
+        stf4(rg, o, f32x4{sv[r][0], sv[r][1], sv[r][2], sv[r][3]});
+      } else {
+        stf(rg, o, sv[r][0]); stf(rg, act ? o + H * 4u : OOB, sv[r][1]); stf(rg, act ? o + 2u * H * 4u : OOB, sv[r][2]);
+        stf(rg, act ? o + 3u * H * 4u : OOB, sv[r][3]);
+      }
+      stf(rc, act ? oc[r] + (unsigned)t * sc : OOB, sv[r][4]);
+      stf(rh, inb[r] ? oh[r] + (unsigned)t * sc : OOB, sv[r][5]);     // zero at padded positions (pad_packed_sequence)
+    }
+  };
   // one time step with the pre-activation buffer `P` (static index: the loop below is unrolled by two)
   auto do_step = [&](int step, float (&P)[4][4], int cur) -> bool {
     const int t = dir ? T - 1 - step : step;
     const unsigned epoch = L.epoch_base + (unsigned)step + 1u;
+    float sv[4][6];
     if (tile_ok) {
       f32x4 acc[4];
 #pragma unroll
@@ -288,13 +319,11 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_cluster_kernel(CLaunch L) {
         c_reg[r] = act ? cn : c_reg[r];
         h_reg[r] = act ? hn : h_reg[r];
         hb[((cur ^ 1) * GROUP + mt * 16 + fq * 4 + r) * ld + col] = f2bf(h_reg[r]);
-        // stash of this step: the publish drain below covers these stores, nothing younger stays outstanding later
-        const unsigned o = act ? og[r] + (unsigned)t * sg : OOB;
-        stf(rg, o, gi); stf(rg, act ? o + H * 4u : OOB, gf); stf(rg, act ? o + 2u * H * 4u : OOB, gg);
-        stf(rg, act ? o + 3u * H * 4u : OOB, go);
-        stf(rc, act ? oc[r] + (unsigned)t * sc : OOB, cn);
-        stf(rh, inb[r] ? oh[r] + (unsigned)t * sc : OOB, act ? hn : 0.f);     // zero at padded positions (pad_packed_sequence)
+        sv[r][0] = gi; sv[r][1] = gf; sv[r][2] = gg; sv[r][3] = go; sv[r][4] = cn; sv[r][5] = act ? hn : 0.f;
       }
+      // stash for the backward pass.  Measured: issued here (the publish drain covers it) beats issuing it after the flag store
+      // (the polling wave's flag reads queue behind it) or behind the gather loads (its ~40 VMEM issues then sit on the chain).
+      store_stash(sv, t);
     }
     STAMP(0);
     __syncthreads();                                     // own h slice complete in LDS
@@ -367,7 +396,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_cluster_kernel(CLaunch L) {
 constexpr int MAXNT = 16;          // n-tiles per wave (two waves share an m-tile): supports nHT <= 32
 constexpr int BPU = 8, BGU = 8;    // publish / gather 16-byte chunks per thread (text: 5 and 5)
 
-template <int NTC>
+template <int NTC, bool GM>
 __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(CLaunch L) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // the serial chain of this kernel is the critical path of the step: its waves issue ahead of any GEMM waves that share the CU
@@ -387,6 +416,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(CLaunch L) {
   const int KW = TPW * 64, lda = KW + 8, lds = Hp + 8, OW = TPW * 16;
   const int ngt = (B + GROUP - 1) / GROUP;
   const unsigned G4 = 4u * H;
+  constexpr bool gm = GM;                               // layout of `gates` (compile time: both forms in one kernel cost registers)
 
   // LDS: W slice [lt][nt][ks2] fragments | A (own dG) | staging (partial dh) | gathered partials | flag
   size_t off = 0;
@@ -427,7 +457,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(CLaunch L) {
     inb[r] = tile_ok && col < H && b < B;
     const int lv = L.lengths[min(b, B - 1)];
     len_r[r] = inb[r] ? lv : 0;
-    og[r] = (((unsigned)b * 2u + dir) * G4 + col) * 4u;
+    og[r] = (((unsigned)b * 2u + dir) * G4 + (gm ? col * 4 : col)) * 4u;
     oc[r] = (((unsigned)b * 2u + dir) * H + col) * 4u;
     oh[r] = ((unsigned)b * 2u * H + dir * H + col) * 4u;
     d_fin[r] = ldf(ru, inb[r] ? ((unsigned)b * 4u * H + (dir * 2 + D.layer) * H + col) * 4u : OOB);
@@ -460,8 +490,14 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(CLaunch L) {
     for (int r = 0; r < 4; ++r) {
       const bool act = step < T && t < len_r[r];
       const unsigned o = og[r] + (unsigned)t * sg;
+      if (gm) {
+        const f32x4 v = ldf4(rg, act ? o : OOB);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) S.g[g][r] = ldf(rg, act ? o + g * H * 4u : OOB);
+        for (int g = 0; g < 4; ++g) S.g[g][r] = v[g];
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) S.g[g][r] = ldf(rg, act ? o + g * H * 4u : OOB);
+      }
       S.c[r] = ldf(rc, act ? oc[r] + (unsigned)t * sc : OOB);
       S.cp[r] = ldf(rc, (act && tp >= 0 && tp < len_r[r]) ? oc[r] + (unsigned)tp * sc : OOB);
       S.dh[r] = ldf(rd, act ? oh[r] + (unsigned)t * sc : OOB);          // zero-record descriptor when d_hseq == NULL
@@ -505,6 +541,20 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(CLaunch L) {
     const int t = dir ? step : T - 1 - step;
     const unsigned epoch = L.epoch_base + (unsigned)step + 1u;
     // (1) lane-local gate gradients of the own hidden units (branch-free); A operand into LDS, fp32 dG in place over the stash
+    float dgv[4][4];
+    auto store_dg = [&]() {
+      if (!tile_ok) return;                              // wave-uniform
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const unsigned o = inb[r] ? og[r] + (unsigned)t * sg : OOB;       // zero at padded positions too
+        if (gm) {
+          stf4(rg, o, f32x4{dgv[r][0], dgv[r][1], dgv[r][2], dgv[r][3]});
+        } else {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) stf(rg, inb[r] ? o + g * H * 4u : OOB, dgv[r][g]);
+        }
+      }
+    };
     if (tile_ok) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -521,11 +571,10 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(CLaunch L) {
         dp[3] = act ? dh * tc * go * (1.f - go) : 0.f;
         dc[r] = act ? dct * gf : dc[r];
         const int row = mt * 16 + fq * 4 + r;
-        const unsigned o = inb[r] ? og[r] + (unsigned)t * sg : OOB;       // zero at padded positions too
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           Ab[row * lda + lt * 64 + g * 16 + fr] = f2bf(dp[g]);
-          stf(rg, inb[r] ? o + g * H * 4u : OOB, dp[g]);
+          dgv[r][g] = dp[g];                             // fp32 dG goes to memory after the publish (off the chain)
         }
       }
     }
@@ -576,6 +625,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(CLaunch L) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) { if (L.xcd_local) st_flag_plain(flags + (size_t)me * 64, epoch); else st_flag(flags + (size_t)me * 64, epoch); }
+      store_dg();                                        // off the chain: the drain above only waited for the publish stores
       load_stash(S, step + 2);                           // lands while the cluster is being polled
       ok = wait_cluster(flags, abort_w, NC, me, epoch, &lds_ok);
       if (ok) {
@@ -588,6 +638,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(CLaunch L) {
       }
       __syncthreads();
     } else {
+      store_dg();
       load_stash(S, step + 2);
     }
     // (3) reduce: dh_{t-1} of the own units = own partial + the NC-1 gathered partials (fp32 sum of bf16 partials)
@@ -648,37 +699,58 @@ static unsigned long long* g_dbg = nullptr;
 // diagnostics only (tools/): device buffer of 8 x u64 per workgroup receiving the forward kernel's phase cycle sums
 extern "C" int mmda_debug_set_lstm_stamps(void* device_buffer) { g_dbg = (unsigned long long*)device_buffer; return MMDA_OK; }
 
-// returns MMDA_OK and sets *used = 1 when the cluster kernels ran; *used = 0 means "not applicable, use the streaming path"
-int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, const int32_t* lengths, void* stream, bool bwd,
-                             int* used) {
-  *used = 0;
-  if (n > MAXD) return MMDA_OK;
-  Plan plans[MAXD];
+namespace {
+// the checks that decide whether the resident-weights kernels can run these descriptors
+bool cluster_applicable(int n, const mmda_lstm_desc* descs, int B, int T, bool bwd, Plan* plans, size_t* lds_out) {
+  if (n > MAXD || n <= 0) return false;
   int maxtw = 1;
   size_t lds = 0;
   for (int i = 0; i < n; ++i) {
-    if (!descs[i].xchg) return MMDA_OK;
-    if (bwd && (!descs[i].wpack_c[0] || !descs[i].wpack_c[1])) return MMDA_OK;
+    if (!descs[i].xchg) return false;
+    if (bwd && (!descs[i].wpack_c[0] || !descs[i].wpack_c[1])) return false;
+    if (descs[i].gate_minor != descs[0].gate_minor) return false;
     plans[i] = plan_for(descs[i].H);
-    if (!plans[i].ok) return MMDA_OK;
+    if (!plans[i].ok) return false;
     maxtw = plans[i].maxtw > maxtw ? plans[i].maxtw : maxtw;
     size_t l = bwd ? plans[i].lds_b : plans[i].lds_f;
     lds = l > lds ? l : lds;
   }
-  if (maxtw > 1) return MMDA_OK;
+  if (maxtw > 1) return false;
   // buffer descriptors address 32-bit byte offsets: every per-step tensor must stay below 4 GiB
   for (int i = 0; i < n; ++i)
-    if ((double)T * B * 2.0 * 4.0 * descs[i].H * 4.0 >= 4.0e9) return MMDA_OK;
+    if ((double)T * B * 2.0 * 4.0 * descs[i].H * 4.0 >= 4.0e9) return false;
+  int wg_per_group = 0;
+  for (int i = 0; i < n; ++i) wg_per_group += 2 * plans[i].NC;
+  if (wg_per_group > MAX_WG_PER_LAUNCH) return false;
+  *lds_out = lds;
+  return true;
+}
+}  // namespace
+
+extern "C" int mmda_lstm_resident_applicable(int mode, int n, const mmda_lstm_desc* descs, int B, int T, int backward) {
+  if (mode != MMDA_BF16 || !descs || B <= 0 || T <= 0) return 0;
+  Plan plans[MAXD];
+  size_t lds = 0;
+  return cluster_applicable(n, descs, B, T, backward != 0, plans, &lds) ? 1 : 0;
+}
+
+// returns MMDA_OK and sets *used = 1 when the cluster kernels ran; *used = 0 means "not applicable, use the streaming path"
+int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, const int32_t* lengths, void* stream, bool bwd,
+                             int* used) {
+  *used = 0;
+  Plan plans[MAXD];
+  size_t lds = 0;
+  if (!cluster_applicable(n, descs, B, T, bwd, plans, &lds)) return MMDA_OK;
   const int ngt = ceil_div(B, GROUP);
   int wg_per_group = 0;
   for (int i = 0; i < n; ++i) wg_per_group += 2 * plans[i].NC;
-  if (wg_per_group > MAX_WG_PER_LAUNCH) return MMDA_OK;
   const int groups_per_launch = MAX_WG_PER_LAUNCH / wg_per_group;
   hipStream_t s = (hipStream_t)stream;
   for (int g0 = 0; g0 < ngt; g0 += groups_per_launch) {
     CLaunch L;
     L.n = n; L.B = B; L.T = T; L.g0 = g0; L.ng = (ngt - g0) < groups_per_launch ? (ngt - g0) : groups_per_launch;
     L.lengths = lengths; L.epoch_base = descs[0].epoch_base; L.dbg = bwd ? nullptr : g_dbg;
+    L.gate_minor = descs[0].gate_minor ? 1 : 0;
     int wg = 0;
     for (int i = 0; i < MAXD; ++i) {
       const mmda_lstm_desc& d = descs[i < n ? i : 0];
@@ -724,7 +796,9 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
     dim3 grid(grid_blocks), block(256);
 #define LAUNCH_C()                                                                                               \
   do {                                                                                                           \
-    auto kfn = bwd ? (bwd_regs ? lstm_bwd_cluster_kernel<10> : lstm_bwd_cluster_kernel<0>) : lstm_fwd_cluster_kernel<10>;   \
+    auto kfn = bwd ? (bwd_regs ? (L.gate_minor ? lstm_bwd_cluster_kernel<10, true> : lstm_bwd_cluster_kernel<10, false>)                \
+                              : (L.gate_minor ? lstm_bwd_cluster_kernel<0, true> : lstm_bwd_cluster_kernel<0, false>))                  \
+                   : (L.gate_minor ? lstm_fwd_cluster_kernel<10, true> : lstm_fwd_cluster_kernel<10, false>);                            \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,     \
                             (int)lds) != hipSuccess) { (void)hipGetLastError(); }                                \
     hipLaunchKernelGGL(kfn, grid, block, lds, s, L);                                                             \

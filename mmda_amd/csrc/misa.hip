@@ -66,6 +66,7 @@ struct mmda_misa {
   int side_pending = 0, use_side = 1;
   int use_cluster = 1, packed_c_valid = 0;
   int use_bf16_gemm = 1;           // bf16 mode: LSTM-sized GEMMs read bf16 operand copies (gemm_bf16.hip)
+  int gate_minor = 0;              // layout of `gates` chosen by the last forward (see mmda_lstm_desc.gate_minor)
   int ldR = 0;
   std::vector<hipEvent_t> ev;      // [step][slot][start/stop]
   int ev_steps = 0, ev_fwd = 0, ev_bwd = 0;
@@ -499,13 +500,31 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
   const bool bfg = mode == MMDA_BF16 && m->use_bf16_gemm;
   const int ldR = m->ldR;
   const float* xin[3] = {WS(m->mod[0].x), v, a};
+  // Gate-minor layout of the pre-activations / stash / gate gradients ([dir][unit][gate], 16-byte accesses in the recurrent
+  // kernels): possible when the bf16 GEMMs produce and consume them (the interleave rides on the W_ih conversion and on the
+  // GEMM epilogues) AND the resident-weights kernels will run, forward and backward.
+  int gm = 0;
+  static const int no_gm = getenv("MMDA_NO_GATE_MINOR") ? 1 : 0;     // ablation switch
+  if (bfg && (B % 8) == 0 && T > 0 && !no_gm) {
+    mmda_lstm_desc probe[3];
+    for (int i = 0; i < 3; ++i) {
+      Mod& md = m->mod[i]; Rnn& r = md.rnn[0];
+      probe[i] = mmda_lstm_desc{};
+      probe[i].H = r.H; probe[i].gates = WS(md.gates[0]); probe[i].cstash = WS(md.c[0]); probe[i].hseq = WS(md.hseq[0]);
+      probe[i].wpack[0] = WS(r.pack_f[0]); probe[i].wpack[1] = WS(r.pack_f[1]);
+      probe[i].wpack_c[0] = WS(r.pack_c[0]); probe[i].wpack_c[1] = WS(r.pack_c[1]); probe[i].utt = WS(md.utt);
+      probe[i].xchg = (m->use_cluster && md.xchg >= 0) ? (void*)WS(md.xchg) : nullptr; probe[i].gate_minor = 1;
+    }
+    gm = mmda_lstm_resident_applicable(mode, 3, probe, B, T, 0) && mmda_lstm_resident_applicable(mode, 3, probe, B, T, 1);
+  }
+  m->gate_minor = gm;
   if (bfg) {
     mmda_convert_job cj[9];
     int n = 0;
     for (int i = 0; i < 3; ++i) {
       for (int l = 0; l < 2; ++l) {
         Rnn& r = m->mod[i].rnn[l];
-        cj[n++] = mmda_convert_job{PP(r.w_ih), r.D, 8 * r.H, r.D, nullptr, WS(r.wb), r.ldD, WS(r.wbT), r.ldG};
+        cj[n++] = mmda_convert_job{PP(r.w_ih), r.D, 8 * r.H, r.D, nullptr, WS(r.wb), r.ldD, WS(r.wbT), r.ldG, gm ? r.H : 0};
       }
       Rnn& r0 = m->mod[i].rnn[0];
       if (i == 0) cj[n++] = mmda_convert_job{PP(m->embed), c.d_t, R, c.d_t, t_ids, WS(r0.xb), r0.ldD, WS(r0.xbT), ldR};
@@ -528,6 +547,7 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
         bg[i] = mmda_gemm_bf16_args{};
         bg[i].M = R; bg[i].N = 8 * r.H; bg[i].K = r.D; bg[i].A = WS(r.xb); bg[i].lda = r.ldD; bg[i].B = WS(r.wb); bg[i].ldb = r.ldD;
         bg[i].C = WS(md.gates[l]); bg[i].ldc = 8 * r.H; bg[i].bias = PP(r.b_ih); bg[i].bias2 = PP(r.b_hh);
+        bg[i].perm_n_H = gm ? r.H : 0;
       } else {
         gemm(x, mode, 0, 1, R, 8 * r.H, r.D, in, r.D, PP(r.w_ih), r.D, WS(md.gates[l]), 8 * r.H, PP(r.b_ih), PP(r.b_hh));
       }
@@ -536,6 +556,7 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
       desc[i].wpack[0] = WS(r.pack_f[0]); desc[i].wpack[1] = WS(r.pack_f[1]);
       desc[i].utt = WS(md.utt); desc[i].layer = l; desc[i].d_hseq = nullptr;
       desc[i].xchg = (m->use_cluster && md.xchg >= 0) ? (void*)WS(md.xchg) : nullptr; desc[i].epoch_base = m->epoch;
+      desc[i].gate_minor = gm;
     }
     if (bfg && !x.rc) x.rc = mmda_gemm_bf16_grouped(bg, 3, stream);
     m->epoch += (unsigned)T + 2u;
@@ -964,6 +985,7 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
       desc[i].wpack_c[0] = m->packed_c_valid ? WS(r.pack_c[0]) : nullptr; desc[i].wpack_c[1] = m->packed_c_valid ? WS(r.pack_c[1]) : nullptr;
       desc[i].utt = WS(md.d_utt); desc[i].layer = l; desc[i].d_hseq = l == 0 ? WS(md.d_hseq1) : nullptr;
       desc[i].xchg = (m->use_cluster && md.xchg >= 0) ? (void*)WS(md.xchg) : nullptr; desc[i].epoch_base = m->epoch;
+      desc[i].gate_minor = m->gate_minor;
     }
     m->epoch += (unsigned)T + 2u;
     ev_rec(m, m->ev_bwd, l == 1 ? 2 : 3, 0, stream);
@@ -1001,7 +1023,7 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
       if (bfg) {
         mmda_gemm_bf16_args g = {};
         g.M = G8; g.N = r.D; g.K = R; g.A = dgT; g.lda = m->ldR; g.B = WS(r.xbT); g.ldb = m->ldR; g.C = GG(r.w_ih); g.ldc = r.D;
-        g.accumulate = 1; g.bias_grad = GG(r.b_ih); g.bias_grad2 = GG(r.b_hh);
+        g.accumulate = 1; g.bias_grad = GG(r.b_ih); g.bias_grad2 = GG(r.b_hh); g.perm_m_H = m->gate_minor ? H : 0;
         wq.push_back(g);
       } else {
         mmda_gemm_args e = {};
@@ -1013,6 +1035,7 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
         if (bf_hh) {
           mmda_gemm_bf16_args g = {};
           g.M = 4 * H; g.N = H; g.K = (T - 1) * B; g.lda = m->ldR; g.ldb = m->ldR; g.ldc = H; g.accumulate = 1;
+          g.perm_m_H = m->gate_minor ? H : 0;
           g.A = dgT + B; g.B = hT; g.C = GG(r.w_hh[0]);
           wq.push_back(g);
           g.A = dgT + (int64_t)4 * H * m->ldR; g.B = hT + (int64_t)H * m->ldR + B; g.C = GG(r.w_hh[1]);

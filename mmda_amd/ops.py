@@ -258,12 +258,22 @@ def lstm_xchg(H, B, device):
     return torch.zeros(n, dtype=torch.uint8, device=device) if n > 0 else None
 
 
-def lstm_bidir_fwd(pre, whh_f, whh_r, lengths, *, mode="fp32", layer=0, utt=None, resident=False):
-    """pre: (T,B,2,4H) = x W_ih^T + b_ih + b_hh per direction.  Returns dict(hseq, gates, cstash, utt, packs)."""
+def _to_gate_minor(x, H):
+    """(..., 4H) [gate][unit] -> [unit][gate] (the resident-weights kernels' 16-byte layout)"""
+    return x.reshape(*x.shape[:-1], 4, H).transpose(-1, -2).reshape(*x.shape[:-1], 4 * H).contiguous()
+
+
+def _from_gate_minor(x, H):
+    return x.reshape(*x.shape[:-1], H, 4).transpose(-1, -2).reshape(*x.shape[:-1], 4 * H).contiguous()
+
+
+def lstm_bidir_fwd(pre, whh_f, whh_r, lengths, *, mode="fp32", layer=0, utt=None, resident=False, gate_minor=False):
+    """pre: (T,B,2,4H) = x W_ih^T + b_ih + b_hh per direction.  Returns dict(hseq, gates, cstash, utt, packs).
+    gate_minor (resident only): the kernels see `gates` as [dir][unit][gate]; inputs/outputs here stay in torch's order."""
     lib = load()
     T, B, _, G4 = pre.shape
     H = G4 // 4
-    gates = pre.clone().contiguous()
+    gates = _to_gate_minor(pre, H) if gate_minor else pre.clone().contiguous()
     cst = torch.zeros(T, B, 2, H, device=pre.device)
     hseq = torch.full((T, B, 2 * H), float("nan"), device=pre.device)
     if utt is None:
@@ -274,8 +284,10 @@ def lstm_bidir_fwd(pre, whh_f, whh_r, lengths, *, mode="fp32", layer=0, utt=None
     xchg = lstm_xchg(H, B, pre.device) if resident else None
     pcs = (lstm_pack_cluster(whh_f), lstm_pack_cluster(whh_r)) if (resident and MODE[mode] == BF16) else (None, None)
     d = (_lib.LstmDesc * 1)(_desc(H, gates, cst, hseq, pf0, pf1, utt, layer, None, xchg, 0))
+    d[0].gate_minor = int(gate_minor)
     check(lib.mmda_lstm_fwd(MODE[mode], 1, d, B, T, ptr(len_dev), stream_ptr()), "lstm_fwd")
-    return dict(hseq=hseq, gates=gates, cstash=cst, utt=utt, packs=(pf0, pb0, pf1, pb1), len_dev=len_dev, xchg=xchg, T=T, pcs=pcs)
+    return dict(hseq=hseq, gates=gates, cstash=cst, utt=utt, packs=(pf0, pb0, pf1, pb1), len_dev=len_dev, xchg=xchg, T=T, pcs=pcs,
+                gate_minor=bool(gate_minor), H=H)
 
 
 def lstm_bidir_bwd(fw, d_utt, d_hseq, *, mode="fp32", layer=0):
@@ -287,8 +299,9 @@ def lstm_bidir_bwd(fw, d_utt, d_hseq, *, mode="fp32", layer=0):
     pf0, pb0, pf1, pb1 = fw["packs"]
     pc0, pc1 = fw.get("pcs", (None, None))
     d = (_lib.LstmDesc * 1)(_desc(H, gates, fw["cstash"], fw["hseq"], pb0, pb1, d_utt, layer, d_hseq, fw.get("xchg"), T + 2, pc0, pc1))
+    d[0].gate_minor = int(fw.get("gate_minor", False))
     check(lib.mmda_lstm_bwd(MODE[mode], 1, d, B, T, ptr(fw["len_dev"]), stream_ptr()), "lstm_bwd")
-    return gates
+    return _from_gate_minor(gates, H) if fw.get("gate_minor") else gates
 
 
 def lstm_aborted(fw):

@@ -109,6 +109,49 @@ def test_gemm_bf16_grouped_backward_forms_bias_grad_accumulate():
     assert relerr(outs[2], dGb[shift:].t() @ Xb[:R - shift]) < TOL["fp32"]
 
 
+def test_gemm_bf16_gate_interleave():
+    """The gate-minor layout end to end at GEMM level: W_ih rows interleaved by the conversion, bias read through the
+    interleave (forward); dW rows and bias gradients written back through it (backward)."""
+    from mmda_amd import ops, _lib
+    import ctypes as C
+    torch.manual_seed(12)
+    R, H, D = 96, 35, 40
+    X = torch.randn(R, D); W = torch.randn(8 * H, D) / 6; b = torch.randn(8 * H)
+    perm = torch.tensor([(j // (4 * H)) * 4 * H + (j % 4) * H + (j % (4 * H)) // 4 for j in range(8 * H)])
+    lib = _lib.load()
+    d = dev()
+    Xd, Wd = X.to(d), W.to(d)
+    ldD = (D + 7) // 8 * 8; ldR = (R + 7) // 8 * 8
+    Xb = torch.zeros(R, ldD, device=d, dtype=torch.bfloat16); XbT = torch.zeros(D, ldR, device=d, dtype=torch.bfloat16)
+    Wb = torch.zeros(8 * H, ldD, device=d, dtype=torch.bfloat16)
+    jobs = (_lib.ConvertJob * 2)()
+    jobs[0].src = Xd.data_ptr(); jobs[0].ld = D; jobs[0].rows = R; jobs[0].cols = D; jobs[0].plain = Xb.data_ptr(); jobs[0].ldp = ldD
+    jobs[0].transposed = XbT.data_ptr(); jobs[0].ldt = ldR
+    jobs[1].src = Wd.data_ptr(); jobs[1].ld = D; jobs[1].rows = 8 * H; jobs[1].cols = D; jobs[1].plain = Wb.data_ptr(); jobs[1].ldp = ldD
+    jobs[1].row_perm_H = H
+    _lib.check(lib.mmda_convert_bf16(jobs, 2, _lib.stream_ptr()), "convert")
+    assert torch.equal(Wb.cpu()[:, :D], W[perm].bfloat16())
+    # forward: gates (interleaved columns) = X W'^T + b[orig]
+    gates = torch.zeros(R, 8 * H, device=d)
+    g = (_lib.GemmBf16Args * 1)()
+    g[0].M = R; g[0].N = 8 * H; g[0].K = D; g[0].A = Xb.data_ptr(); g[0].lda = ldD; g[0].B = Wb.data_ptr(); g[0].ldb = ldD
+    g[0].C = gates.data_ptr(); g[0].ldc = 8 * H; bd = b.to(d); g[0].bias = bd.data_ptr(); g[0].perm_n_H = H
+    _lib.check(lib.mmda_gemm_bf16_grouped(g, 1, _lib.stream_ptr()), "gemm fwd")
+    ref = X.bfloat16().float() @ W.bfloat16().float().t() + b
+    assert relerr(gates, ref[:, perm]) < TOL["fp32"]
+    # backward: dW[orig(m)] += dG'^T X, bias gradient likewise
+    dG = torch.randn(R, 8 * H)                       # in interleaved column order
+    (_, dGT), = ops.convert_bf16([(dG.to(d), None, False, True)])
+    dW = torch.zeros(8 * H, D, device=d); db = torch.zeros(8 * H, device=d)
+    g[0] = _lib.GemmBf16Args()
+    g[0].M = 8 * H; g[0].N = D; g[0].K = R; g[0].A = dGT.data_ptr(); g[0].lda = dGT.shape[1]; g[0].B = XbT.data_ptr(); g[0].ldb = ldR
+    g[0].C = dW.data_ptr(); g[0].ldc = D; g[0].accumulate = 1; g[0].bias_grad = db.data_ptr(); g[0].perm_m_H = H
+    _lib.check(lib.mmda_gemm_bf16_grouped(g, 1, _lib.stream_ptr()), "gemm bwd")
+    ref_dW = torch.zeros(8 * H, D); ref_dW[perm] = dG.bfloat16().float().t() @ X.bfloat16().float()
+    ref_db = torch.zeros(8 * H); ref_db[perm] = dG.bfloat16().float().sum(0)
+    assert relerr(dW, ref_dW) < TOL["fp32"] and relerr(db, ref_db) < TOL["fp32"]
+
+
 def test_gemm_bf16_rejects_misaligned_operands():
     from mmda_amd import ops, _lib
     A = torch.zeros(16, 24, device=dev(), dtype=torch.bfloat16); B = torch.zeros(16, 24, device=dev(), dtype=torch.bfloat16)
@@ -376,14 +419,15 @@ def _lstm_case(T, B, H, D, ragged, seed):
     return rnn, x, lengths
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16", "bf16-resident"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16", "bf16-resident", "bf16-resident-gateminor"])
 @pytest.mark.parametrize("T,B,H,ragged", [(9, 5, 6, True), (12, 16, 35, True), (7, 20, 74, True), (10, 32, 300, False),
                                           (6, 3, 300, True), (5, 17, 128, True), (8, 70, 300, True)])
 def test_lstm_fwd_bwd_vs_nn_lstm(mode, T, B, H, ragged):
     """Three implementations of the recurrence behind one entry point: exact f32-MFMA streaming kernel, bf16 streaming kernel,
     and the bf16 kernel with W_hh resident in LDS across a cluster of workgroups (per-step h / dG all-gather)."""
     from mmda_amd import ops
-    resident = mode.endswith("resident")
+    resident = "resident" in mode
+    gate_minor = mode.endswith("gateminor")      # `gates` as [dir][unit][gate]: 16-byte stash accesses in the resident kernels
     mode = mode.split("-")[0]
     D = H if H < 100 else 40
     rnn, x, lengths = _lstm_case(T, B, H, D, ragged, 7)
@@ -399,7 +443,7 @@ def test_lstm_fwd_bwd_vs_nn_lstm(mode, T, B, H, ragged):
     bhh = torch.cat((rnn.bias_hh_l0, rnn.bias_hh_l0_reverse), 0).detach()
     pre = ops.gemm(x.detach().reshape(T * B, D).to(d), wih.to(d), mode=mode, bias=bih.to(d), bias2=bhh.to(d)).view(T, B, 2, 4 * H)
     fw = ops.lstm_bidir_fwd(pre, rnn.weight_hh_l0.detach().to(d), rnn.weight_hh_l0_reverse.detach().to(d), lengths, mode=mode, layer=1,
-                            resident=resident)
+                            resident=resident, gate_minor=gate_minor)
     assert not ops.lstm_aborted(fw), "cluster exchange timed out in forward"
     tol = TOL[mode]
     assert relerr(fw["hseq"], pad) < tol
