@@ -529,7 +529,7 @@ def _side(B, D, seed):
     return [torch.sigmoid(torch.randn(B, D)).requires_grad_(True) for _ in range(6)]
 
 
-@pytest.mark.parametrize("B,D", [(32, 128), (5, 16), (70, 128)])
+@pytest.mark.parametrize("B,D", [(32, 128), (5, 16), (70, 128), (41, 100), (64, 128)])
 def test_diff_cmd_recon_losses_and_grads(B, D):
     from types import SimpleNamespace
     from mmda_amd.utils import functions as F
