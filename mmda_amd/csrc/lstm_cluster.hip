@@ -42,6 +42,7 @@ struct CDesc {
   const float* d_hseq;
   unsigned char* xchg;
   int wg_begin;
+  int NCw;                           // wave-autonomous forward: workgroups per cluster = ceil(2 * nHT / waves per block)
 };
 struct CLaunch {
   CDesc d[MAXD];
@@ -51,12 +52,16 @@ struct CLaunch {
   unsigned long long* dbg;           // diagnostics only: per-workgroup phase cycle sums (NULL in production)
   int gate_minor;                    // `gates` columns are [dir][unit][gate]: 16-byte accesses (see mmda_lstm_desc)
   int xcd_local;                     // EXPERIMENT: publish with plain stores (valid only when a cluster shares one XCD)
+  int wpb;                           // wave-autonomous forward: waves per block (1, 2 or 4)
   short blk2role[256];               // blockIdx -> linear role (-1: no role, exit at once); roles of one cluster share blockIdx % 8
 };
 
-// xchg layout per descriptor: [0,64) abort word | flags: (dir, group, wg) x 64 B | X: (dir, group, parity) x GROUP x XW bf16
+// xchg layout per descriptor: [0,64) abort word | flags: (dir, group, wg) x FLAG_STRIDE B | X: (dir, group, parity) x slot
+// Flags: four 64-byte lines per workgroup.  The barrier-synchronised kernels signal on line 0; the wave-autonomous forward
+// kernel signals per wave on line (m-tile * 2 + local hidden tile).
+constexpr size_t FLAG_STRIDE = 256;
 __host__ __device__ inline size_t xchg_flags_off() { return 64; }
-__host__ __device__ inline size_t xchg_x_off(int ngroups_total, int NC) { return 64 + (size_t)2 * ngroups_total * NC * 64; }
+__host__ __device__ inline size_t xchg_x_off(int ngroups_total, int NC) { return 64 + (size_t)2 * ngroups_total * NC * FLAG_STRIDE; }
 // one exchange slot = one (direction, group, parity): forward uses GROUP x 4Hp bf16 of it, backward NC x GROUP x Hp
 __host__ __device__ inline size_t xchg_slot(int NC, int Hp) { return (size_t)(NC > 4 ? NC : 4) * GROUP * Hp * 2; }
 __host__ __device__ inline size_t xchg_bytes(int ngroups_total, int NC, int Hp) {
@@ -107,7 +112,7 @@ __device__ __forceinline__ bool wait_cluster(unsigned char* flags, unsigned char
     bool ok = true;
     if (lane < NC && lane != me) {
       unsigned spins = 0;
-      while ((int)(ld_flag(flags + (size_t)lane * 64) - epoch) < 0) {
+      while ((int)(ld_flag(flags + (size_t)lane * FLAG_STRIDE) - epoch) < 0) {
         ++spins;
         if (spins > SPIN_LIMIT || ((spins & 255u) == 0 && ld_flag(abort_w) != 0)) { ok = false; break; }
         __builtin_amdgcn_s_sleep(1);
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_cluster_kernel(CLaunch L) {
   volatile int& lds_ok = *reinterpret_cast<volatile int*>(smem + (size_t)TPW * 4 * KS * 1024 + (size_t)2 * GROUP * ld * 2);
 
   unsigned char* abort_w = D.xchg;
-  unsigned char* flags = D.xchg + xchg_flags_off() + ((size_t)(dir * ngt + wh.grp) * NC) * 64;
+  unsigned char* flags = D.xchg + xchg_flags_off() + ((size_t)(dir * ngt + wh.grp) * NC) * FLAG_STRIDE;
   unsigned char* Xb = D.xchg + xchg_x_off(ngt, NC) + ((size_t)(dir * ngt + wh.grp) * 2) * xchg_slot(NC, Hp);
 
   // resident weights: the forward packing is [(ht*4+g)*KS + ks][lane] x 16 B; this workgroup owns tiles me*TPW..+TPW
@@ -343,7 +348,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_cluster_kernel(CLaunch L) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
       STAMP(2);
       __syncthreads();
-      if (tid == 0) { if (L.xcd_local) st_flag_plain(flags + (size_t)me * 64, epoch); else st_flag(flags + (size_t)me * 64, epoch); }
+      if (tid == 0) { if (L.xcd_local) st_flag_plain(flags + (size_t)me * FLAG_STRIDE, epoch); else st_flag(flags + (size_t)me * FLAG_STRIDE, epoch); }
       STAMP(3);
       load_pre(P, step + 2);                             // lands while the cluster is being polled
       ok = wait_cluster(flags, abort_w, NC, me, epoch, &lds_ok);
@@ -378,6 +383,230 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_cluster_kernel(CLaunch L) {
     for (int i = 0; i < 8; ++i) L.dbg[(size_t)role * 8 + i] = ph[i];
     if (L.xcd_local < 0) L.dbg[(size_t)role * 8 + 7] = ((unsigned long long)blockIdx.x << 32) | (unsigned)__builtin_amdgcn_s_getreg(6164);   // XCC_ID
   }
+#undef STAMP
+  // final hidden state straight into the utterance layout [h1_fwd, h2_fwd, h1_bwd, h2_bwd] (models.py:203)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int b = wh.grp * GROUP + mt * 16 + fq * 4 + r;
+    if (inb[r]) D.utt[(int64_t)b * 4 * H + (dir * 2 + D.layer) * H + col] = h_reg[r];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ forward, wave-autonomous form
+// Same cluster, same math, no workgroup barrier and no LDS staging.  Every wave owns one (16-sample m-tile, 16-unit hidden
+// tile) for the whole sequence and runs on its own:
+//   poll    lanes 0..nHT-1 each read the flag of one hidden tile of THIS m-tile (one load instruction covers the cluster)
+//   gather  the exchange image is TILE-MAJOR: [hidden tile][m-tile][16 rows][16 units] bf16, 512 contiguous bytes per tile.  The
+//           A operand of k-step ks is h[m-tile rows][32ks .. 32ks+31] = tiles 2ks and 2ks+1; in fragment order a lane needs the
+//           16 bytes at (row = lane & 15, units 8 (lane >> 4) ..+7): ONE 16-byte sc1 load per lane and k-step straight into the
+//           MFMA operand registers -- the gathered h never touches LDS; tiles past the last one read as zero (OOB offset)
+//   MFMA    W_hh fragments resident in registers (wreg), counted waits let the MFMAs start as fragments land
+//   cell    lane-local, as before
+//   publish the wave's 16 x 16 bf16 tile goes through 512 B of wave-private LDS (fragment order -> row order) and out as 32
+//           16-byte write-through stores covering whole 64-byte sectors; the wave drains them and raises ITS OWN flag
+//           (line m-tile*2 + local tile of its workgroup's flag block)
+template <int KSM, bool GM>
+__global__ __launch_bounds__(256, 1) void lstm_fwd_wave_kernel(CLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __builtin_amdgcn_s_setprio(3);
+  const int role = L.blk2role[blockIdx.x];
+  if (role < 0) return;
+  // role -> (descriptor, direction, batch group, first wave-role of this block); wave-role rho = (hidden tile, m-tile)
+  Where wh;
+  wh.di = 0;
+#pragma unroll
+  for (int i = 1; i < MAXD; ++i)
+    if (i < L.n && role >= L.d[i].wg_begin) wh.di = i;
+  const CDesc& D = L.d[wh.di];
+  {
+    const int local = role - D.wg_begin;
+    wh.dir = local / (L.ng * D.NCw);
+    const int rem = local % (L.ng * D.NCw);
+    wh.grp = L.g0 + rem / D.NCw;
+    wh.me = rem % D.NCw;
+  }
+  const int H = D.H, Hp = D.Hp, KS = D.KS, nHT = D.nHT, NC = D.NC;
+  const int B = L.B, T = L.T, dir = wh.dir;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int rho = wh.me * L.wpb + wave;
+  const int mt = rho & 1, ht = rho >> 1;
+  if (ht >= nHT) return;                                // no tile: nothing to compute, nobody waits for this wave
+  const int col = ht * 16 + fr;
+  const int ngt = (B + GROUP - 1) / GROUP;
+  const unsigned G4 = 4u * H;
+  constexpr bool gm = GM;
+  unsigned short* Tr = reinterpret_cast<unsigned short*>(smem) + wave * 256;      // 16 x 16 bf16, wave-private
+
+  unsigned char* abort_w = D.xchg;
+  unsigned char* flags = D.xchg + xchg_flags_off() + ((size_t)(dir * ngt + wh.grp) * NC) * FLAG_STRIDE;
+  unsigned char* Xb = D.xchg + xchg_x_off(ngt, NC) + ((size_t)(dir * ngt + wh.grp) * 2) * xchg_slot(NC, Hp);
+  // one 64-byte flag line per wave-role (the block of NC * FLAG_STRIDE bytes holds >= 2 * nHT lines)
+  unsigned char* my_flag = flags + (size_t)rho * 64;
+  // lane tau < nHT polls the flag of hidden tile tau for this m-tile
+  const int tau = lane < nHT ? lane : 0;
+  const unsigned char* poll_flag = flags + (size_t)(tau * 2 + mt) * 64;
+
+  bf16x8 wreg[4][KSM];
+  {
+    const bf16x8* src = reinterpret_cast<const bf16x8*>(D.wpack[dir]);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int k2 = 0; k2 < KSM; ++k2)
+        wreg[g][k2] = k2 < KS ? src[((size_t)(ht * 4 + g) * KS + k2) * 64 + lane] : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  }
+  const __amdgpu_buffer_rsrc_t rg = make_rsrc(D.gates, (unsigned)T * B * 2u * G4 * 4u);
+  const __amdgpu_buffer_rsrc_t rc = make_rsrc(D.cstash, (unsigned)T * B * 2u * H * 4u);
+  const __amdgpu_buffer_rsrc_t rh = make_rsrc(D.hseq, (unsigned)T * B * 2u * H * 4u);
+  const unsigned sg = (unsigned)B * 2u * G4 * 4u, sc = (unsigned)B * 2u * H * 4u;
+  unsigned og[4], oc[4], oh[4];
+  int len_r[4];
+  bool inb[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int b = wh.grp * GROUP + mt * 16 + fq * 4 + r;
+    inb[r] = col < H && b < B;
+    const int lv = L.lengths[min(b, B - 1)];
+    len_r[r] = inb[r] ? lv : 0;
+    og[r] = (((unsigned)b * 2u + dir) * G4 + (gm ? col * 4 : col)) * 4u;
+    oc[r] = (((unsigned)b * 2u + dir) * H + col) * 4u;
+    oh[r] = ((unsigned)b * 2u * H + dir * H + col) * 4u;
+  }
+  float c_reg[4] = {0.f, 0.f, 0.f, 0.f}, h_reg[4] = {0.f, 0.f, 0.f, 0.f};
+  float pre[2][4][4];
+  auto load_pre = [&](float (&dst)[4][4], int step) {
+    const int t = dir ? T - 1 - step : step;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool act = step < T && t < len_r[r];
+      const unsigned o = og[r] + (unsigned)t * sg;
+      if (gm) {
+        const f32x4 v = ldf4(rg, act ? o : OOB);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dst[g][r] = v[g];
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dst[g][r] = ldf(rg, act ? o + g * H * 4u : OOB);
+      }
+    }
+  };
+  load_pre(pre[0], 0);
+  load_pre(pre[1], 1);
+  // ONE descriptor over both parity images (selecting between two descriptors per step makes hipcc keep them in VGPRs and
+  // wrap every access in a readfirstlane loop); the parity picks a byte offset instead
+  const unsigned slot_b = (unsigned)xchg_slot(NC, Hp);
+  const unsigned img_b = (unsigned)nHT * 2u * 512u;
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(Xb, slot_b + img_b);
+  // fragment of k-step ks: tile 2ks + (fq >> 1), row fr, units 8 (fq & 1) ..+7
+  unsigned frag_off[KSM];
+#pragma unroll
+  for (int k2 = 0; k2 < KSM; ++k2) {
+    const int tl = 2 * k2 + (fq >> 1);
+    frag_off[k2] = (k2 < KS && tl < nHT) ? (unsigned)((((tl * 2 + mt) * 256) + fr * 16 + 8 * (fq & 1)) * 2) : OOB;
+  }
+  const unsigned pub_off = lane < 32 ? (unsigned)((((ht * 2 + mt) * 256) + lane * 8) * 2) : OOB;
+
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last = 0;
+#define STAMP(i) do { if (L.dbg && tid == 0) { unsigned long long now_ = __builtin_readcyclecounter(); ph[i] += now_ - last; last = now_; } } while (0)
+  if (L.dbg && tid == 0) last = __builtin_readcyclecounter();
+
+  bool alive = true;
+  float sv[4][6];                                       // stash of the previous step, flushed behind the next step's fragment loads
+  // off the chain: the stash of step `ps` for the backward pass and the pre-activations of step ps + 2 into the buffer that
+  // step used.  Issued right after a step's fragment loads (in front of the poll they would delay every wave's flag reads).
+  auto flush = [&](int ps, float (&Pp)[4][4]) {
+    const int t = dir ? T - 1 - ps : ps;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool act = t < len_r[r];
+      const unsigned o = act ? og[r] + (unsigned)t * sg : OOB;
+      if (gm) {
+        stf4(rg, o, f32x4{sv[r][0], sv[r][1], sv[r][2], sv[r][3]});
+      } else {
+        stf(rg, o, sv[r][0]); stf(rg, act ? o + H * 4u : OOB, sv[r][1]); stf(rg, act ? o + 2u * H * 4u : OOB, sv[r][2]);
+        stf(rg, act ? o + 3u * H * 4u : OOB, sv[r][3]);
+      }
+      stf(rc, act ? oc[r] + (unsigned)t * sc : OOB, sv[r][4]);
+      stf(rh, inb[r] ? oh[r] + (unsigned)t * sc : OOB, sv[r][5]);     // zero at padded positions (pad_packed_sequence)
+    }
+    load_pre(Pp, ps + 2);
+  };
+  // P: pre-activations of this step; Pp: the buffer the previous step used (refilled for step + 1 by flush)
+  auto do_step = [&](int step, float (&P)[4][4], float (&Pp)[4][4]) {
+    const int t = dir ? T - 1 - step : step;
+    const unsigned epoch = L.epoch_base + (unsigned)step + 1u;
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (step > 0) {
+      // every hidden tile of this m-tile must have published the previous step
+      const unsigned need = epoch - 1u;
+      unsigned spins = 0;
+      for (;;) {
+        const unsigned f = ld_flag(poll_flag);
+        const bool ok = lane >= nHT || (int)(f - need) >= 0;
+        if (__all(ok)) break;
+        ++spins;
+        if (spins > SPIN_LIMIT || ((spins & 255u) == 0 && ld_flag(abort_w) != 0)) { alive = false; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (!alive) { if (lane == 0) st_flag(abort_w, 1u); return; }
+      STAMP(0);
+      const unsigned par = (need & 1u) * slot_b;
+      bf16x8 af[KSM];
+#pragma unroll
+      for (int k2 = 0; k2 < KSM; ++k2)
+        af[k2] = __builtin_bit_cast(bf16x8, ld16_sc1(xr, frag_off[k2] == OOB ? OOB : par + frag_off[k2]));
+      flush(step - 1, Pp);
+      STAMP(1);
+#pragma unroll
+      for (int k2 = 0; k2 < KSM; ++k2) {
+        if (k2 < KS) {                                   // workgroup-uniform
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k2], wreg[g][k2], acc[g], 0, 0, 0);
+        }
+      }
+      if (L.dbg) { asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0])); STAMP(2); }
+    }
+    // lane-local cell update, branch-free (inactive lanes compute on zeros and are masked by the selects / OOB stores)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool act = t < len_r[r];
+      const float gi = sigmoid_fast(acc[0][r] + P[0][r]);
+      const float gf = sigmoid_fast(acc[1][r] + P[1][r]);
+      const float gg = tanh_fast(acc[2][r] + P[2][r]);
+      const float go = sigmoid_fast(acc[3][r] + P[3][r]);
+      const float cn = gf * c_reg[r] + gi * gg;
+      const float hn = go * tanh_fast(cn);
+      c_reg[r] = act ? cn : c_reg[r];
+      h_reg[r] = act ? hn : h_reg[r];
+      Tr[(fq * 4 + r) * 16 + fr] = f2bf(h_reg[r]);
+      sv[r][0] = gi; sv[r][1] = gf; sv[r][2] = gg; sv[r][3] = go; sv[r][4] = cn; sv[r][5] = act ? hn : 0.f;
+    }
+    if (step + 1 < T) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the tile is complete in the wave-private LDS block
+      STAMP(3);
+      const unsigned par = (epoch & 1u) * slot_b;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(&Tr[(lane & 31) * 8]);
+      st16_sc1(xr, pub_off == OOB ? OOB : par + pub_off, v);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's write-through stores have landed
+      STAMP(4);
+      if (lane == 0) st_flag(my_flag, epoch);
+    }
+  };
+  {
+    // pre[0] holds step 0, pre[1] step 1; afterwards flush() refills the buffer of step s - 1 with step s + 1
+    int step = 0;
+    for (; step + 1 < T && alive; step += 2) {
+      do_step(step, pre[0], pre[1]);
+      if (alive) do_step(step + 1, pre[1], pre[0]);
+    }
+    if (step < T && alive) { do_step(step, pre[0], pre[1]); ++step; }
+    if (alive && T > 0) flush(T - 1, (T - 1) & 1 ? pre[1] : pre[0]);
+  }
+  if (L.dbg && tid == 0)
+    for (int i = 0; i < 8; ++i) L.dbg[(size_t)role * 8 + i] = ph[i];
 #undef STAMP
   // final hidden state straight into the utterance layout [h1_fwd, h2_fwd, h1_bwd, h2_bwd] (models.py:203)
 #pragma unroll
@@ -427,7 +656,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(CLaunch L) {
   volatile int& lds_ok = *reinterpret_cast<volatile int*>(smem + off);
 
   unsigned char* abort_w = D.xchg;
-  unsigned char* flags = D.xchg + xchg_flags_off() + ((size_t)(dir * ngt + wh.grp) * NC) * 64;
+  unsigned char* flags = D.xchg + xchg_flags_off() + ((size_t)(dir * ngt + wh.grp) * NC) * FLAG_STRIDE;
   unsigned char* Xb = D.xchg + xchg_x_off(ngt, NC) + ((size_t)(dir * ngt + wh.grp) * 2) * xchg_slot(NC, Hp);
   {
     // cluster-backward packing: [(ht*nHT + nt)*2 + ks2][lane] x 16 B; the tiles of this workgroup are contiguous blocks
@@ -624,7 +853,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(CLaunch L) {
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid == 0) { if (L.xcd_local) st_flag_plain(flags + (size_t)me * 64, epoch); else st_flag(flags + (size_t)me * 64, epoch); }
+      if (tid == 0) { if (L.xcd_local) st_flag_plain(flags + (size_t)me * FLAG_STRIDE, epoch); else st_flag(flags + (size_t)me * FLAG_STRIDE, epoch); }
       store_dg();                                        // off the chain: the drain above only waited for the publish stores
       load_stash(S, step + 2);                           // lands while the cluster is being polled
       ok = wait_cluster(flags, abort_w, NC, me, epoch, &lds_ok);
@@ -742,8 +971,27 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
   size_t lds = 0;
   if (!cluster_applicable(n, descs, B, T, bwd, plans, &lds)) return MMDA_OK;
   const int ngt = ceil_div(B, GROUP);
+  // forward: the wave-autonomous kernel when every descriptor's W_hh k-steps fit its register-resident form.  Its blocks hold
+  // 1, 2 or 4 waves (one (hidden tile, m-tile) each): the fewest waves per block that still fit one launch, because the waves
+  // of a block share the CU's address unit and the per-step memory instructions are what they queue on.
+  static const int no_wave = getenv("MMDA_LSTM_BARRIER_FWD") ? 1 : 0;        // ablation: the barrier-synchronised forward kernel
+  static const int force_wpb = getenv("MMDA_LSTM_WPB") ? atoi(getenv("MMDA_LSTM_WPB")) : 0;
+  bool fwd_wave = !bwd && !no_wave;
+  for (int i = 0; i < n; ++i) fwd_wave = fwd_wave && round_up(descs[i].H, 32) / 32 <= 10;
+  int wpb = 4;
+  int members[MAXD];                       // workgroups per cluster
+  auto count_wgs = [&](int w) { int t = 0; for (int i = 0; i < n; ++i) t += 2 * ceil_div(2 * (round_up(descs[i].H, 16) / 16), w); return t; };
+  if (fwd_wave) {
+    wpb = 1;
+    while (wpb < 4 && count_wgs(wpb) > MAX_WG_PER_LAUNCH) wpb *= 2;
+    if (force_wpb == 1 || force_wpb == 2 || force_wpb == 4) wpb = force_wpb;
+    if (count_wgs(wpb) > MAX_WG_PER_LAUNCH) fwd_wave = false;
+  }
   int wg_per_group = 0;
-  for (int i = 0; i < n; ++i) wg_per_group += 2 * plans[i].NC;
+  for (int i = 0; i < n; ++i) {
+    members[i] = fwd_wave ? ceil_div(2 * (round_up(descs[i].H, 16) / 16), wpb) : plans[i].NC;
+    wg_per_group += 2 * members[i];
+  }
   const int groups_per_launch = MAX_WG_PER_LAUNCH / wg_per_group;
   hipStream_t s = (hipStream_t)stream;
   for (int g0 = 0; g0 < ngt; g0 += groups_per_launch) {
@@ -751,18 +999,19 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
     L.n = n; L.B = B; L.T = T; L.g0 = g0; L.ng = (ngt - g0) < groups_per_launch ? (ngt - g0) : groups_per_launch;
     L.lengths = lengths; L.epoch_base = descs[0].epoch_base; L.dbg = bwd ? nullptr : g_dbg;
     L.gate_minor = descs[0].gate_minor ? 1 : 0;
+    L.wpb = wpb;
     int wg = 0;
     for (int i = 0; i < MAXD; ++i) {
       const mmda_lstm_desc& d = descs[i < n ? i : 0];
       const Plan& p = plans[i < n ? i : 0];
       CDesc& c = L.d[i];
       c.H = d.H; c.Hp = round_up(d.H, 16); c.Kp = round_up(d.H, 32); c.KS = c.Kp / 32; c.KSB = 4 * c.Hp / 32; c.nHT = c.Hp / 16;
-      c.TPW = p.TPW; c.NC = p.NC;
+      c.TPW = p.TPW; c.NC = p.NC; c.NCw = members[i < n ? i : 0];
       c.gates = d.gates; c.cstash = d.cstash; c.hseq = d.hseq; c.wpack[0] = d.wpack[0]; c.wpack[1] = d.wpack[1];
       c.wpack_c[0] = d.wpack_c[0]; c.wpack_c[1] = d.wpack_c[1];
       c.utt = d.utt; c.layer = d.layer; c.d_hseq = d.d_hseq; c.xchg = (unsigned char*)d.xchg;
       c.wg_begin = wg;
-      if (i < n) wg += 2 * L.ng * p.NC;
+      if (i < n) wg += 2 * L.ng * members[i];
     }
     // Placement (speed only): blocks b and b + 8 are dealt to the same XCD, so the members of one cluster get block ids that
     // are equal mod 8; clusters go to the XCD with the fewest members so far.
@@ -773,9 +1022,9 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
     {
       int used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       bool fits = use_place && wg <= 256;
-      std::vector<std::pair<int, int>> clusters;     // (first role, NC)
+      std::vector<std::pair<int, int>> clusters;     // (first role, members)
       for (int i = 0; i < n; ++i)
-        for (int c2 = 0; c2 < 2 * L.ng; ++c2) clusters.push_back({L.d[i].wg_begin + c2 * plans[i].NC, plans[i].NC});
+        for (int c2 = 0; c2 < 2 * L.ng; ++c2) clusters.push_back({L.d[i].wg_begin + c2 * members[i], members[i]});
       std::stable_sort(clusters.begin(), clusters.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.second > b.second; });
       short map[256];
       for (int b = 0; b < 256; ++b) map[b] = -1;
@@ -793,15 +1042,17 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
     }
     bool bwd_regs = true;                    // every descriptor's n-tiles fit the register-resident form (<= 10 per wave)
     for (int i = 0; i < n; ++i) bwd_regs = bwd_regs && L.d[i].nHT <= 20;
-    dim3 grid(grid_blocks), block(256);
+    const size_t lds_launch = fwd_wave ? (size_t)4 * 512 : lds;
+    dim3 grid(grid_blocks), block(fwd_wave ? 64 * wpb : 256);
 #define LAUNCH_C()                                                                                               \
   do {                                                                                                           \
     auto kfn = bwd ? (bwd_regs ? (L.gate_minor ? lstm_bwd_cluster_kernel<10, true> : lstm_bwd_cluster_kernel<10, false>)                \
                               : (L.gate_minor ? lstm_bwd_cluster_kernel<0, true> : lstm_bwd_cluster_kernel<0, false>))                  \
-                   : (L.gate_minor ? lstm_fwd_cluster_kernel<10, true> : lstm_fwd_cluster_kernel<10, false>);                            \
+                   : fwd_wave ? (L.gate_minor ? lstm_fwd_wave_kernel<10, true> : lstm_fwd_wave_kernel<10, false>)                        \
+                              : (L.gate_minor ? lstm_fwd_cluster_kernel<10, true> : lstm_fwd_cluster_kernel<10, false>);                 \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                            (int)lds) != hipSuccess) { (void)hipGetLastError(); }                                \
-    hipLaunchKernelGGL(kfn, grid, block, lds, s, L);                                                             \
+                            (int)lds_launch) != hipSuccess) { (void)hipGetLastError(); }                         \
+    hipLaunchKernelGGL(kfn, grid, block, lds_launch, s, L);                                                      \
   } while (0)
     LAUNCH_C();
 #undef LAUNCH_C

@@ -12,6 +12,7 @@ pre = torch.randn(T, B, 2, 4 * H, device=d)
 wf = (torch.rand(4 * H, H, device=d) - 0.5) * 0.1; wr = (torch.rand(4 * H, H, device=d) - 0.5) * 0.1
 lengths = torch.full((B,), T)
 dbg = torch.zeros(64 * 8, dtype=torch.int64, device=d)
+wave_names = ["poll", "issue fragment loads + flush previous stash", "fragment wait + MFMA", "cell update + LDS tile", "publish + drain", "-", "-", "-"]
 names = ["cell update+stash stores+lds write", "barrier1", "publish+drain", "barrier2+flag", "poll+barrier3", "gather issue+side traffic", "gather wait+ldswrite", "h fragments from LDS + MFMA"]
 for it in range(3):
     lib.mmda_debug_set_lstm_stamps(dbg.data_ptr())
@@ -26,5 +27,5 @@ raw = dbg.view(64, 8)[:20].cpu()
 v = raw.double()
 tot = v.sum(1)
 print("per-WG total cycles/step:", (tot / T).tolist())
-for i, n in enumerate(names):
+for i, n in enumerate(wave_names if os.environ.get("MMDA_LSTM_WAVE_FWD") else names):
     print(f"{n:28s} mean {float(v[:, i].mean())/T:8.0f} cyc/step  min {float(v[:, i].min())/T:8.0f} max {float(v[:, i].max())/T:8.0f}")
