@@ -63,7 +63,11 @@ constexpr size_t FLAG_STRIDE = 256;
 __host__ __device__ inline size_t xchg_flags_off() { return 64; }
 __host__ __device__ inline size_t xchg_x_off(int ngroups_total, int NC) { return 64 + (size_t)2 * ngroups_total * NC * FLAG_STRIDE; }
 // one exchange slot = one (direction, group, parity): forward uses GROUP x 4Hp bf16 of it, backward NC x GROUP x Hp
-__host__ __device__ inline size_t xchg_slot(int NC, int Hp) { return (size_t)(NC > 4 ? NC : 4) * GROUP * Hp * 2; }
+__host__ __device__ inline size_t xchg_slot(int NC, int Hp) {
+  const size_t barrier_form = (size_t)(NC > 4 ? NC : 4) * GROUP * Hp * 2;
+  const size_t wave_form = (size_t)(Hp / 16) * 2 * (Hp / 16) * 512;       // backward, wave-autonomous: [tile][m-tile][tile][64] x 8 B
+  return barrier_form > wave_form ? barrier_form : wave_form;
+}
 __host__ __device__ inline size_t xchg_bytes(int ngroups_total, int NC, int Hp) {
   return xchg_x_off(ngroups_total, NC) + (size_t)2 * ngroups_total * 2 * xchg_slot(NC, Hp);
 }
@@ -499,12 +503,8 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wave_kernel(CLaunch L) {
   const unsigned img_b = (unsigned)nHT * 2u * 512u;
   const __amdgpu_buffer_rsrc_t xr = make_rsrc(Xb, slot_b + img_b);
   // fragment of k-step ks: tile 2ks + (fq >> 1), row fr, units 8 (fq & 1) ..+7
-  unsigned frag_off[KSM];
-#pragma unroll
-  for (int k2 = 0; k2 < KSM; ++k2) {
-    const int tl = 2 * k2 + (fq >> 1);
-    frag_off[k2] = (k2 < KS && tl < nHT) ? (unsigned)((((tl * 2 + mt) * 256) + fr * 16 + 8 * (fq & 1)) * 2) : OOB;
-  }
+  // = frag_base + k2 * 2048 bytes; the second tile of the last k-step may not exist (odd tile count): those lanes read zero
+  const unsigned frag_base = (unsigned)(((((fq >> 1) * 2 + mt) * 256) + fr * 16 + 8 * (fq & 1)) * 2);
   const unsigned pub_off = lane < 32 ? (unsigned)((((ht * 2 + mt) * 256) + lane * 8) * 2) : OOB;
 
   unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last = 0;
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wave_kernel(CLaunch L) {
       bf16x8 af[KSM];
 #pragma unroll
       for (int k2 = 0; k2 < KSM; ++k2)
-        af[k2] = __builtin_bit_cast(bf16x8, ld16_sc1(xr, frag_off[k2] == OOB ? OOB : par + frag_off[k2]));
+        af[k2] = __builtin_bit_cast(bf16x8, ld16_sc1(xr, (k2 < KS && 2 * k2 + (fq >> 1) < nHT) ? par + frag_base + (unsigned)k2 * 2048u : OOB));
       flush(step - 1, Pp);
       STAMP(1);
 #pragma unroll
@@ -892,6 +892,216 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(CLaunch L) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ backward, wave-autonomous form
+// dh_{t-1} = dG_t W_hh, reduce-scattered as in the barrier kernel but per WAVE: every wave owns one (m-tile, hidden tile) for
+// the whole sequence.  From its own dG (16 samples x 64 gate rows, K = 64: two k-steps, A fragments through 2 KB of
+// wave-private LDS) it computes the PARTIAL dh for every hidden tile with W_hh fragments that stay in registers, and
+// publishes each 16 x 16 partial in the CONSUMER's accumulator-fragment order (lane: unit lane&15, samples (lane>>4)*4..+3,
+// four bf16 = 8 bytes per lane).  The consumer of tile nt reads its nHT partials with one 8-byte sc1 load per lane and
+// producer, sums them in fp32 straight in fragment order and runs the lane-local cell backward: no workgroup barrier, no
+// LDS staging of gathered data, no transposition on the consumer side.
+template <int NTM, bool GM>
+__global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __builtin_amdgcn_s_setprio(3);
+  const int role = L.blk2role[blockIdx.x];
+  if (role < 0) return;
+  Where wh;
+  wh.di = 0;
+#pragma unroll
+  for (int i = 1; i < MAXD; ++i)
+    if (i < L.n && role >= L.d[i].wg_begin) wh.di = i;
+  const CDesc& D = L.d[wh.di];
+  {
+    const int local = role - D.wg_begin;
+    wh.dir = local / (L.ng * D.NCw);
+    const int rem = local % (L.ng * D.NCw);
+    wh.grp = L.g0 + rem / D.NCw;
+    wh.me = rem % D.NCw;
+  }
+  const int H = D.H, Hp = D.Hp, nHT = D.nHT, NC = D.NC;
+  const int B = L.B, T = L.T, dir = wh.dir;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int rho = wh.me * L.wpb + wave;
+  const int mt = rho & 1, ht = rho >> 1;
+  if (ht >= nHT) return;
+  const int col = ht * 16 + fr;
+  const int ngt = (B + GROUP - 1) / GROUP;
+  const unsigned G4 = 4u * H;
+  constexpr bool gm = GM;
+  unsigned short* Tr = reinterpret_cast<unsigned short*>(smem) + wave * 1024;     // 16 x 64 bf16, wave-private
+
+  unsigned char* abort_w = D.xchg;
+  unsigned char* flags = D.xchg + xchg_flags_off() + ((size_t)(dir * ngt + wh.grp) * NC) * FLAG_STRIDE;
+  unsigned char* Xb = D.xchg + xchg_x_off(ngt, NC) + ((size_t)(dir * ngt + wh.grp) * 2) * xchg_slot(NC, Hp);
+  unsigned char* my_flag = flags + (size_t)rho * 64;
+  const int tau = lane < nHT ? lane : 0;
+  const unsigned char* poll_flag = flags + (size_t)(tau * 2 + mt) * 64;
+
+  // W_hh fragments: gate rows of the own hidden tile (two k-steps) x every column tile nt; cluster-backward packing
+  bf16x8 wreg[NTM][2];
+  {
+    const bf16x8* src = reinterpret_cast<const bf16x8*>(D.wpack_c[dir]);
+#pragma unroll
+    for (int nt = 0; nt < NTM; ++nt)
+#pragma unroll
+      for (int ks2 = 0; ks2 < 2; ++ks2)
+        wreg[nt][ks2] = nt < nHT ? src[((size_t)(ht * nHT + nt) * 2 + ks2) * 64 + lane] : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  }
+  const __amdgpu_buffer_rsrc_t rg = make_rsrc(D.gates, (unsigned)T * B * 2u * G4 * 4u);
+  const __amdgpu_buffer_rsrc_t rc = make_rsrc(D.cstash, (unsigned)T * B * 2u * H * 4u);
+  const __amdgpu_buffer_rsrc_t rd = make_rsrc(const_cast<float*>(D.d_hseq), D.d_hseq ? (unsigned)T * B * 2u * H * 4u : 0u);
+  const __amdgpu_buffer_rsrc_t ru = make_rsrc(D.utt, (unsigned)B * 4u * H * 4u);
+  const unsigned sg = (unsigned)B * 2u * G4 * 4u, sc = (unsigned)B * 2u * H * 4u;
+  unsigned og[4], oc[4], oh[4];
+  int len_r[4];
+  bool inb[4];
+  float d_fin[4];                                       // gradient of the final hidden state of this (sample, unit)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int b = wh.grp * GROUP + mt * 16 + fq * 4 + r;
+    inb[r] = col < H && b < B;
+    const int lv = L.lengths[min(b, B - 1)];
+    len_r[r] = inb[r] ? lv : 0;
+    og[r] = (((unsigned)b * 2u + dir) * G4 + (gm ? col * 4 : col)) * 4u;
+    oc[r] = (((unsigned)b * 2u + dir) * H + col) * 4u;
+    oh[r] = ((unsigned)b * 2u * H + dir * H + col) * 4u;
+    d_fin[r] = ldf(ru, inb[r] ? ((unsigned)b * 4u * H + (dir * 2 + D.layer) * H + col) * 4u : OOB);
+  }
+  float dc[4] = {0.f, 0.f, 0.f, 0.f};
+  struct Stash { float g[4][4], c[4], cp[4], dh[4]; };
+  Stash sb[2];                                          // forward stash of the coming steps
+  auto load_stash = [&](Stash& S, int step) {
+    const int t = dir ? step : T - 1 - step;
+    const int tp = dir ? t + 1 : t - 1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool act = step < T && t < len_r[r];
+      const unsigned o = og[r] + (unsigned)t * sg;
+      if (gm) {
+        const f32x4 v = ldf4(rg, act ? o : OOB);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) S.g[g][r] = v[g];
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) S.g[g][r] = ldf(rg, act ? o + g * H * 4u : OOB);
+      }
+      S.c[r] = ldf(rc, act ? oc[r] + (unsigned)t * sc : OOB);
+      S.cp[r] = ldf(rc, (act && tp >= 0 && tp < len_r[r]) ? oc[r] + (unsigned)tp * sc : OOB);
+      S.dh[r] = ldf(rd, act ? oh[r] + (unsigned)t * sc : OOB);          // zero-record descriptor when d_hseq == NULL
+    }
+  };
+  load_stash(sb[0], 0);
+  load_stash(sb[1], 1);
+  // exchange image per parity: [consumer tile nt][m-tile][producer tile][64 lanes] x 8 B
+  const unsigned slot_b = (unsigned)xchg_slot(NC, Hp);
+  const unsigned img_b = (unsigned)(nHT * 2 * nHT) * 512u;
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(Xb, slot_b + img_b);
+  const unsigned gat_base = (unsigned)((((ht * 2 + mt) * nHT) * 64 + lane) * 8);          // + producer * 512
+  const unsigned pub_base = (unsigned)(((mt * nHT + ht) * 64 + lane) * 8);                // + consumer tile nt * (2 * nHT * 512)
+  const unsigned pub_stride = (unsigned)(2 * nHT) * 512u;
+
+  bool alive = true;
+  float dgv[4][4];                                      // fp32 dG of the previous step, stored behind the next step's gather loads
+  auto flush = [&](int ps, Stash& Sp) {
+    const int t = dir ? ps : T - 1 - ps;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const unsigned o = inb[r] ? og[r] + (unsigned)t * sg : OOB;       // zero at padded positions too
+      if (gm) {
+        stf4(rg, o, f32x4{dgv[r][0], dgv[r][1], dgv[r][2], dgv[r][3]});
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) stf(rg, inb[r] ? o + g * H * 4u : OOB, dgv[r][g]);
+      }
+    }
+    load_stash(Sp, ps + 2);
+  };
+  typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+  auto do_step = [&](int step, Stash& S, Stash& Sp) {
+    const int t = dir ? step : T - 1 - step;
+    const unsigned epoch = L.epoch_base + (unsigned)step + 1u;
+    float dh_rec[4] = {0.f, 0.f, 0.f, 0.f};
+    if (step > 0) {
+      const unsigned need = epoch - 1u;
+      unsigned spins = 0;
+      for (;;) {
+        const unsigned f = ld_flag(poll_flag);
+        const bool ok = lane >= nHT || (int)(f - need) >= 0;
+        if (__all(ok)) break;
+        ++spins;
+        if (spins > SPIN_LIMIT || ((spins & 255u) == 0 && ld_flag(abort_w) != 0)) { alive = false; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (!alive) { if (lane == 0) st_flag(abort_w, 1u); return; }
+      const unsigned par = (need & 1u) * slot_b;
+      u32x2 gv[NTM];
+#pragma unroll
+      for (int p = 0; p < NTM; ++p)
+        gv[p] = __builtin_amdgcn_raw_buffer_load_b64(xr, p < nHT ? par + gat_base + (unsigned)p * 512u : OOB, 0, 16);
+      flush(step - 1, Sp);
+#pragma unroll
+      for (int p = 0; p < NTM; ++p) {
+        dh_rec[0] += __builtin_bit_cast(float, gv[p][0] << 16);
+        dh_rec[1] += __builtin_bit_cast(float, gv[p][0] & 0xffff0000u);
+        dh_rec[2] += __builtin_bit_cast(float, gv[p][1] << 16);
+        dh_rec[3] += __builtin_bit_cast(float, gv[p][1] & 0xffff0000u);
+      }
+    }
+    // lane-local gate gradients of the own hidden units (branch-free)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool act = t < len_r[r];
+      const bool fin = dir ? (t == 0) : (t == len_r[r] - 1);
+      const float gi = S.g[0][r], gf = S.g[1][r], gg = S.g[2][r], go = S.g[3][r];
+      const float dh = dh_rec[r] + S.dh[r] + (fin ? d_fin[r] : 0.f);
+      const float tc = tanh_fast(S.c[r]);
+      const float dct = dc[r] + dh * go * (1.f - tc * tc);
+      float dp[4];
+      dp[0] = act ? dct * gg * gi * (1.f - gi) : 0.f;
+      dp[1] = act ? dct * S.cp[r] * gf * (1.f - gf) : 0.f;
+      dp[2] = act ? dct * gi * (1.f - gg * gg) : 0.f;
+      dp[3] = act ? dh * tc * go * (1.f - go) : 0.f;
+      dc[r] = act ? dct * gf : dc[r];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        Tr[(fq * 4 + r) * 64 + g * 16 + fr] = f2bf(dp[g]);
+        dgv[r][g] = dp[g];
+      }
+    }
+    if (step + 1 < T) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the dG tile is complete in the wave-private LDS block
+      // A fragments of the two k-steps (gate pairs): row fr, 8 consecutive k at 32 ks2 + 8 fq
+      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&Tr[fr * 64 + fq * 8]);
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&Tr[fr * 64 + 32 + fq * 8]);
+      const unsigned par = (epoch & 1u) * slot_b;
+#pragma unroll
+      for (int nt = 0; nt < NTM; ++nt) {
+        if (nt < nHT) {                                  // workgroup-uniform
+          f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wreg[nt][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wreg[nt][1], acc, 0, 0, 0);
+          u32x2 pk;
+          pk[0] = (unsigned)f2bf(acc[0]) | ((unsigned)f2bf(acc[1]) << 16);
+          pk[1] = (unsigned)f2bf(acc[2]) | ((unsigned)f2bf(acc[3]) << 16);
+          __builtin_amdgcn_raw_buffer_store_b64(pk, xr, par + pub_base + (unsigned)nt * pub_stride, 0, 16);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's write-through stores have landed
+      if (lane == 0) st_flag(my_flag, epoch);
+    }
+  };
+  {
+    int step = 0;
+    for (; step + 1 < T && alive; step += 2) {
+      do_step(step, sb[0], sb[1]);
+      if (alive) do_step(step + 1, sb[1], sb[0]);
+    }
+    if (step < T && alive) { do_step(step, sb[0], sb[1]); ++step; }
+    if (alive && T > 0) flush(T - 1, (T - 1) & 1 ? sb[1] : sb[0]);
+  }
+}
+
 struct Plan { int TPW, NC, maxtw; size_t lds_f, lds_b; bool ok; };
 
 Plan plan_for(int H) {
@@ -976,7 +1186,8 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
   // of a block share the CU's address unit and the per-step memory instructions are what they queue on.
   static const int no_wave = getenv("MMDA_LSTM_BARRIER_FWD") ? 1 : 0;        // ablation: the barrier-synchronised forward kernel
   static const int force_wpb = getenv("MMDA_LSTM_WPB") ? atoi(getenv("MMDA_LSTM_WPB")) : 0;
-  bool fwd_wave = !bwd && !no_wave;
+  static const int no_wave_b = getenv("MMDA_LSTM_BARRIER_BWD") ? 1 : 0;      // ablation: the barrier-synchronised backward kernel
+  bool fwd_wave = bwd ? !no_wave_b : !no_wave;            // (named for the forward kernel; selects the wave-autonomous form of either pass)
   for (int i = 0; i < n; ++i) fwd_wave = fwd_wave && round_up(descs[i].H, 32) / 32 <= 10;
   int wpb = 4;
   int members[MAXD];                       // workgroups per cluster
@@ -1042,11 +1253,12 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
     }
     bool bwd_regs = true;                    // every descriptor's n-tiles fit the register-resident form (<= 10 per wave)
     for (int i = 0; i < n; ++i) bwd_regs = bwd_regs && L.d[i].nHT <= 20;
-    const size_t lds_launch = fwd_wave ? (size_t)4 * 512 : lds;
+    const size_t lds_launch = fwd_wave ? (size_t)4 * 2048 : lds;
     dim3 grid(grid_blocks), block(fwd_wave ? 64 * wpb : 256);
 #define LAUNCH_C()                                                                                               \
   do {                                                                                                           \
-    auto kfn = bwd ? (bwd_regs ? (L.gate_minor ? lstm_bwd_cluster_kernel<10, true> : lstm_bwd_cluster_kernel<10, false>)                \
+    auto kfn = bwd ? (fwd_wave ? (L.gate_minor ? lstm_bwd_wave_kernel<20, true> : lstm_bwd_wave_kernel<20, false>)                       \
+                    : bwd_regs ? (L.gate_minor ? lstm_bwd_cluster_kernel<10, true> : lstm_bwd_cluster_kernel<10, false>)                \
                               : (L.gate_minor ? lstm_bwd_cluster_kernel<0, true> : lstm_bwd_cluster_kernel<0, false>))                  \
                    : fwd_wave ? (L.gate_minor ? lstm_fwd_wave_kernel<10, true> : lstm_fwd_wave_kernel<10, false>)                        \
                               : (L.gate_minor ? lstm_fwd_cluster_kernel<10, true> : lstm_fwd_cluster_kernel<10, false>);                 \
