@@ -975,6 +975,11 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
   if (x.rc) return x.rc;
   // encoders, top layer first
   const float* xin[3] = {WS(m->mod[0].x), v, a};
+  // Layer 2's weight-gradient GEMMs: beside the layer-1 recurrent kernel on the side stream (MMDA_DW_OVERLAP=1), or held back
+  // and issued with layer 1's in one grouped launch after it.  The wave-autonomous recurrence runs one wave on each of ~110
+  // CUs and is bound by memory latency: a chip-filling GEMM beside it costs the recurrence about what the overlap hides.
+  static const int dw_overlap = getenv("MMDA_DW_OVERLAP") ? atoi(getenv("MMDA_DW_OVERLAP")) : 0;
+  std::vector<mmda_gemm_bf16_args> bside;
   for (int l = 1; l >= 0; --l) {
     mmda_lstm_desc desc[3];
     for (int i = 0; i < 3; ++i) {
@@ -996,7 +1001,7 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
     // next recurrent kernel (main stream); its weight gradients run on the side stream underneath that kernel.
     const bool bfg = mode == MMDA_BF16 && m->use_bf16_gemm;
     const bool bf_hh = bfg && (B % 8) == 0;        // the time-shifted views of dG^T / hseq^T start B elements into a row
-    std::vector<mmda_gemm_bf16_args> bmain, bside;
+    std::vector<mmda_gemm_bf16_args> bmain;
     if (bfg) {
       // gate gradients -> bf16: transposed (A of every dW) and, where an input gradient is needed, plain (A of dX)
       mmda_convert_job cj[3];
@@ -1061,6 +1066,7 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
     }
     group_end(x);
     x.deferring = false;
+    if (l == 0 && !dw_overlap) { bmain.insert(bmain.end(), bside.begin(), bside.end()); bside.clear(); }
     if (!x.rc && !bmain.empty()) x.rc = mmda_gemm_bf16_grouped(bmain.data(), (int)bmain.size(), stream);
     if (l == 1 && !x.rc) {
       // the inter-layer LayerNorm backward gives d(hseq of layer 1): input gradients on the main stream (they feed the next
@@ -1078,7 +1084,7 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
       for (int i = 0; i < 3; ++i) { lb[i].dgamma = GG(m->mod[i].ln_w); lb[i].dbeta = GG(m->mod[i].ln_b); lb[i].d_x = nullptr; }
       if (!x.rc) x.rc = mmda_layernorm_param_grads(lb, 3, ss);
       if (!x.rc && !x.deferred.empty()) x.rc = mmda_gemm_grouped(x.deferred.data(), (int)x.deferred.size(), ss);
-      if (!x.rc && !bside.empty()) x.rc = mmda_gemm_bf16_grouped(bside.data(), (int)bside.size(), ss);
+      if (!x.rc && !bside.empty() && dw_overlap) { x.rc = mmda_gemm_bf16_grouped(bside.data(), (int)bside.size(), ss); bside.clear(); }
       x.deferred.clear();
     } else if (!x.rc) {
       // text: gradient w.r.t. the embedding rows, scattered densely into embed.weight.grad (sparse=False)
