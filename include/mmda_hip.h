@@ -274,6 +274,15 @@ int mmda_loss_cmd_pairs(const float* x, int64_t stride, int nt, int np, const in
 int mmda_loss_recon(const float* recon, const float* orig, int64_t stride, int B, int D, float scale, float* loss,
                     float* drecon, float* dorig, void* stream);
 /* domain: solver.py:388-407.  dom: (3,B,3) logits stacked t,v,a; labels 0/1/2 */
+/* cls + conf (ConfidNet, ncls == 6 only, with_conf) + recon over n_recon contiguous elements in ONE launch, plus the weighted
+ * total L[5] = L[0] + diff_w L[1] + sim_w L[2] + recon_w L[3] (+ conf_w L[4] if use_conf) written by the last block to finish.
+ * L: 8 floats {cls, diff, sim, recon, conf, total, -, ticket}; L[0], L[3], L[4], L[7] must be zero on entry, L[1], L[2] final.
+ * Gradients (optional) are ADDED to d_scores / d_tcp (atomics: cls and conf share d_scores) and d_recon / d_orig.
+ * Replaces: solver.py:165-181 (the criterion, get_conf_loss, get_recon_loss calls and the weighted sum). */
+int mmda_loss_misc(const float* scores, const float* tcp, const float* emo, int B, int ncls, float* d_scores, float* d_tcp,
+                   int with_conf, int conf_grads, float conf_scale, const float* recon, const float* orig, int64_t n_recon,
+                   float recon_scale, float* d_recon, float* d_orig, float* L, float diff_w, float sim_w, float recon_w,
+                   float conf_w, int use_conf, void* stream);
 int mmda_loss_domain(const float* dom, int B, float scale, float* loss, float* ddom, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- optimizer

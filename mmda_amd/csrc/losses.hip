@@ -104,6 +104,103 @@ __global__ __launch_bounds__(256) void conf_kernel(const float* __restrict__ s, 
   if (threadIdx.x == 0 && loss) atomicAdd(loss, lt / (B * nz) + lm / nz);
 }
 
+// ------------------------------------------------------------------------------------------------ cls + conf + recon + total
+// The three small losses in ONE launch (block 0: cls, blocks 1..ncls: conf, the rest: recon) and, by the block that finishes
+// last (device-scope ticket), the weighted total of all five (solver.py:175-181).  Launched after the diff and similarity
+// losses on the same stream, so those sums are complete.  d_scores is shared by cls and conf: atomic adds here.
+struct MiscLossArgs {
+  const float* scores; const float* tcp; const float* emo; int B, ncls;
+  float* d_scores; float* d_tcp;            // NULL: no gradients
+  int conf_grads;                           // conf seeds gradients only with use_confidNet (solver.py:180-181)
+  float conf_scale;
+  const float* recon; const float* orig; int64_t n_recon; float recon_inv_n, recon_scale; float* d_recon; float* d_orig;
+  float* L;                                 // cls, diff, sim, recon, conf, total, -, ticket
+  float dw, sw, rw, cw; int use_conf, with_conf;
+  int recon_blocks;
+};
+
+__global__ __launch_bounds__(256) void misc_losses_kernel(MiscLossArgs a) {
+  __shared__ float red[16];
+  __shared__ float smax[4];
+  const int B = a.B, ncls = a.ncls;
+  const int role = blockIdx.x;
+  if (role == 0) {
+    float acc = 0.f;
+    for (int e = threadIdx.x; e < B * ncls; e += blockDim.x) {
+      float sv = a.scores[e], yv = a.emo[e];
+      float lp = fmaxf(logf(sv), -100.f), lq = fmaxf(log1pf(-sv), -100.f);
+      acc += -(yv * lp + (1.f - yv) * lq);
+      if (a.d_scores) atomicAdd(&a.d_scores[e], (sv - yv) / fmaxf(sv * (1.f - sv), 1e-12f) / B);
+    }
+    float t = block_sum(acc, red);
+    if (threadIdx.x == 0) atomicAdd(&a.L[0], t / B);
+  } else if (role <= (a.with_conf ? ncls : 0)) {
+    const int c = role - 1;
+    const float* s = a.scores; const float* y = a.emo;
+    float nz = 0.f, sy = 0.f, mx = -INFINITY;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+      float yv = y[b * ncls + c];
+      nz += (yv != 0.f) ? 1.f : 0.f;
+      sy += yv;
+      mx = fmaxf(mx, s[b * ncls + c]);
+    }
+    nz = block_sum(nz, red);
+    sy = block_sum(sy, red);
+    mx = wave_max(mx);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+    float se = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) se += expf(s[b * ncls + c] - mx);
+    se = block_sum(se, red);
+    const float lse = mx + logf(se);
+    float lt = 0.f, lm = 0.f;
+    const bool cg = a.conf_grads && a.d_scores;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+      int e = b * ncls + c;
+      float sv = s[e], yv = y[e], tv = a.tcp[e];
+      float diff = tv - yv * sv;
+      lt += diff * diff;
+      lm += -yv * (sv - lse);
+      float gt = 2.f * diff / (B * nz);
+      if (cg) {
+        atomicAdd(&a.d_tcp[e], a.conf_scale * gt);
+        atomicAdd(&a.d_scores[e], a.conf_scale * (-yv * gt + (-yv + sy * expf(sv - lse)) / nz));
+      }
+    }
+    lt = block_sum(lt, red);
+    lm = block_sum(lm, red);
+    if (threadIdx.x == 0) atomicAdd(&a.L[4], lt / (B * nz) + lm / nz);
+  } else {
+    const int rb = role - 1 - (a.with_conf ? ncls : 0);
+    float acc = 0.f;
+    for (int64_t e = rb * (int64_t)blockDim.x + threadIdx.x; e < a.n_recon; e += (int64_t)a.recon_blocks * blockDim.x) {
+      float d = a.recon[e] - a.orig[e];
+      acc += d * d;
+      float g = 2.f * d * a.recon_inv_n * a.recon_scale;
+      if (a.d_recon) a.d_recon[e] += g;
+      if (a.d_orig) a.d_orig[e] -= g;
+    }
+    float t = block_sum(acc, red);
+    if (threadIdx.x == 0) atomicAdd(&a.L[3], t * a.recon_inv_n);
+  }
+  // the last block to arrive sees every sum (release by the fence before the ticket, agent-scope reads after it)
+  if (threadIdx.x == 0) {
+    __threadfence();
+    unsigned* ticket = reinterpret_cast<unsigned*>(a.L + 7);
+    const unsigned prev = atomicAdd(ticket, 1u);
+    if (prev == gridDim.x - 1) {
+      __threadfence();
+      float v[5];
+      for (int i = 0; i < 5; ++i) v[i] = __hip_atomic_load(a.L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      float t = v[0] + a.dw * v[1] + a.sw * v[2] + a.rw * v[3];
+      if (a.use_conf) t += a.cw * v[4];
+      a.L[5] = t;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ diff
 // (1) per tensor: centre over the batch, divide rows by (detached L2 norm + 1e-6)            -> Ahat, invn
 // (2) K_k = Ahat_k Ahat_k^T (B x B) for the six tensors (batched MFMA GEMM)
@@ -142,6 +239,84 @@ __global__ __launch_bounds__(256) void diff_prep_kernel(const float* __restrict_
       v = (v != v) ? 0.f : fminf(fmaxf(v, -3.402823466e38f), 3.402823466e38f);
       Ahat[((int64_t)k * B + r) * D + i] = (v - M[i]) * inv;
     }
+  }
+}
+
+// Parallel forms of diff_prep_kernel / diff_finish_kernel for the training shapes (D <= 128, B <= 64): one 1024-thread block per
+// tensor = 128 columns x 8 row groups, the tensor's elements stay in registers; the serial per-column row loops of the
+// generic kernels (one dependent load per row) cost 12 + 18 us of the step for 100 KB of data.
+template <int RPT>
+__global__ __launch_bounds__(1024) void diff_prep_fast_kernel(const float* __restrict__ x, int64_t stride, int B, int D, float* Ahat,
+                                                              float* invn, float* mean) {
+  __shared__ float P[8][128];
+  __shared__ float R2[RPT * 8][2];
+  const int k = blockIdx.x, tid = threadIdx.x, c = tid & 127, rg = tid >> 7;
+  const int cc = min(c, D - 1);
+  const bool c_ok = c < D;
+  const float* X = x + k * stride;
+  float v[RPT];
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) {
+    const int r = rg + 8 * j;
+    float val = X[(int64_t)min(r, B - 1) * D + cc];
+    val = (val != val) ? 0.f : fminf(fmaxf(val, -3.402823466e38f), 3.402823466e38f);   // nan_to_num
+    v[j] = (c_ok && r < B) ? val : 0.f;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) s += v[j];
+  P[rg][c] = s;
+  __syncthreads();
+  float m = 0.f;
+#pragma unroll
+  for (int g = 0; g < 8; ++g) m += P[g][c];
+  m /= B;
+  if (rg == 0 && c_ok) mean[k * D + c] = m;
+  // row norms of the centred rows: a row's 128 columns sit in two waves
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) {
+    const bool ok = c_ok && rg + 8 * j < B;
+    v[j] = ok ? v[j] - m : 0.f;
+    const float q = wave_sum(v[j] * v[j]);
+    if ((tid & 63) == 0) R2[j * 8 + rg][c >> 6] = q;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) {
+    const int r = rg + 8 * j;
+    const float inv = 1.0f / (sqrtf(R2[j * 8 + rg][0] + R2[j * 8 + rg][1]) + 1e-6f);
+    if (c == 0 && r < B) invn[k * B + r] = inv;
+    if (c_ok && r < B) Ahat[((int64_t)k * B + r) * D + c] = v[j] * inv;
+  }
+}
+
+template <int RPT>
+__global__ __launch_bounds__(1024) void diff_finish_fast_kernel(const float* __restrict__ dA, const float* __restrict__ invn, int B,
+                                                                int D, int64_t stride, float* dx) {
+  __shared__ float P[8][128];
+  const int k = blockIdx.x, tid = threadIdx.x, c = tid & 127, rg = tid >> 7;
+  const int cc = min(c, D - 1);
+  const bool c_ok = c < D;
+  float v[RPT], old[RPT];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) {
+    const int r = rg + 8 * j, rc = min(r, B - 1);
+    const float val = dA[((int64_t)k * B + rc) * D + cc] * invn[k * B + rc];
+    old[j] = dx[k * stride + (int64_t)rc * D + cc];
+    v[j] = (c_ok && r < B) ? val : 0.f;
+    s += v[j];
+  }
+  P[rg][c] = s;
+  __syncthreads();
+  float cm = 0.f;
+#pragma unroll
+  for (int g = 0; g < 8; ++g) cm += P[g][c];
+  cm /= B;
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) {
+    const int r = rg + 8 * j;
+    if (c_ok && r < B) dx[k * stride + (int64_t)r * D + c] = old[j] + v[j] - cm;
   }
 }
 
@@ -504,28 +679,61 @@ extern "C" int mmda_loss_diff_pairs(const float* x, int64_t stride, int nt, int 
   float* mean = invn + 6 * B;                       // 6*D
   float* K = mean + 6 * D;                          // 6*B*B
   float* Ksum = K + (int64_t)6 * B * B;             // 6*B*B
-  hipLaunchKernelGGL(diff_prep_kernel, dim3(nt), dim3(256), 0, s, x, stride, B, D, Ahat, invn, mean);
+  const bool fast = D <= 128 && B <= 64;
+  if (fast) {
+    if (B <= 32) hipLaunchKernelGGL(diff_prep_fast_kernel<4>, dim3(nt), dim3(1024), 0, s, x, stride, B, D, Ahat, invn, mean);
+    else hipLaunchKernelGGL(diff_prep_fast_kernel<8>, dim3(nt), dim3(1024), 0, s, x, stride, B, D, Ahat, invn, mean);
+  } else {
+    hipLaunchKernelGGL(diff_prep_kernel, dim3(nt), dim3(256), 0, s, x, stride, B, D, Ahat, invn, mean);
+  }
   MMDA_CHECK_LAUNCH("mmda_loss_diff/prep");
-  mmda_gemm_args g = {};
-  g.mode = MMDA_F32; g.transA = 0; g.transB = 1; g.M = B; g.N = B; g.K = D; g.batch = nt;
-  g.A = Ahat; g.lda = D; g.strideA = (int64_t)B * D;
-  g.B = Ahat; g.ldb = D; g.strideB = (int64_t)B * D;
-  g.C = K; g.ldc = B; g.strideC = (int64_t)B * B;
-  int rc = mmda_gemm(&g, stream);
+  const int64_t BB = (int64_t)B * B;
+  int rc;
+  if (B <= 256) {
+    // few rows: the nt Gram matrices K_k = Ahat_k Ahat_k^T as one row-skinny launch
+    mmda_skinny_args sk[6];
+    for (int k = 0; k < nt; ++k) {
+      sk[k] = mmda_skinny_args{};
+      sk[k].M = B; sk[k].N = B; sk[k].K = D; sk[k].transB = 1; sk[k].A = Ahat + (int64_t)k * B * D; sk[k].lda = D;
+      sk[k].B = Ahat + (int64_t)k * B * D; sk[k].ldb = D; sk[k].C = K + k * BB; sk[k].ldc = B;
+    }
+    rc = mmda_gemm_skinny(sk, nt, stream);
+  } else {
+    mmda_gemm_args g = {};
+    g.mode = MMDA_F32; g.transA = 0; g.transB = 1; g.M = B; g.N = B; g.K = D; g.batch = nt;
+    g.A = Ahat; g.lda = D; g.strideA = (int64_t)B * D;
+    g.B = Ahat; g.ldb = D; g.strideB = (int64_t)B * D;
+    g.C = K; g.ldc = B; g.strideC = (int64_t)B * B;
+    rc = mmda_gemm(&g, stream);
+  }
   if (rc) return rc;
-  int64_t BB = (int64_t)B * B;
   int blocks = (int)((BB + 255) / 256); if (blocks > 256) blocks = 256;
   hipLaunchKernelGGL(diff_combine_kernel, dim3(blocks), dim3(256), 0, s, K, B, D, scale, loss, Ksum, pl);
   MMDA_CHECK_LAUNCH("mmda_loss_diff/combine");
   if (!dx) return MMDA_OK;
-  mmda_gemm_args h = {};
-  h.mode = MMDA_F32; h.transA = 0; h.transB = 0; h.M = B; h.N = D; h.K = B; h.batch = nt;
-  h.A = Ksum; h.lda = B; h.strideA = BB;
-  h.B = Ahat; h.ldb = D; h.strideB = (int64_t)B * D;
-  h.C = dA; h.ldc = D; h.strideC = (int64_t)B * D;
-  rc = mmda_gemm(&h, stream);
+  if (B <= 256) {
+    mmda_skinny_args sk[6];
+    for (int k = 0; k < nt; ++k) {
+      sk[k] = mmda_skinny_args{};
+      sk[k].M = B; sk[k].N = D; sk[k].K = B; sk[k].transB = 0; sk[k].A = Ksum + k * BB; sk[k].lda = B;
+      sk[k].B = Ahat + (int64_t)k * B * D; sk[k].ldb = D; sk[k].C = dA + (int64_t)k * B * D; sk[k].ldc = D;
+    }
+    rc = mmda_gemm_skinny(sk, nt, stream);
+  } else {
+    mmda_gemm_args h = {};
+    h.mode = MMDA_F32; h.transA = 0; h.transB = 0; h.M = B; h.N = D; h.K = B; h.batch = nt;
+    h.A = Ksum; h.lda = B; h.strideA = BB;
+    h.B = Ahat; h.ldb = D; h.strideB = (int64_t)B * D;
+    h.C = dA; h.ldc = D; h.strideC = (int64_t)B * D;
+    rc = mmda_gemm(&h, stream);
+  }
   if (rc) return rc;
-  hipLaunchKernelGGL(diff_finish_kernel, dim3(nt), dim3(256), 0, s, dA, invn, B, D, stride, dx);
+  if (fast) {
+    if (B <= 32) hipLaunchKernelGGL(diff_finish_fast_kernel<4>, dim3(nt), dim3(1024), 0, s, dA, invn, B, D, stride, dx);
+    else hipLaunchKernelGGL(diff_finish_fast_kernel<8>, dim3(nt), dim3(1024), 0, s, dA, invn, B, D, stride, dx);
+  } else {
+    hipLaunchKernelGGL(diff_finish_kernel, dim3(nt), dim3(256), 0, s, dA, invn, B, D, stride, dx);
+  }
   MMDA_CHECK_LAUNCH("mmda_loss_diff/finish");
   return MMDA_OK;
 }
@@ -579,6 +787,25 @@ extern "C" int mmda_loss_recon(const float* recon, const float* orig, int64_t st
                        1.0f / (3.0f * n), scale, loss, drecon ? drecon + k * stride : nullptr, dorig ? dorig + k * stride : nullptr);
   }
   MMDA_CHECK_LAUNCH("mmda_loss_recon");
+  return MMDA_OK;
+}
+
+extern "C" int mmda_loss_misc(const float* scores, const float* tcp, const float* emo, int B, int ncls, float* d_scores, float* d_tcp,
+                              int with_conf, int conf_grads, float conf_scale, const float* recon, const float* orig, int64_t n_recon,
+                              float recon_scale, float* d_recon, float* d_orig, float* L, float diff_w, float sim_w, float recon_w,
+                              float conf_w, int use_conf, void* stream) {
+  if (!scores || !emo || !recon || !orig || !L || B <= 0 || ncls <= 0 || n_recon <= 0) return MMDA_EINVAL;
+  if (with_conf && (!tcp || ncls != 6)) return MMDA_EINVAL;
+  MiscLossArgs a = {};
+  a.scores = scores; a.tcp = tcp; a.emo = emo; a.B = B; a.ncls = ncls; a.d_scores = d_scores; a.d_tcp = d_tcp;
+  a.conf_grads = conf_grads && d_scores && d_tcp; a.conf_scale = conf_scale; a.with_conf = with_conf;
+  a.recon = recon; a.orig = orig; a.n_recon = n_recon; a.recon_inv_n = 1.0f / (float)n_recon; a.recon_scale = recon_scale;
+  a.d_recon = d_recon; a.d_orig = d_orig; a.L = L; a.dw = diff_w; a.sw = sim_w; a.rw = recon_w; a.cw = conf_w; a.use_conf = use_conf;
+  int rb = (int)((n_recon + 255) / 256); if (rb > 64) rb = 64;
+  a.recon_blocks = rb;
+  const int blocks = 1 + (with_conf ? ncls : 0) + rb;
+  hipLaunchKernelGGL(misc_losses_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  MMDA_CHECK_LAUNCH("mmda_loss_misc");
   return MMDA_OK;
 }
 

@@ -224,10 +224,11 @@ int64_t layout(mmda_misa* m, int B, int T, bool commit) {
   o->qkv = k.take(6 * BH * 3); o->probs = k.take((int64_t)B * NHEAD * S6 * S6); o->ctx = k.take(6 * BH);
   o->attn_out = k.take(6 * BH); o->ln1_mean = k.take(6 * B); o->ln1_rstd = k.take(6 * B); o->x1 = k.take(6 * BH);
   o->f1 = k.take((int64_t)6 * B * FFN); o->f2 = k.take(6 * BH); o->ln2_mean = k.take(6 * B); o->ln2_rstd = k.take(6 * B);
-  o->hfused = k.take(6 * BH); o->logits = k.take((int64_t)B * NC); o->losses = k.take(8);
+  o->hfused = k.take(6 * BH); o->logits = k.take((int64_t)B * NC);
   o->diff_work = k.take(mmda_loss_diff_work_floats(B, hs));
-  // ---- activation gradients seeded by the losses (zeroed every step, contiguous)
+  // ---- the loss sums and the activation gradients seeded by the losses (zeroed every step by ONE memset, contiguous)
   o->zero_begin = k.cur;
+  o->losses = k.take(8);
   o->d_scores = k.take((int64_t)B * c.ncls); o->d_tcp = k.take((int64_t)B * 6); o->d_x6 = k.take(6 * BH);
   o->d_orig = k.take(3 * BH); o->d_recon = k.take(3 * BH); o->d_dom = k.take((int64_t)3 * B * 3);
   o->zero_end = k.cur;
@@ -316,12 +317,6 @@ void sk_launch(Ctx& c, const mmda_skinny_args* p, int n) {
   if (!c.rc) c.rc = mmda_gemm_skinny(p, n, c.s);
 }
 
-__global__ void total_loss_kernel(float* L, float dw, float sw, float rw, float cw, int use_conf) {
-  // L: cls, diff, sim, recon, conf, total   (solver.py:175-181)
-  float t = L[0] + dw * L[1] + sw * L[2] + rw * L[3];
-  if (use_conf) t += cw * L[4];
-  L[5] = t;
-}
 
 void ev_rec(mmda_misa* m, int step, int slot, int which, void* stream) {
   if (m->ev.empty() || step >= m->ev_steps) return;
@@ -738,30 +733,20 @@ extern "C" int mmda_misa_losses(mmda_misa* m, const float* emo, int with_grads, 
   const int64_t BH = (int64_t)B * hs;
   hipStream_t s = (hipStream_t)stream;
   int rc = MMDA_OK;
-  if (hipMemsetAsync(WS(m->losses), 0, sizeof(float) * 8, s) != hipSuccess) return MMDA_ELAUNCH;
-  if (with_grads) { rc = mmda_misa_zero_act_grads(m, stream); if (rc) return rc; }
+  if (with_grads) { rc = mmda_misa_zero_act_grads(m, stream); if (rc) return rc; }      // covers the loss sums too
+  else if (hipMemsetAsync(WS(m->losses), 0, sizeof(float) * 8, s) != hipSuccess) return MMDA_ELAUNCH;
   float* L = WS(m->losses);
-  float* g_sc = with_grads ? WS(m->d_scores) : nullptr;
-  rc = mmda_loss_cls(WS(m->scores), emo, B, c.ncls, 1.f, L + 0, g_sc, stream);
-  if (rc) return rc;
   rc = mmda_loss_diff(WS(m->x6), BH, B, hs, c.diff_weight, L + 1, with_grads ? WS(m->d_x6) : nullptr, WS(m->diff_work), stream);
   if (rc) return rc;
   if (c.use_cmd_sim) rc = mmda_loss_cmd(WS(m->x6 + 3 * BH), BH, B, hs, c.sim_weight, L + 2, with_grads ? WS(m->d_x6 + 3 * BH) : nullptr, stream);
   else rc = mmda_loss_domain(WS(m->dom), B, c.sim_weight, L + 2, with_grads ? WS(m->d_dom) : nullptr, stream);
   if (rc) return rc;
-  rc = mmda_loss_recon(WS(m->recon), WS(m->orig), BH, B, hs, c.recon_weight, L + 3, with_grads ? WS(m->d_recon) : nullptr,
-                       with_grads ? WS(m->d_orig) : nullptr, stream);
-  if (rc) return rc;
-  if (c.ncls == 6) {   // computed every step like solver.py:168; only seeds gradients when use_confidNet (solver.py:180-181)
-    bool cg = with_grads && c.use_confidNet;
-    rc = mmda_loss_conf(WS(m->scores), WS(m->tcp), emo, B, c.ncls, c.conf_weight, L + 4, cg ? WS(m->d_scores) : nullptr,
-                        cg ? WS(m->d_tcp) : nullptr, stream);
-    if (rc) return rc;
-  }
-  hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(1), 0, s, L, c.diff_weight, c.sim_weight, c.recon_weight, c.conf_weight,
-                     c.use_confidNet);
-  MMDA_CHECK_LAUNCH("mmda_misa_losses/total");
-  return MMDA_OK;
+  // cls, conf (computed every step like solver.py:168; it only seeds gradients with use_confidNet, solver.py:180-181), recon and
+  // the weighted total in one launch
+  return mmda_loss_misc(WS(m->scores), WS(m->tcp), emo, B, c.ncls, with_grads ? WS(m->d_scores) : nullptr,
+                        with_grads ? WS(m->d_tcp) : nullptr, c.ncls == 6, with_grads && c.use_confidNet, c.conf_weight, WS(m->recon),
+                        WS(m->orig), 3 * BH, c.recon_weight, with_grads ? WS(m->d_recon) : nullptr, with_grads ? WS(m->d_orig) : nullptr,
+                        L, c.diff_weight, c.sim_weight, c.recon_weight, c.conf_weight, c.use_confidNet, stream);
 }
 
 // =============================================================================================== backward
