@@ -12,7 +12,7 @@
 
 namespace {
 
-constexpr int TM = 128, TN = 128, TK = 64;
+constexpr int TK = 64;
 constexpr int LDT = TK + 8;                 // bf16 elements per LDS row (144 B: 16-B aligned, conflict-light for ds_read_b128)
 constexpr int GROUP_MAX = 16;
 
@@ -159,8 +159,63 @@ __device__ __forceinline__ void gemm_bf16_tile(const mmda_gemm_bf16_args& g, int
         }
     }
   }
-  // Accumulating without split-K reads C first: all loads are issued from clamped addresses before the first add (a load
-  // under the m < M / n < N branches would be waited for one by one).
+  // ---- C tile.  Without split-K and with 16-byte-aligned rows the tile goes out through LDS: the accumulator fragments hold 4
+  // rows x 16 columns per wave-register, so storing them directly is 64-byte pieces (a 1600 x 2400 fp32 output took 16 us
+  // that way, 4x a memset of the same size); staged, every store instruction writes 16 bytes per lane along a row and the
+  // bias / accumulate reads are 16-byte loads of the same shape.
+  const bool vec_out = splitk == 1 && (g.ldc & 3) == 0 && ((uintptr_t)g.C & 15) == 0 && (N & 3) == 0;      // block-uniform
+  if (vec_out) {
+    constexpr int LDC = T + 4;                           // floats per staged row
+    constexpr int RP = T == 128 ? 32 : 64;               // rows per pass: RP * LDC * 4 bytes <= the operand LDS block
+    constexpr int C4 = T / 4;                            // float4 per staged row; divides 256, so a thread keeps ONE column group
+    float* Cs = reinterpret_cast<float*>(As);
+    const int c4 = tid % C4;
+    const int n = col0 + c4 * 4;
+    const bool n_ok = n < N;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias || g.bias2) {
+      // n is a multiple of 4: with the gate interleave the four columns are the four gates of ONE unit, orig = nb0 + e * H
+      const int nn = min(n, N - 4);
+      int nb0 = nn, nbs = 1;
+      if (g.perm_n_H > 0) { const int G = 4 * g.perm_n_H, d = nn / G; nb0 = d * G + ((nn - d * G) >> 2); nbs = g.perm_n_H; }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (g.bias) bsum[e] += g.bias[nb0 + e * nbs];
+        if (g.bias2) bsum[e] += g.bias2[nb0 + e * nbs];
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < T / RP; ++p) {
+      __syncthreads();                                   // operand tiles (first pass) / previous pass are no longer read
+#pragma unroll
+      for (int i = 0; i < W; ++i) {
+        const int lr0 = wm * (T / 2) + i * 16 - p * RP;  // first row of this fragment block within the pass
+        if (lr0 >= 0 && lr0 < RP) {                      // wave-uniform
+#pragma unroll
+          for (int j = 0; j < W; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              Cs[(lr0 + (lane >> 4) * 4 + r) * LDC + wn * (T / 2) + j * 16 + (lane & 15)] = alpha * acc[i][j][r];
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < RP * C4 / 256; ++q) {
+        const int lr = (q * 256 + tid) / C4;
+        const int m = row0 + p * RP + lr;
+        if (m < M && n_ok) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[lr * LDC + c4 * 4]) + bsum;
+          const int mo = g.perm_m_H > 0 ? gate_orig(m, g.perm_m_H) : m;
+          float* dst = g.C + (int64_t)mo * g.ldc + n;
+          if (g.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
+          *reinterpret_cast<f32x4*>(dst) = v;
+        }
+      }
+    }
+    return;
+  }
+  // Scalar path (split-K atomics, unaligned rows).  Accumulating without split-K reads C first: all loads are issued from
+  // clamped addresses before the first add (a load under the m < M / n < N branches would be waited for one by one).
 #pragma unroll
   for (int i = 0; i < W; ++i) {
     float oldc[W][4];
@@ -195,9 +250,11 @@ __device__ __forceinline__ void gemm_bf16_tile(const mmda_gemm_bf16_args& g, int
   }
 }
 
+// One kernel per tile size: the 64 x 64 form needs half the registers and LDS of the 128 x 128 one, and the long-K gradient
+// GEMMs that use it are bound by per-k-tile latency -- more resident workgroups per CU is what hides it.
+template <int T>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(Bf16Group G) {
-  __shared__ __attribute__((aligned(16))) unsigned short As[TM * LDT];
-  __shared__ __attribute__((aligned(16))) unsigned short Bs[TN * LDT];
+  __shared__ __attribute__((aligned(16))) unsigned short AB[2 * T * LDT];       // A block | B block (the C tile is staged over both)
   int pi = 0;
 #pragma unroll
   for (int k = 1; k < GROUP_MAX; ++k)
@@ -206,8 +263,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(Bf16Group G) {
   const int splitk = G.splitk[pi];
   const int local = blockIdx.x - G.start[pi];
   const int bx = local % G.tx[pi], by = (local / G.tx[pi]) % G.ty[pi], sp = local / (G.tx[pi] * G.ty[pi]);
-  if (G.tile[pi] == 128) gemm_bf16_tile<128>(g, splitk, bx, by, sp, As, Bs);
-  else gemm_bf16_tile<64>(g, splitk, bx, by, sp, As, Bs);
+  gemm_bf16_tile<T>(g, splitk, bx, by, sp, AB, AB + T * LDT);
 }
 
 // ------------------------------------------------------------------------------------------------ conversion
@@ -267,27 +323,39 @@ __global__ __launch_bounds__(256) void convert_kernel(ConvLaunch L) {
 extern "C" int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, void* stream) {
   if (!args || n < 0) return MMDA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  for (int base = 0; base < n; base += GROUP_MAX) {
-    const int cnt = (n - base) < GROUP_MAX ? (n - base) : GROUP_MAX;
+  for (int i = 0; i < n; ++i) {
+    const mmda_gemm_bf16_args& a = args[i];
+    if (!a.A || !a.B || !a.C || a.M < 0 || a.N < 0 || a.K <= 0) return MMDA_EINVAL;
+    if ((a.lda & 7) || (a.ldb & 7) || (((uintptr_t)a.A | (uintptr_t)a.B) & 15)) return MMDA_EINVAL;
+    if (a.lda < ((a.K + 7) & ~7) || a.ldb < ((a.K + 7) & ~7)) return MMDA_EINVAL;
+    if (a.perm_n_H < 0 || a.perm_m_H < 0 || (a.perm_n_H && a.N % (4 * a.perm_n_H)) || (a.perm_m_H && a.M % (4 * a.perm_m_H))) return MMDA_EINVAL;
+  }
+  // 128 x 128 tiles when they alone fill the chip twice over; else 64 x 64 (4x the workgroups, 2x the residency)
+  auto tile_of = [](const mmda_gemm_bf16_args& a) {
+    const int Ne = a.N + (a.bias_grad ? 1 : 0);
+    return ceil_div(Ne, 128) * ceil_div(a.M, 128) >= 512 ? 128 : 64;
+  };
+  for (int T = 64; T <= 128; T += 64) {
     Bf16Group G;
     G.n = 0;
-    for (int i = 0; i < cnt; ++i) {
-      const mmda_gemm_bf16_args& a = args[base + i];
-      if (!a.A || !a.B || !a.C || a.M < 0 || a.N < 0 || a.K <= 0) return MMDA_EINVAL;
-      if ((a.lda & 7) || (a.ldb & 7) || (((uintptr_t)a.A | (uintptr_t)a.B) & 15)) return MMDA_EINVAL;
-      if (a.lda < ((a.K + 7) & ~7) || a.ldb < ((a.K + 7) & ~7)) return MMDA_EINVAL;
-      if (a.perm_n_H < 0 || a.perm_m_H < 0 || (a.perm_n_H && a.N % (4 * a.perm_n_H)) || (a.perm_m_H && a.M % (4 * a.perm_m_H))) return MMDA_EINVAL;
-    }
     int blocks = 0;
-    for (int i = 0; i < cnt; ++i) {
-      const mmda_gemm_bf16_args& a = args[base + i];
-      if (a.M == 0 || a.N == 0) continue;
+    auto flush = [&]() -> int {
+      if (blocks == 0) { G.n = 0; return MMDA_OK; }
+      for (int k = G.n; k <= GROUP_MAX; ++k) G.start[k] = blocks;
+      for (int k = G.n; k < GROUP_MAX; ++k) { G.p[k] = G.p[0]; G.tx[k] = G.ty[k] = G.splitk[k] = 1; G.tile[k] = T; }
+      if (T == 128) hipLaunchKernelGGL(gemm_bf16_kernel<128>, dim3(blocks), dim3(256), 0, s, G);
+      else hipLaunchKernelGGL(gemm_bf16_kernel<64>, dim3(blocks), dim3(256), 0, s, G);
+      MMDA_CHECK_LAUNCH("mmda_gemm_bf16_grouped");
+      G.n = 0; blocks = 0;
+      return MMDA_OK;
+    };
+    for (int i = 0; i < n; ++i) {
+      const mmda_gemm_bf16_args& a = args[i];
+      if (a.M == 0 || a.N == 0 || tile_of(a) != T) continue;
+      if (G.n == GROUP_MAX) { int rc = flush(); if (rc) return rc; }
       const int k = G.n++;
       G.p[k] = a;
       const int Ne = a.N + (a.bias_grad ? 1 : 0);
-      // 128 x 128 tiles when they alone give ~2/3 of a chip-wide wave; else 64 x 64 (4x the workgroups)
-      const int t128 = ceil_div(Ne, 128) * ceil_div(a.M, 128);
-      const int T = t128 >= 160 ? 128 : 64;
       G.tile[k] = T;
       G.tx[k] = ceil_div(Ne, T); G.ty[k] = ceil_div(a.M, T);
       const int tiles = G.tx[k] * G.ty[k];
@@ -295,8 +363,8 @@ extern "C" int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, vo
       // split-K combines through float atomics, which the chip retires at ~1.3 TB/s of added bytes: split only while the
       // added bytes stay small (<= 6 MB, ~5 us) and every slice keeps >= 4 k-tiles
       int sk = 1;
-      if (tiles < 192 && nk >= 8) {
-        sk = ceil_div(256, tiles);
+      if (tiles < 256 && nk >= 8) {
+        sk = ceil_div(512, tiles);
         if (sk > nk / 4) sk = nk / 4;
         const double out_mb = (double)a.M * a.N * 4.0 / 1048576.0;
         while (sk > 1 && sk * out_mb > 6.0) --sk;
@@ -311,11 +379,8 @@ extern "C" int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, vo
       G.start[k] = blocks;
       blocks += tiles * sk;
     }
-    for (int k = G.n; k <= GROUP_MAX; ++k) G.start[k] = blocks;
-    for (int k = G.n; k < GROUP_MAX; ++k) { G.p[k] = G.p[0]; G.tx[k] = G.ty[k] = G.splitk[k] = 1; G.tile[k] = 64; }
-    if (blocks == 0) continue;
-    hipLaunchKernelGGL(gemm_bf16_kernel, dim3(blocks), dim3(256), 0, s, G);
-    MMDA_CHECK_LAUNCH("mmda_gemm_bf16_grouped");
+    int rc = flush();
+    if (rc) return rc;
   }
   return MMDA_OK;
 }
