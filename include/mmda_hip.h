@@ -365,6 +365,9 @@ int mmda_misa_train_step(mmda_misa* m, const int64_t* t_ids, const float* v, con
  * (bench.py's roofline leg).  begin(max_steps) arms it; every train_step/forward/backward then brackets its four
  * recurrent launches (0: fwd layer1, 1: fwd layer2, 2: bwd layer2, 3: bwd layer1); collect() synchronises the events and
  * returns the mean milliseconds per launch of each and the number of timed steps; end() disarms and frees the events. */
+/* record the recurrent kernels' event pairs only on every stride-th step (default 1; set before mmda_misa_timing_begin, whose
+ * max_steps then counts RECORDED steps): eight event records per step cost ~35 us of a 1.4 ms step */
+int mmda_misa_timing_stride(mmda_misa* m, int stride);
 int mmda_misa_timing_begin(mmda_misa* m, int max_steps);
 int mmda_misa_timing_collect(mmda_misa* m, float mean_ms[4], int* steps);
 int mmda_misa_timing_end(mmda_misa* m);

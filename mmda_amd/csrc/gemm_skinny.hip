@@ -13,6 +13,7 @@
 //     alpha, bias, accumulate, activation, dropout, relu-gate, sigmoid-backward factor, second destination.
 // Up to 8 independent problems per launch.  Deterministic: no atomics, fixed reduction order.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -23,14 +24,16 @@ struct SkinnyLaunch {
   mmda_skinny_args p[SK_MAXP];
   int start[SK_MAXP + 1];
   int tx[SK_MAXP];
+  int nsplit[SK_MAXP];           // 1: waves split N (short K), 0: waves split K
   int n;
 };
 
 typedef __attribute__((ext_vector_type(4))) float f4;
+__device__ __forceinline__ bool vec_ok(const float* p, int ld) { return (((uintptr_t)p) & 15) == 0 && (ld & 3) == 0; }
 
 // One product: acc[t] += A[row0 + 16t .. , :] * op(B)[:, col0 ..] over this wave's chunks.
 // VEC: float4 loads along k for A (and for B when TB); needs 16-B aligned bases, ld % 4 == 0 and K % 4 == 0.
-template <bool TB, bool VEC>
+template <bool TB, bool VEC, int WK>
 __device__ __forceinline__ void skinny_product(f32x4 (&acc)[2], const float* __restrict__ A, const float* __restrict__ A2, int lda,
                                                const float* __restrict__ Bm, int ldb, int M, int N, int K, int row0, int col0,
                                                int wave, int lane) {
@@ -97,59 +100,19 @@ __device__ __forceinline__ void skinny_product(f32x4 (&acc)[2], const float* __r
 
   if (wave >= nchunks) return;                       // wave-uniform
 #pragma unroll
-  for (int p = 0; p < SK_PF; ++p) load(p, wave + SK_WAVES * p);      // chunks past the end load clamped addresses and read as zero
-  for (int base = wave; base < nchunks; base += SK_WAVES * SK_PF) {
+  for (int p = 0; p < SK_PF; ++p) load(p, wave + WK * p);            // chunks past the end load clamped addresses and read as zero
+  for (int base = wave; base < nchunks; base += WK * SK_PF) {
 #pragma unroll
     for (int p = 0; p < SK_PF; ++p) {
-      if (base + SK_WAVES * p < nchunks) mma(p);     // wave-uniform
-      const int next = base + SK_WAVES * (p + SK_PF);
+      if (base + WK * p < nchunks) mma(p);           // wave-uniform
+      const int next = base + WK * (p + SK_PF);
       if (next < nchunks) load(p, next);             // wave-uniform
     }
   }
 }
 
-__device__ __forceinline__ bool vec_ok(const float* p, int ld) { return (((uintptr_t)p) & 15) == 0 && (ld & 3) == 0; }
-
-__global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyLaunch L) {
-  __shared__ float red[SK_WAVES][2][256];
-  int pi = 0;
-#pragma unroll
-  for (int k = 1; k < SK_MAXP; ++k)
-    if (k < L.n && (int)blockIdx.x >= L.start[k]) pi = k;
-  const mmda_skinny_args& g = L.p[pi];
-  const int local = blockIdx.x - L.start[pi];
-  const int bx = local % L.tx[pi], by = local / L.tx[pi];
-  const int row0 = by * SK_TM, col0 = bx * SK_TN;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-  for (int prod = 0; prod < 2; ++prod) {
-    const float* A = prod ? g.A_2nd : g.A;
-    const float* A2 = prod ? nullptr : g.A2;
-    const float* Bm = prod ? g.B_2nd : g.B;
-    const int lda = prod ? g.lda_2nd : g.lda, ldb = prod ? g.ldb_2nd : g.ldb, K = prod ? g.K2 : g.K;
-    if (!A || K <= 0) continue;
-    const bool va = vec_ok(A, lda) && (K & 3) == 0 && (!A2 || vec_ok(A2, lda));
-    if (g.transB) {
-      if (va && vec_ok(Bm, ldb)) skinny_product<true, true>(acc, A, A2, lda, Bm, ldb, g.M, g.N, K, row0, col0, wave, lane);
-      else skinny_product<true, false>(acc, A, A2, lda, Bm, ldb, g.M, g.N, K, row0, col0, wave, lane);
-    } else {
-      if (va) skinny_product<false, true>(acc, A, A2, lda, Bm, ldb, g.M, g.N, K, row0, col0, wave, lane);
-      else skinny_product<false, false>(acc, A, A2, lda, Bm, ldb, g.M, g.N, K, row0, col0, wave, lane);
-    }
-  }
-  // D fragment: col = lane & 15, row = (lane >> 4) * 4 + reg
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) red[wave][t][((lane >> 4) * 4 + rg) * 16 + (lane & 15)] = acc[t][rg];
-  __syncthreads();
-  const int t = tid >> 8, e = tid & 255;
-  const int m = row0 + t * 16 + (e >> 4), n = col0 + (e & 15);
-  if (m >= g.M || n >= g.N) return;
-  float raw = 0.f;
-#pragma unroll
-  for (int w = 0; w < SK_WAVES; ++w) raw += red[w][t][e];      // fixed order: bitwise reproducible
+// the fused epilogue of one output element
+__device__ __forceinline__ void skinny_epilogue(const mmda_skinny_args& g, int m, int n, float raw) {
   raw *= (g.alpha == 0.f ? 1.f : g.alpha);
   float v = raw;
   if (g.bias) v += g.bias[n];
@@ -168,6 +131,69 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyLaunch L) {
     if (g.dsig2) { const float s = g.dsig2[(int64_t)m * g.lddsig + n]; u *= s * (1.f - s); }
     g.C2[c2] = u;
   }
+}
+
+template <int WK>
+__device__ __forceinline__ void skinny_products(f32x4 (&acc)[2], const mmda_skinny_args& g, int row0, int col0, int wave, int lane) {
+  for (int prod = 0; prod < 2; ++prod) {
+    const float* A = prod ? g.A_2nd : g.A;
+    const float* A2 = prod ? nullptr : g.A2;
+    const float* Bm = prod ? g.B_2nd : g.B;
+    const int lda = prod ? g.lda_2nd : g.lda, ldb = prod ? g.ldb_2nd : g.ldb, K = prod ? g.K2 : g.K;
+    if (!A || K <= 0) continue;
+    const bool va = vec_ok(A, lda) && (K & 3) == 0 && (!A2 || vec_ok(A2, lda));
+    if (g.transB) {
+      if (va && vec_ok(Bm, ldb)) skinny_product<true, true, WK>(acc, A, A2, lda, Bm, ldb, g.M, g.N, K, row0, col0, wave, lane);
+      else skinny_product<true, false, WK>(acc, A, A2, lda, Bm, ldb, g.M, g.N, K, row0, col0, wave, lane);
+    } else {
+      if (va) skinny_product<false, true, WK>(acc, A, A2, lda, Bm, ldb, g.M, g.N, K, row0, col0, wave, lane);
+      else skinny_product<false, false, WK>(acc, A, A2, lda, Bm, ldb, g.M, g.N, K, row0, col0, wave, lane);
+    }
+  }
+}
+
+__global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyLaunch L) {
+  __shared__ float red[SK_WAVES][2][256];
+  int pi = 0;
+#pragma unroll
+  for (int k = 1; k < SK_MAXP; ++k)
+    if (k < L.n && (int)blockIdx.x >= L.start[k]) pi = k;
+  const mmda_skinny_args& g = L.p[pi];
+  const int local = blockIdx.x - L.start[pi];
+  const int bx = local % L.tx[pi], by = local / L.tx[pi];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  if (L.nsplit[pi]) {
+    // short K, wide N: the eight waves take eight adjacent 16-column tiles and each walks the whole K; no cross-wave sum
+    const int row0 = by * SK_TM, col0 = (bx * SK_WAVES + wave) * SK_TN;
+    if (col0 >= g.N) return;                             // wave-uniform; no barrier on this path
+    skinny_products<1>(acc, g, row0, col0, 0, lane);
+    const int n = col0 + (lane & 15);
+    if (n >= g.N) return;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int m = row0 + t * 16 + (lane >> 4) * 4 + rg;
+        if (m < g.M) skinny_epilogue(g, m, n, acc[t][rg]);
+      }
+    return;
+  }
+  const int row0 = by * SK_TM, col0 = bx * SK_TN;
+  skinny_products<SK_WAVES>(acc, g, row0, col0, wave, lane);
+  // D fragment: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) red[wave][t][((lane >> 4) * 4 + rg) * 16 + (lane & 15)] = acc[t][rg];
+  __syncthreads();
+  const int t = tid >> 8, e = tid & 255;
+  const int m = row0 + t * 16 + (e >> 4), n = col0 + (e & 15);
+  if (m >= g.M || n >= g.N) return;
+  float raw = 0.f;
+#pragma unroll
+  for (int w = 0; w < SK_WAVES; ++w) raw += red[w][t][e];      // fixed order: bitwise reproducible
+  skinny_epilogue(g, m, n, raw);
 }
 
 }  // namespace
@@ -192,12 +218,17 @@ extern "C" int mmda_gemm_skinny(const mmda_skinny_args* args, int n, void* strea
       if (a.M == 0 || a.N == 0) continue;
       const int k = L.n++;
       L.p[k] = a;
-      L.tx[k] = ceil_div(a.N, SK_TN);
+      // Column-split form (one wave per 16-column tile walks the whole K; K <= 256): OFF unless MMDA_SKINNY_NSPLIT_MIN_N is set.
+      // Measured on the training step it loses to the K-split form at every shape of the fusion block (1.35 -> 1.43 ms per
+      // step with it on for N >= 128, 1.37 for N >= 1024): eight waves sharing one k-walk's latency beat eight walking alone.
+      static const int nsplit_min_n = getenv("MMDA_SKINNY_NSPLIT_MIN_N") ? atoi(getenv("MMDA_SKINNY_NSPLIT_MIN_N")) : (1 << 30);
+      L.nsplit[k] = (a.K <= 256 && a.K2 <= 256 && a.N >= nsplit_min_n) ? 1 : 0;
+      L.tx[k] = L.nsplit[k] ? ceil_div(a.N, SK_WAVES * SK_TN) : ceil_div(a.N, SK_TN);
       L.start[k] = blocks;
       blocks += L.tx[k] * ceil_div(a.M, SK_TM);
     }
     for (int k = L.n; k <= SK_MAXP; ++k) L.start[k] = blocks;
-    for (int k = L.n; k < SK_MAXP; ++k) { L.p[k] = L.p[0]; L.tx[k] = 1; }
+    for (int k = L.n; k < SK_MAXP; ++k) { L.p[k] = L.p[0]; L.tx[k] = 1; L.nsplit[k] = 0; }
     if (blocks == 0) continue;
     hipLaunchKernelGGL(gemm_skinny_kernel, dim3(blocks), dim3(512), 0, s, L);
     MMDA_CHECK_LAUNCH("mmda_gemm_skinny");

@@ -70,6 +70,7 @@ struct mmda_misa {
   int ldR = 0;
   std::vector<hipEvent_t> ev;      // [step][slot][start/stop]
   int ev_steps = 0, ev_fwd = 0, ev_bwd = 0;
+  int ev_stride = 1, ev_seen_f = 0, ev_seen_b = 0;   // record every ev_stride-th step (the event pairs cost ~35 us per step)
 };
 
 namespace {
@@ -320,6 +321,7 @@ void sk_launch(Ctx& c, const mmda_skinny_args* p, int n) {
 
 void ev_rec(mmda_misa* m, int step, int slot, int which, void* stream) {
   if (m->ev.empty() || step >= m->ev_steps) return;
+  if ((slot < 2 ? m->ev_seen_f : m->ev_seen_b) % m->ev_stride) return;
   (void)hipEventRecord(m->ev[(step * 4 + slot) * 2 + which], (hipStream_t)stream);
 }
 
@@ -714,7 +716,7 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
       x.rc = mmda_heads_fwd(WS(m->logits), B, c.ncls, c.threshold, WS(m->tcp), WS(m->scores), WS(m->labels), p_cls, seed, SITE_CLS,
                             stream);
   }
-  if (!m->ev.empty()) m->ev_fwd++;
+  if (!m->ev.empty()) { if (m->ev_seen_f % m->ev_stride == 0) m->ev_fwd++; m->ev_seen_f++; }
   return x.rc;
 }
 
@@ -1077,7 +1079,7 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
     }
     if (x.rc) return x.rc;
   }
-  if (!m->ev.empty()) m->ev_bwd++;
+  if (!m->ev.empty()) { if (m->ev_seen_b % m->ev_stride == 0) m->ev_bwd++; m->ev_seen_b++; }
   if (!x.rc) x.rc = side_join(m, stream);      // every gradient is complete on `stream` when backward returns
   return x.rc;
 }
@@ -1085,7 +1087,12 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
 extern "C" int mmda_misa_timing_end(mmda_misa* m) {
   if (!m) return MMDA_EINVAL;
   for (hipEvent_t e : m->ev) (void)hipEventDestroy(e);
-  m->ev.clear(); m->ev_steps = m->ev_fwd = m->ev_bwd = 0;
+  m->ev.clear(); m->ev_steps = m->ev_fwd = m->ev_bwd = 0; m->ev_seen_f = m->ev_seen_b = 0;
+  return MMDA_OK;
+}
+extern "C" int mmda_misa_timing_stride(mmda_misa* m, int stride) {
+  if (!m || stride < 1) return MMDA_EINVAL;
+  m->ev_stride = stride;
   return MMDA_OK;
 }
 extern "C" int mmda_misa_timing_begin(mmda_misa* m, int max_steps) {
