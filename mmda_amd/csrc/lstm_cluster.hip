@@ -396,6 +396,31 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_cluster_kernel(CLaunch L) {
   }
 }
 
+// Pipelined flag poll of the wave-autonomous kernels: lane tau watches the flag of hidden tile tau.  A flag read is a ~1 us
+// round trip to memory; with one read in flight the wait is quantised to that round trip (half of it lost on average), so
+// four reads are kept in flight ~130 cycles apart and the oldest is examined each time round.  Returns false on timeout /
+// abort (bounded spin).
+__device__ __forceinline__ bool poll_tiles(const unsigned char* poll_flag, const unsigned char* abort_w, bool watching, unsigned need) {
+  unsigned f0 = ld_flag(poll_flag);
+  __builtin_amdgcn_s_sleep(2);
+  unsigned f1 = ld_flag(poll_flag);
+  __builtin_amdgcn_s_sleep(2);
+  unsigned f2 = ld_flag(poll_flag);
+  __builtin_amdgcn_s_sleep(2);
+  unsigned f3 = ld_flag(poll_flag);
+  for (unsigned spins = 0;; spins += 4) {
+    if (__all(!watching || (int)(f0 - need) >= 0)) return true;
+    f0 = ld_flag(poll_flag);
+    if (__all(!watching || (int)(f1 - need) >= 0)) return true;
+    f1 = ld_flag(poll_flag);
+    if (__all(!watching || (int)(f2 - need) >= 0)) return true;
+    f2 = ld_flag(poll_flag);
+    if (__all(!watching || (int)(f3 - need) >= 0)) return true;
+    f3 = ld_flag(poll_flag);
+    if (spins > SPIN_LIMIT || ((spins & 255u) == 0 && spins && ld_flag(abort_w) != 0)) return false;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ forward, wave-autonomous form
 // Same cluster, same math, no workgroup barrier and no LDS staging.  Every wave owns one (16-sample m-tile, 16-unit hidden
 // tile) for the whole sequence and runs on its own:
@@ -542,15 +567,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wave_kernel(CLaunch L) {
     if (step > 0) {
       // every hidden tile of this m-tile must have published the previous step
       const unsigned need = epoch - 1u;
-      unsigned spins = 0;
-      for (;;) {
-        const unsigned f = ld_flag(poll_flag);
-        const bool ok = lane >= nHT || (int)(f - need) >= 0;
-        if (__all(ok)) break;
-        ++spins;
-        if (spins > SPIN_LIMIT || ((spins & 255u) == 0 && ld_flag(abort_w) != 0)) { alive = false; break; }
-        __builtin_amdgcn_s_sleep(1);
-      }
+      alive = poll_tiles(poll_flag, abort_w, lane < nHT, need);
       if (!alive) { if (lane == 0) st_flag(abort_w, 1u); return; }
       STAMP(0);
       const unsigned par = (need & 1u) * slot_b;
@@ -1002,6 +1019,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
   const unsigned pub_base = (unsigned)(((mt * nHT + ht) * 64 + lane) * 8);                // + consumer tile nt * (2 * nHT * 512)
   const unsigned pub_stride = (unsigned)(2 * nHT) * 512u;
 
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last = 0;
+#define STAMP(i) do { if (L.dbg && tid == 0) { unsigned long long now_ = __builtin_readcyclecounter(); ph[i] += now_ - last; last = now_; } } while (0)
+  if (L.dbg && tid == 0) last = __builtin_readcyclecounter();
   bool alive = true;
   float dgv[4][4];                                      // fp32 dG of the previous step, stored behind the next step's gather loads
   auto flush = [&](int ps, Stash& Sp) {
@@ -1025,22 +1045,16 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
     float dh_rec[4] = {0.f, 0.f, 0.f, 0.f};
     if (step > 0) {
       const unsigned need = epoch - 1u;
-      unsigned spins = 0;
-      for (;;) {
-        const unsigned f = ld_flag(poll_flag);
-        const bool ok = lane >= nHT || (int)(f - need) >= 0;
-        if (__all(ok)) break;
-        ++spins;
-        if (spins > SPIN_LIMIT || ((spins & 255u) == 0 && ld_flag(abort_w) != 0)) { alive = false; break; }
-        __builtin_amdgcn_s_sleep(1);
-      }
+      alive = poll_tiles(poll_flag, abort_w, lane < nHT, need);
       if (!alive) { if (lane == 0) st_flag(abort_w, 1u); return; }
+      STAMP(0);
       const unsigned par = (need & 1u) * slot_b;
       u32x2 gv[NTM];
 #pragma unroll
       for (int p = 0; p < NTM; ++p)
         gv[p] = __builtin_amdgcn_raw_buffer_load_b64(xr, p < nHT ? par + gat_base + (unsigned)p * 512u : OOB, 0, 16);
       flush(step - 1, Sp);
+      STAMP(1);
 #pragma unroll
       for (int p = 0; p < NTM; ++p) {
         dh_rec[0] += __builtin_bit_cast(float, gv[p][0] << 16);
@@ -1049,6 +1063,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
         dh_rec[3] += __builtin_bit_cast(float, gv[p][1] & 0xffff0000u);
       }
     }
+    if (L.dbg) { asm volatile("s_nop 0" :: "v"(dh_rec[0]), "v"(dh_rec[1]), "v"(dh_rec[2]), "v"(dh_rec[3])); STAMP(2); }
     // lane-local gate gradients of the own hidden units (branch-free)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -1072,6 +1087,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
     }
     if (step + 1 < T) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the dG tile is complete in the wave-private LDS block
+      STAMP(3);
       // A fragments of the two k-steps (gate pairs): row fr, 8 consecutive k at 32 ks2 + 8 fq
       const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&Tr[fr * 64 + fq * 8]);
       const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&Tr[fr * 64 + 32 + fq * 8]);
@@ -1087,7 +1103,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
           __builtin_amdgcn_raw_buffer_store_b64(pk, xr, par + pub_base + (unsigned)nt * pub_stride, 0, 16);
         }
       }
+      STAMP(4);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's write-through stores have landed
+      STAMP(5);
       if (lane == 0) st_flag(my_flag, epoch);
     }
   };
@@ -1100,6 +1118,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
     if (step < T && alive) { do_step(step, sb[0], sb[1]); ++step; }
     if (alive && T > 0) flush(T - 1, (T - 1) & 1 ? sb[1] : sb[0]);
   }
+  if (L.dbg && tid == 0)
+    for (int i = 0; i < 8; ++i) L.dbg[(size_t)role * 8 + i] = ph[i];
+#undef STAMP
 }
 
 struct Plan { int TPW, NC, maxtw; size_t lds_f, lds_b; bool ok; };
@@ -1208,7 +1229,7 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
   for (int g0 = 0; g0 < ngt; g0 += groups_per_launch) {
     CLaunch L;
     L.n = n; L.B = B; L.T = T; L.g0 = g0; L.ng = (ngt - g0) < groups_per_launch ? (ngt - g0) : groups_per_launch;
-    L.lengths = lengths; L.epoch_base = descs[0].epoch_base; L.dbg = bwd ? nullptr : g_dbg;
+    L.lengths = lengths; L.epoch_base = descs[0].epoch_base; L.dbg = g_dbg;
     L.gate_minor = descs[0].gate_minor ? 1 : 0;
     L.wpb = wpb;
     int wg = 0;
