@@ -247,6 +247,7 @@ int64_t layout(mmda_misa* m, int B, int T, bool commit) {
     t["d_recon"] = m->d_recon; t["d_dom"] = m->d_dom;
     t["pub_begin"] = pub_begin; t["pub_end"] = pub_end; t["zero_begin"] = m->zero_begin; t["zero_end"] = m->zero_end;
     t["hseq1_t"] = m->mod[0].hseq[0]; t["hseq1_v"] = m->mod[1].hseq[0]; t["hseq1_a"] = m->mod[2].hseq[0];
+    t["d_x_t"] = m->mod[0].d_x;      // gradient w.r.t. the gathered embedding rows (T*B, d_t): the sparse form of embed.weight.grad
   }
   return k.cur;
 }

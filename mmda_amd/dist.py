@@ -16,13 +16,17 @@ import torch.distributed as dist
 
 
 class DataParallelSync:
-    def __init__(self, group=None, bucket_mb: float = 0.0):
+    def __init__(self, group=None, bucket_mb: float = 0.0, sparse_embedding: bool = False):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.bucket_floats = int(bucket_mb * (1 << 20) / 4) if bucket_mb > 0 else 0
+        # Opt-in: exchange the embedding gradient as (ids, rows) instead of all-reducing V x d_t.  Less traffic (1.9 MB per rank
+        # against 24 MB at V = 20 000), but every rank then scatter-adds with float atomics in its own order, so replicas agree
+        # only to rounding, not bit for bit as after an all-reduce.  Default: the dense, bit-identical exchange.
+        self.sparse_embedding = bool(sparse_embedding)
 
     def broadcast_parameters(self, model):
         """Rank 0's weights everywhere (one broadcast of the flat bucket when the model has one)."""
@@ -47,12 +51,51 @@ class DataParallelSync:
             return None
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
-    def sync(self, flat_grads: torch.Tensor, dense_floats: int) -> float:
+    def _all_gather(self, t: torch.Tensor) -> torch.Tensor:
+        """(world, *t.shape) gathered from every rank (equal shapes; t has at least one dimension)."""
+        flat_shape = (self.world * t.shape[0],) + tuple(t.shape[1:])      # concatenation along dim 0: the form every backend takes
+        if t.is_cuda and dist.get_backend(self.group) == "gloo":
+            h = torch.empty(flat_shape, dtype=t.dtype)
+            dist.all_gather_into_tensor(h, t.cpu().contiguous(), group=self.group)
+            out = h.to(t.device)
+        else:
+            out = torch.empty(flat_shape, dtype=t.dtype, device=t.device)
+            dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+        return out.view((self.world,) + tuple(t.shape))
+
+    def _sync_sparse_embedding(self, flat_grads: torch.Tensor, dense_floats: int, model) -> None:
+        """Dense prefix: one all-reduce.  Embedding gradient: every rank's (ids, rows) are all-gathered and the other ranks'
+        rows scatter-added into the local dense gradient (which already holds the local rows) -- 2 * T*B*d_t*4 bytes per
+        rank on the wire instead of an all-reduce of V*d_t*4 (1.9 MB against 24 MB at MOSEI sizes, V = 20 000)."""
+        self._all_reduce(flat_grads[:dense_floats])
+        ids, rows = model.embedding_grad_rows()
+        # ranks may hold batches of different length: agree on the row count, pad with (id 0, zero row)
+        n = torch.tensor([ids.numel()], dtype=torch.int64, device=ids.device)
+        counts = self._all_gather(n).view(-1).tolist()
+        cap = max(counts)
+        if ids.numel() < cap:
+            pad = cap - ids.numel()
+            ids = torch.cat([ids, ids.new_zeros(pad)])
+            rows = torch.cat([rows, rows.new_zeros(pad, rows.shape[1])])
+        all_ids = self._all_gather(ids)               # (world, cap)
+        all_rows = self._all_gather(rows)             # (world, cap, d_t)
+        if self.rank > 0:
+            model.scatter_embedding_rows(all_ids[:self.rank].reshape(-1), all_rows[:self.rank].reshape(-1, rows.shape[1]))
+        if self.rank + 1 < self.world:
+            model.scatter_embedding_rows(all_ids[self.rank + 1:].reshape(-1), all_rows[self.rank + 1:].reshape(-1, rows.shape[1]))
+
+    def sync(self, flat_grads: torch.Tensor, dense_floats: int, model=None) -> float:
         """All-reduce(sum) the gradient bucket in place; returns the scale (1/world) the optimizer applies.
+        With ``sparse_embedding=True`` and a model that exposes ``embedding_grad_rows`` the embedding gradient travels in its
+        sparse form (see __init__).
         With bucket_floats > 0 the bucket is cut into chunks so the first all-reduce can start while later chunks are
         still being enqueued (xGMI rings are per-link bound; >=8 MB chunks keep them at bandwidth)."""
         if self.world == 1:
             return 1.0
+        if model is not None and self.sparse_embedding and hasattr(model, "embedding_grad_rows") \
+                and dense_floats < flat_grads.numel():
+            self._sync_sparse_embedding(flat_grads, dense_floats, model)
+            return 1.0 / self.world
         n = flat_grads.numel()
         if self.bucket_floats <= 0 or self.bucket_floats >= n:
             self._all_reduce(flat_grads)

@@ -357,7 +357,7 @@ class MISA(nn.Module):
     def train_step(self, sentences, video, acoustic, lengths, emo_label, lr: float, clip: float, do_adam: bool = True,
                    training: bool = True, seed=None, grad_sync=None):
         """One reference loop iteration (solver.py:139-186) in native code: zero_grad, forward, six losses, backward,
-        clip + Adam.  ``grad_sync(flat_grad_bucket, dense_floats)`` is called between backward and Adam for the
+        clip + Adam.  ``grad_sync(flat_grad_bucket, dense_floats, model)`` is called between backward and Adam for the
         data-parallel all-reduce (mmda_amd/dist.py) and must return the gradient scale (1/world).
         Losses stay on the device (read them with ``read_losses()``; one sync, not six)."""
         t, v, a, len_dev = self._prepare(sentences, video, acoustic, lengths)
@@ -373,8 +373,28 @@ class MISA(nn.Module):
         self._fwd_id += 1
         self._last = dict(t=t, v=v, a=a, len_dev=len_dev, emo=emo)
         if do_adam and grad_sync is not None:
-            scale = grad_sync(self._G, self._dense_floats)
+            try:
+                scale = grad_sync(self._G, self._dense_floats, self)
+            except TypeError:                       # a plain (bucket, dense_floats) callable
+                scale = grad_sync(self._G, self._dense_floats)
             _lib.check(self._lib.mmda_misa_adam_step(self._h, lr, clip, float(scale), self._step, s), "adam_step")
+
+    # ------------------------------------------------------------------ sparse view of the embedding gradient (data parallel)
+    def embedding_grad_rows(self):
+        """(ids (R,) int64, rows (R, d_t) fp32) of the last backward: embed.weight.grad == scatter_add(ids, rows).  The dense
+        gradient is non-zero in at most R = T*B of its V rows, so data-parallel ranks exchange these instead of V x d_t."""
+        t = self._last["t"]
+        R = t.numel()
+        return t.reshape(R), self._ws_view("d_x_t", (R, self._layout["embed.weight"][1][1]))
+
+    def scatter_embedding_rows(self, ids: torch.Tensor, rows: torch.Tensor):
+        """embed.weight.grad[ids] += rows (other ranks' contributions), with the native dense scatter-add."""
+        if ids.numel() == 0:
+            return
+        off, (V, D) = self._layout["embed.weight"]
+        g = self._G[off:off + V * D]
+        _lib.check(self._lib.mmda_embed_scatter_add(g.data_ptr(), ids.contiguous().data_ptr(), ids.numel(), D,
+                                                    rows.contiguous().data_ptr(), _lib.stream_ptr()), "embed_scatter_add")
 
     def read_losses(self) -> Dict[str, float]:
         """cls, diff, sim, recon, conf, total of the last losses pass (one device->host sync)."""

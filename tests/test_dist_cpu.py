@@ -69,3 +69,54 @@ def test_flat_bucket_allreduce_world2_single_bucket():
 
 def test_flat_bucket_allreduce_world2_chunked():
     _run(0.1)
+
+
+def _sparse_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dp = DataParallelSync(sparse_embedding=True)
+        n_dense, V, D = 1003, 40, 6
+        R = 7 + 3 * rank                              # ranks hold batches of different length: the exchange pads
+        g = torch.Generator().manual_seed(200 + rank)
+        ids = torch.randint(0, V, (R,), generator=g)
+        rows = torch.randn(R, D, generator=g)
+        dense = torch.randn(n_dense, generator=g)
+
+        class FakeModel:                              # the two hooks of mmda_amd.models.MISA that the sparse exchange uses
+            def __init__(self):
+                self.G = torch.cat([dense, torch.zeros(V * D).index_add_(0, (ids[:, None] * D + torch.arange(D)).reshape(-1), rows.reshape(-1))])
+            def embedding_grad_rows(self): return ids, rows
+            def scatter_embedding_rows(self, i, r):
+                self.G[n_dense:].index_add_(0, (i[:, None] * D + torch.arange(D)).reshape(-1), r.reshape(-1))
+        m = FakeModel()
+        scale = dp.sync(m.G, n_dense, m)
+        # oracle: sum over ranks of the DENSE gradients
+        exp = torch.zeros(n_dense + V * D)
+        for r in range(world):
+            gg = torch.Generator().manual_seed(200 + r)
+            Rr = 7 + 3 * r
+            i2 = torch.randint(0, V, (Rr,), generator=gg); r2 = torch.randn(Rr, D, generator=gg); d2 = torch.randn(n_dense, generator=gg)
+            exp[:n_dense] += d2
+            exp[n_dense:].index_add_(0, (i2[:, None] * D + torch.arange(D)).reshape(-1), r2.reshape(-1))
+        q.put((rank, torch.allclose(m.G, exp, atol=1e-5), abs(scale - 1.0 / world) < 1e-12))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sparse_embedding_exchange_world2_ragged_shards():
+    """opt-in sparse form: dense prefix all-reduced, embedding gradient as all-gathered (ids, rows) with padding to the longest
+    shard -- the result must equal the all-reduce of the dense gradients."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sparse_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in res:
+        assert all(r[1:]), r
