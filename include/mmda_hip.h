@@ -283,6 +283,11 @@ int mmda_loss_misc(const float* scores, const float* tcp, const float* emo, int 
                    int with_conf, int conf_grads, float conf_scale, const float* recon, const float* orig, int64_t n_recon,
                    float recon_scale, float* d_recon, float* d_orig, float* L, float diff_w, float sim_w, float recon_w,
                    float conf_w, int use_conf, void* stream);
+/* Evaluation counts on the device (reference utils/eval.py:14-31 get_accuracy and the tp/fp/fn that sklearn's
+ * f1/precision/recall in get_metrics :33-65 are functions of), ACCUMULATED into `state` = 3*C + 2 doubles (zeroed by the caller
+ * before the first batch): tp[C], fp[C], fn[C], sum_i |y_i & p_i| / max(|y_i | p_i|, 1), number of samples.  pred / truth are
+ * (N, C) fp32, an entry counts as set when > 0.  C <= 16.  One read-back per evaluation pass instead of one per batch. */
+int mmda_eval_accumulate(const float* pred, const float* truth, int N, int C, double* state, void* stream);
 int mmda_loss_domain(const float* dom, int B, float scale, float* loss, float* ddom, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- optimizer

@@ -130,6 +130,7 @@ SIGNATURES = {
     "mmda_loss_cmd": (_I, [_P, _I64, _I, _I, _F, _P, _P, _P]),
     "mmda_loss_recon": (_I, [_P, _P, _I64, _I, _I, _F, _P, _P, _P, _P]),
     "mmda_loss_misc": (_I, [_P, _P, _P, _I, _I, _P, _P, _I, _I, _F, _P, _P, _I64, _F, _P, _P, _P, _F, _F, _F, _F, _I, _P]),
+    "mmda_eval_accumulate": (_I, [_P, _P, _I, _I, _P, _P]),
     "mmda_loss_domain": (_I, [_P, _I, _F, _P, _P, _P]),
     "mmda_clamp_adam": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _I, _P]),
     "mmda_clamp": (_I, [_P, _I64, _F, _P]),

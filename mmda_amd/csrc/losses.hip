@@ -613,6 +613,47 @@ __global__ __launch_bounds__(256) void domain_kernel(const float* __restrict__ d
   if (threadIdx.x == 0 && loss) atomicAdd(loss, t / rows);
 }
 
+// ------------------------------------------------------------------------------------------------ evaluation counts
+// Per-class tp / fp / fn over (pred > 0, truth > 0) and the Jaccard-style accuracy sum of the reference's get_accuracy
+// (utils/eval.py:14-31), accumulated into a device state so that an evaluation pass over many batches needs one read-back:
+//   state[0..C) tp, [C..2C) fp, [2C..3C) fn, [3C] sum_i |y_i & p_i| / max(|y_i | p_i|, 1), [3C+1] samples      (doubles)
+constexpr int EVAL_MAXC = 16;
+__global__ __launch_bounds__(256) void eval_counts_kernel(const float* __restrict__ pred, const float* __restrict__ truth, int N, int C,
+                                                          double* state) {
+  double tp[EVAL_MAXC], fp[EVAL_MAXC], fn[EVAL_MAXC];
+#pragma unroll
+  for (int c = 0; c < EVAL_MAXC; ++c) { tp[c] = 0.0; fp[c] = 0.0; fn[c] = 0.0; }
+  double jac = 0.0, cnt = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+    int inter = 0, uni = 0;
+#pragma unroll
+    for (int c = 0; c < EVAL_MAXC; ++c) {
+      if (c < C) {
+        const bool y = truth[(int64_t)i * C + c] > 0.f, p = pred[(int64_t)i * C + c] > 0.f;
+        tp[c] += (y && p) ? 1.0 : 0.0; fp[c] += (!y && p) ? 1.0 : 0.0; fn[c] += (y && !p) ? 1.0 : 0.0;
+        inter += (y && p) ? 1 : 0; uni += (y || p) ? 1 : 0;
+      }
+    }
+    jac += (double)inter / (double)(uni > 0 ? uni : 1);
+    cnt += 1.0;
+  }
+  auto wsum = [](double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+  };
+  const bool lead = (threadIdx.x & 63) == 0;
+#pragma unroll
+  for (int c = 0; c < EVAL_MAXC; ++c) {
+    if (c < C) {
+      const double a = wsum(tp[c]), b = wsum(fp[c]), d = wsum(fn[c]);
+      if (lead) { if (a != 0.0) atomicAdd(&state[c], a); if (b != 0.0) atomicAdd(&state[C + c], b); if (d != 0.0) atomicAdd(&state[2 * C + c], d); }
+    }
+  }
+  jac = wsum(jac); cnt = wsum(cnt);
+  if (lead && cnt != 0.0) { atomicAdd(&state[3 * C], jac); atomicAdd(&state[3 * C + 1], cnt); }
+}
+
 }  // namespace
 
 extern "C" int mmda_heads_fwd(const float* logits, int B, int ncls, float threshold, float* tcp, float* scores, float* labels,
@@ -806,6 +847,15 @@ extern "C" int mmda_loss_misc(const float* scores, const float* tcp, const float
   const int blocks = 1 + (with_conf ? ncls : 0) + rb;
   hipLaunchKernelGGL(misc_losses_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
   MMDA_CHECK_LAUNCH("mmda_loss_misc");
+  return MMDA_OK;
+}
+
+extern "C" int mmda_eval_accumulate(const float* pred, const float* truth, int N, int C, double* state, void* stream) {
+  if (!pred || !truth || !state || N < 0 || C <= 0 || C > EVAL_MAXC || ((uintptr_t)state & 7)) return MMDA_EINVAL;
+  if (N == 0) return MMDA_OK;
+  int blocks = (N + 255) / 256; if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(eval_counts_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pred, truth, N, C, state);
+  MMDA_CHECK_LAUNCH("mmda_eval_accumulate");
   return MMDA_OK;
 }
 

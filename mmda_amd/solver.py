@@ -23,14 +23,7 @@ from .utils import to_gpu, to_cpu, set_device
 from .utils import functions as F
 
 
-def get_accuracy(y, y_pre):
-    """Multi-label Jaccard-style accuracy (reference utils/eval.py:14-31), vectorised."""
-    y = np.asarray(y) > 0
-    p = np.asarray(y_pre) > 0
-    inter = (y & p).sum(axis=1).astype(np.float64)
-    union = (y | p).sum(axis=1).astype(np.float64)
-    union[union <= 0] = 1.0
-    return round(float((inter / union).mean()), 4)
+from .utils.eval import get_accuracy, get_metrics, DeviceEval      # reference utils/eval.py
 
 
 class Solver(object):
@@ -158,6 +151,9 @@ class Solver(object):
             path = f"checkpoints/model_{self.train_config.name}.std"
             if os.path.exists(path):
                 self.model.load_state_dict(torch.load(path, weights_only=True))
+        # Device-side evaluation: predictions, the per-batch classification loss and the metric counts stay on the GPU; one
+        # read-back at the end of the pass instead of three per batch (solver.py:350-360 calls .item()/.cpu() per batch).
+        acc_dev = None
         with torch.no_grad():
             for batch in dataloader:
                 t, v, a, y, emo_label, l, bert_sent, bert_sent_type, bert_sent_mask, ids = batch
@@ -165,12 +161,22 @@ class Solver(object):
                 l = to_cpu(l)
                 predicted_scores, predicted_labels = self.model(t, v, a, l, bert_sent, bert_sent_type, bert_sent_mask)
                 emo_label = emo_label.type(torch.float)
-                eval_loss.append(self.get_cls_loss(predicted_scores, emo_label).item())
-                y_pred.append(predicted_labels.detach().cpu().numpy())
-                y_true.append(emo_label.detach().cpu().numpy())
+                if predicted_labels.is_cuda:
+                    if acc_dev is None:
+                        acc_dev = DeviceEval(predicted_labels.shape[1], predicted_labels.device)
+                    acc_dev.update(predicted_labels, emo_label)
+                    acc_dev.add_cls_loss(predicted_scores, emo_label)
+                else:
+                    eval_loss.append(self.get_cls_loss(predicted_scores, emo_label).item())
+                y_pred.append(predicted_labels.detach())
+                y_true.append(emo_label.detach())
+        y_true = torch.cat(y_true, 0).cpu().numpy().squeeze() if y_true else np.zeros((0,))
+        y_pred = torch.cat(y_pred, 0).cpu().numpy().squeeze() if y_pred else np.zeros((0,))
+        if acc_dev is not None:
+            loss, acc, self.last_eval_metrics = acc_dev.result()
+            return loss, acc, y_pred, y_true
         eval_loss = float(np.mean(eval_loss)) if eval_loss else 0.0
-        y_true = np.concatenate(y_true, axis=0).squeeze()
-        y_pred = np.concatenate(y_pred, axis=0).squeeze()
+        self.last_eval_metrics = get_metrics(y_true, y_pred)
         return eval_loss, get_accuracy(y_true, y_pred), y_pred, y_true
 
     # ------------------------------------------------------------------ getters (solver.py:373-462)

@@ -301,3 +301,34 @@ def test_cpu_inputs_fail_loudly():
     m = MISA(make_config(vocab_size=50))
     with pytest.raises(_lib.MMDAError):
         m(torch.zeros(3, 2, dtype=torch.long), torch.zeros(3, 2, 35), torch.zeros(3, 2, 74), torch.tensor([3, 2]))
+
+
+def test_solver_eval_device_side_metrics_match_oracle_forward():
+    """Solver.eval over three ragged batches (reference solver.py:311-370): the loss is the mean of the per-batch classification
+    losses and the accuracy / P-R-F1 come from counts accumulated on the device -- compared with the oracle's forward on the
+    same parameters and with the host metric functions on the returned arrays."""
+    from mmda_amd import make_config, MISA
+    from mmda_amd.solver import Solver
+    from mmda_amd.data import SyntheticLoader
+    from mmda_amd.utils.eval import get_metrics, get_accuracy
+    cfg = orc.default_config(vocab_size=90)
+    P = orc.synth_params(cfg, 5)
+    c = make_config(device=DEV, precision="fp32", **vars(cfg))
+    m = MISA(c); m.load_state_dict(P); m.to(DEV)
+    loader = SyntheticLoader(c, 3, 5, 7, seed=3, ragged=True, device="cpu")
+    s = Solver(c, c, c, None, loader, loader, is_train=False, model=m)
+    loss, acc, y_pred, y_true = s.eval(mode="dev")
+    # oracle forward per batch
+    losses, preds, truths = [], [], []
+    for (t, v, a, y, emo, l, *_) in loader:
+        out = orc.forward(P, cfg, t, v, a, l)
+        losses.append(float(orc.cls_loss(out.scores, emo.float())))
+        preds.append((out.scores > cfg.threshold).float().numpy()); truths.append(emo.float().numpy())
+    assert abs(loss - float(np.mean(losses))) < 1e-4 * max(1.0, abs(float(np.mean(losses))))
+    yp, yt = np.concatenate(preds), np.concatenate(truths)
+    assert np.array_equal(y_true, yt)
+    assert (y_pred == yp).mean() > 0.99                   # a score within rounding of the 0.35 threshold may flip
+    assert acc == get_accuracy(y_true, y_pred)
+    ref = get_metrics(y_true, y_pred)
+    for k, vv in s.last_eval_metrics.items():
+        assert abs(vv - ref[k]) < 1e-12, k

@@ -640,3 +640,32 @@ def test_dropout_rng_statistics_and_replay():
     k = (h > 0).float()
     c = ((k[1:] - k.mean()) * (k[:-1] - k.mean())).mean().item()
     assert abs(c) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ evaluation metrics on the device
+def test_device_eval_counts_match_reference_golden():
+    """mmda_eval_accumulate over the batches of an evaluation pass -> accuracy and the nine P/R/F1 figures of the reference's
+    get_metrics (golden vectors from src/utils/eval.py), exact counts, one read-back."""
+    import os
+    from mmda_amd.utils.eval import DeviceEval, KEYS
+    from oracle import eval_oracle as ev
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "eval_metrics.npz"))
+    for c in sorted({k.split("/")[0] for k in G.files if "/" in k}):
+        y = torch.from_numpy(G[c + "/y"]).to(dev()); p = torch.from_numpy(G[c + "/pred"]).to(dev())
+        acc = DeviceEval(y.shape[1], dev())
+        for s in range(0, y.shape[0], 50):                      # ragged last batch
+            acc.update(p[s:s + 50], y[s:s + 50])
+        _, a, m = acc.result()
+        for k, r in zip(KEYS, G[c + "/metrics"]):
+            assert abs(m[k] - r) < 1e-12, (c, k, m[k], r)
+        assert a == G[c + "/metrics"][0] == ev.get_accuracy(G[c + "/y"], G[c + "/pred"])
+    # full-size property check: 2**18 samples, counts are exact integers and add up
+    torch.manual_seed(0)
+    N = 1 << 18
+    y = (torch.rand(N, 6, device=dev()) > 0.7).float(); p = (torch.rand(N, 6, device=dev()) > 0.6).float()
+    acc = DeviceEval(6, dev()); acc.update(p, y)
+    st = acc.state.cpu().numpy()
+    tp, fp, fn = st[:6], st[6:12], st[12:18]
+    assert np.array_equal(tp, ((y > 0) & (p > 0)).sum(0).cpu().numpy().astype(np.float64))
+    assert np.array_equal(tp + fn, (y > 0).sum(0).cpu().numpy().astype(np.float64))
+    assert np.array_equal(tp + fp, (p > 0).sum(0).cpu().numpy().astype(np.float64)) and st[19] == N

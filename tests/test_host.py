@@ -116,3 +116,18 @@ def test_solver_surface_exists():
     c = make_config(vocab_size=20)
     s = Solver(c, c, c, None, None, None, is_train=True, model=None)
     assert s.get_domain_loss() == 0.0          # python float when use_cmd_sim (solver.py:390-391)
+
+
+def test_eval_metrics_host_match_reference_golden():
+    """mmda_amd.utils.eval.get_accuracy / get_metrics (the product's host forms) against outputs of the reference's
+    src/utils/eval.py (tests/golden/eval_metrics.npz)."""
+    import os
+    import numpy as np
+    from mmda_amd.utils import eval as E
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "eval_metrics.npz"))
+    assert list(G["keys"]) == E.KEYS
+    for c in sorted({k.split("/")[0] for k in G.files if "/" in k}):
+        m = E.get_metrics(G[c + "/y"], G[c + "/pred"])
+        for k, r in zip(E.KEYS, G[c + "/metrics"]):
+            assert abs(m[k] - r) < 1e-12, (c, k)
+        assert E.get_accuracy(G[c + "/y"], G[c + "/pred"]) == G[c + "/metrics"][0]
