@@ -209,6 +209,9 @@ typedef struct mmda_lstm_desc {
                           gates of one hidden unit are 16 contiguous bytes: the resident-weights kernels then move them with one
                           16-byte access instead of four 4-byte ones (the address unit, shared by the CU's four waves, is what
                           their per-step stash traffic is bound by).  Only the resident-weights kernels accept 1. */
+  int forward_only;    /* forward: 1 = no backward pass will follow (evaluation): the activated gates and the cell states need not be
+                          stashed; `gates` / `cstash` contents are then unspecified after the call.  hseq and utt are written as usual.
+                          Honoured by the wave-autonomous kernel, ignored (stash written) by the others. */
 } mmda_lstm_desc;
 int64_t mmda_lstm_xchg_bytes(int H, int B);
 /* 1 if mmda_lstm_fwd/bwd would run these descriptors on the resident-weights kernels (so gate_minor = 1 may be used), else 0 */
@@ -339,6 +342,10 @@ int mmda_misa_set_recurrence(mmda_misa* m, int resident_weights);
 /* bf16 mode only: 1 (default) = the LSTM-sized GEMMs read bf16 operand copies made by mmda_convert_bf16 (gemm_bf16.hip);
  * 0 = they stage the fp32 tensors through the generic kernel (same rounding of the operands, different summation order). */
 int mmda_misa_set_gemm_operands(mmda_misa* m, int bf16_copies);
+/* 1 = forward passes are evaluation passes (no backward follows): the recurrences skip their stash stores and the transposed
+ * bf16 copies that only the weight-gradient GEMMs read are not made.  Default 0.  mmda_misa_backward after a forward in this mode
+ * returns MMDA_EINVAL. */
+int mmda_misa_set_inference(mmda_misa* m, int forward_only);
 /* 1 (default) = weight-gradient GEMMs run on an internal side stream underneath the recurrent kernels (joined before
  * mmda_misa_backward returns control of `stream`); 0 = everything on `stream` */
 int mmda_misa_set_overlap(mmda_misa* m, int side_stream);

@@ -73,7 +73,7 @@ class LnBwdArgs(C.Structure):
 class LstmDesc(C.Structure):
     _fields_ = [("H", C.c_int), ("gates", C.c_void_p), ("cstash", C.c_void_p), ("hseq", C.c_void_p),
                 ("wpack", C.c_void_p * 2), ("wpack_c", C.c_void_p * 2), ("utt", C.c_void_p), ("layer", C.c_int), ("d_hseq", C.c_void_p),
-                ("xchg", C.c_void_p), ("epoch_base", C.c_uint32), ("gate_minor", C.c_int)]
+                ("xchg", C.c_void_p), ("epoch_base", C.c_uint32), ("gate_minor", C.c_int), ("forward_only", C.c_int)]
 
 
 class MisaConfig(C.Structure):
@@ -148,6 +148,7 @@ SIGNATURES = {
     "mmda_misa_set_overlap": (_I, [_P, _I]),
     "mmda_misa_set_recurrence": (_I, [_P, _I]),
     "mmda_misa_set_gemm_operands": (_I, [_P, _I]),
+    "mmda_misa_set_inference": (_I, [_P, _I]),
     "mmda_misa_cluster_status": (_I, [_P, C.POINTER(_I)]),
     "mmda_misa_forward": (_I, [_P, _P, _P, _P, _P, _I, _U64, _P]),
     "mmda_misa_losses": (_I, [_P, _P, _I, _P]),

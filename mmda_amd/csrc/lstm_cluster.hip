@@ -53,6 +53,7 @@ struct CLaunch {
   int gate_minor;                    // `gates` columns are [dir][unit][gate]: 16-byte accesses (see mmda_lstm_desc)
   int xcd_local;                     // EXPERIMENT: publish with plain stores (valid only when a cluster shares one XCD)
   int wpb;                           // wave-autonomous forward: waves per block (1, 2 or 4)
+  int no_stash;                      // forward only (evaluation): gates / cell states are not stashed
   short blk2role[256];               // blockIdx -> linear role (-1: no role, exit at once); roles of one cluster share blockIdx % 8
 };
 
@@ -545,14 +546,16 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wave_kernel(CLaunch L) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool act = t < len_r[r];
-      const unsigned o = act ? og[r] + (unsigned)t * sg : OOB;
-      if (gm) {
-        stf4(rg, o, f32x4{sv[r][0], sv[r][1], sv[r][2], sv[r][3]});
-      } else {
-        stf(rg, o, sv[r][0]); stf(rg, act ? o + H * 4u : OOB, sv[r][1]); stf(rg, act ? o + 2u * H * 4u : OOB, sv[r][2]);
-        stf(rg, act ? o + 3u * H * 4u : OOB, sv[r][3]);
+      const unsigned o = (act && !L.no_stash) ? og[r] + (unsigned)t * sg : OOB;
+      if (!L.no_stash) {                                 // launch-uniform
+        if (gm) {
+          stf4(rg, o, f32x4{sv[r][0], sv[r][1], sv[r][2], sv[r][3]});
+        } else {
+          stf(rg, o, sv[r][0]); stf(rg, act ? o + H * 4u : OOB, sv[r][1]); stf(rg, act ? o + 2u * H * 4u : OOB, sv[r][2]);
+          stf(rg, act ? o + 3u * H * 4u : OOB, sv[r][3]);
+        }
+        stf(rc, act ? oc[r] + (unsigned)t * sc : OOB, sv[r][4]);
       }
-      stf(rc, act ? oc[r] + (unsigned)t * sc : OOB, sv[r][4]);
       stf(rh, inb[r] ? oh[r] + (unsigned)t * sc : OOB, sv[r][5]);     // zero at padded positions (pad_packed_sequence)
     }
     load_pre(Pp, ps + 2);
@@ -1232,6 +1235,8 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
     L.lengths = lengths; L.epoch_base = descs[0].epoch_base; L.dbg = g_dbg;
     L.gate_minor = descs[0].gate_minor ? 1 : 0;
     L.wpb = wpb;
+    L.no_stash = 1;
+    for (int i = 0; i < n; ++i) L.no_stash = L.no_stash && descs[i].forward_only;
     int wg = 0;
     for (int i = 0; i < MAXD; ++i) {
       const mmda_lstm_desc& d = descs[i < n ? i : 0];

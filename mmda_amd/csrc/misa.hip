@@ -67,6 +67,7 @@ struct mmda_misa {
   int use_cluster = 1, packed_c_valid = 0;
   int use_bf16_gemm = 1;           // bf16 mode: LSTM-sized GEMMs read bf16 operand copies (gemm_bf16.hip)
   int gate_minor = 0;              // layout of `gates` chosen by the last forward (see mmda_lstm_desc.gate_minor)
+  int inference = 0, last_fwd_inference = 0;   // evaluation passes: no stash, no copies that only the backward pass reads
   int ldR = 0;
   std::vector<hipEvent_t> ev;      // [step][slot][start/stop]
   int ev_steps = 0, ev_fwd = 0, ev_bwd = 0;
@@ -447,6 +448,11 @@ extern "C" int mmda_misa_set_gemm_operands(mmda_misa* m, int bf16_copies) {
   m->use_bf16_gemm = bf16_copies ? 1 : 0;
   return MMDA_OK;
 }
+extern "C" int mmda_misa_set_inference(mmda_misa* m, int forward_only) {
+  if (!m) return MMDA_EINVAL;
+  m->inference = forward_only ? 1 : 0;
+  return MMDA_OK;
+}
 extern "C" int mmda_misa_cluster_status(const mmda_misa* m, int* aborted_host) {
   // reads the sticky abort words of the three exchange buffers (device->host copy: call it off the step path)
   if (!m || !m->ws || !aborted_host) return MMDA_EINVAL;
@@ -516,17 +522,19 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
     gm = mmda_lstm_resident_applicable(mode, 3, probe, B, T, 0) && mmda_lstm_resident_applicable(mode, 3, probe, B, T, 1);
   }
   m->gate_minor = gm;
+  const bool inf = m->inference != 0;                   // no backward follows: transposed copies and stashes are not needed
+  m->last_fwd_inference = inf;
   if (bfg) {
     mmda_convert_job cj[9];
     int n = 0;
     for (int i = 0; i < 3; ++i) {
       for (int l = 0; l < 2; ++l) {
         Rnn& r = m->mod[i].rnn[l];
-        cj[n++] = mmda_convert_job{PP(r.w_ih), r.D, 8 * r.H, r.D, nullptr, WS(r.wb), r.ldD, WS(r.wbT), r.ldG, gm ? r.H : 0};
+        cj[n++] = mmda_convert_job{PP(r.w_ih), r.D, 8 * r.H, r.D, nullptr, WS(r.wb), r.ldD, inf ? nullptr : WS(r.wbT), r.ldG, gm ? r.H : 0};
       }
       Rnn& r0 = m->mod[i].rnn[0];
-      if (i == 0) cj[n++] = mmda_convert_job{PP(m->embed), c.d_t, R, c.d_t, t_ids, WS(r0.xb), r0.ldD, WS(r0.xbT), ldR};
-      else cj[n++] = mmda_convert_job{xin[i], r0.D, R, r0.D, nullptr, WS(r0.xb), r0.ldD, WS(r0.xbT), ldR};
+      if (i == 0) cj[n++] = mmda_convert_job{PP(m->embed), c.d_t, R, c.d_t, t_ids, WS(r0.xb), r0.ldD, inf ? nullptr : WS(r0.xbT), ldR};
+      else cj[n++] = mmda_convert_job{xin[i], r0.D, R, r0.D, nullptr, WS(r0.xb), r0.ldD, inf ? nullptr : WS(r0.xbT), ldR};
     }
     x.rc = mmda_convert_bf16(cj, n, stream);
   } else {
@@ -554,7 +562,7 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
       desc[i].wpack[0] = WS(r.pack_f[0]); desc[i].wpack[1] = WS(r.pack_f[1]);
       desc[i].utt = WS(md.utt); desc[i].layer = l; desc[i].d_hseq = nullptr;
       desc[i].xchg = (m->use_cluster && md.xchg >= 0) ? (void*)WS(md.xchg) : nullptr; desc[i].epoch_base = m->epoch;
-      desc[i].gate_minor = gm;
+      desc[i].gate_minor = gm; desc[i].forward_only = inf;
     }
     if (bfg && !x.rc) x.rc = mmda_gemm_bf16_grouped(bg, 3, stream);
     m->epoch += (unsigned)T + 2u;
@@ -579,12 +587,12 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
         mmda_convert_job cj[6];
         for (int i = 0; i < 3; ++i) {
           Mod& md = m->mod[i]; Rnn& r1 = md.rnn[1]; Rnn& r0 = md.rnn[0];
-          cj[i] = mmda_convert_job{WS(md.normed), 2 * md.H, R, 2 * md.H, nullptr, WS(r1.xb), r1.ldD, WS(r1.xbT), ldR};
+          cj[i] = mmda_convert_job{WS(md.normed), 2 * md.H, R, 2 * md.H, nullptr, WS(r1.xb), r1.ldD, inf ? nullptr : WS(r1.xbT), ldR};
           cj[3 + i] = mmda_convert_job{WS(md.hseq[0]), 2 * md.H, R, 2 * md.H, nullptr, nullptr, 0, WS(r0.hbT), ldR};
         }
-        x.rc = mmda_convert_bf16(cj, 6, stream);
+        x.rc = mmda_convert_bf16(cj, inf ? 3 : 6, stream);
       }
-    } else if (bfg && !x.rc) {
+    } else if (bfg && !x.rc && !inf) {
       // hseq^T of layer 2 for its dW_hh: on the side stream, beside the fusion block
       mmda_convert_job cj[3];
       for (int i = 0; i < 3; ++i) {
@@ -762,6 +770,7 @@ extern "C" int mmda_misa_zero_grad(mmda_misa* m, void* stream) {
 extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const float* v, const float* a, const int32_t* lengths,
                                   void* stream) {
   if (check_ready(m) || !m->G || !t_ids || !v || !a || !lengths) return MMDA_EINVAL;
+  if (m->last_fwd_inference) return MMDA_EINVAL;        // the last forward was an evaluation pass: nothing was stashed
   const mmda_misa_config& c = m->cfg;
   const int B = m->B, T = m->T, hs = c.hidden, mode = c.mode, NC = 6 + c.ncls;
   const int fmode = MMDA_F32;       // fusion block: exact path (see mmda_misa_forward)
@@ -1134,6 +1143,7 @@ extern "C" int mmda_misa_train_step(mmda_misa* m, const int64_t* t_ids, const fl
   // the gradient bucket is cleared on the side stream underneath the first kernels of the forward pass; forward() joins the
   // side stream (W_hh packing) before its first recurrent kernel, long before any gradient is accumulated
   if (check_ready(m)) return MMDA_EINVAL;
+  m->inference = 0;                                     // a training step always stashes
   void* ss = nullptr;
   int rc = side_fork(m, stream, &ss);
   if (rc) return rc;

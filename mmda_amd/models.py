@@ -305,7 +305,9 @@ class MISA(nn.Module):
         self._seed = (self._seed * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
         return self._seed
 
-    def _forward_raw(self, t, v, a, len_dev, training: bool, seed: int):
+    def _forward_raw(self, t, v, a, len_dev, training: bool, seed: int, inference: bool = False):
+        # inference: a forward that no backward will follow (torch.no_grad()): no stash, no backward-only operand copies
+        _lib.check(self._lib.mmda_misa_set_inference(self._h, int(inference)), "set_inference")
         _lib.check(self._lib.mmda_misa_forward(self._h, t.data_ptr(), v.data_ptr(), a.data_ptr(), len_dev.data_ptr(),
                                                int(training), seed, _lib.stream_ptr()), "mmda_misa_forward")
         self._fwd_id += 1
@@ -323,7 +325,7 @@ class MISA(nn.Module):
             named = dict(zip(_PUB, outs[:-1]))
             labels = outs[-1]
         else:
-            self._forward_raw(t, v, a, len_dev, self.training, seed)
+            self._forward_raw(t, v, a, len_dev, self.training, seed, inference=True)
             pub = self._public()
             named = {k: pub[k].clone() if k in pub else None for k in _PUB}
             labels = pub["labels"].clone()
