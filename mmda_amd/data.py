@@ -60,3 +60,97 @@ def get_loader(config, shuffle=True, n_batches=8, seed=0, ragged=True, device="c
     """Same name as the reference's factory (data_loader.py:50); synthetic data."""
     config.data_len = n_batches * config.batch_size
     return SyntheticLoader(config, n_batches, config.batch_size, getattr(config, "seq_len", 50), seed, ragged, device)
+
+
+# ---------------------------------------------------------------------------------------------- collate (reference data_loader.py:59-122)
+def collate_fn(batch, use_bert: bool = False):
+    """The reference's collate for samples ``((word_ids, visual (L,dv), acoustic (L,da), words), label (1,7) | (1,1), segment)``:
+    sort by length descending, time-major zero/PAD padding, MOSEI labels (1,7) = [sentiment, 6 emotion scores] -> ``labels``
+    (B,) sentiment and ``emo_labels`` (B,6) float32 {0,1} (score > 0), NaNs in labels replaced by 0, int64 CPU ``lengths``.
+    Vectorised: one pass per tensor instead of the reference's per-sample pad_sequence / torch.cat calls.  Without BERT
+    (``use_bert=False``, the branch this build covers) the three BERT tensors are zeros of shape (B, T+2): the reference
+    tokenises every sample here even when the model ignores the result."""
+    import numpy as np
+    batch = sorted(batch, key=lambda x: np.asarray(x[0][0]).shape[0], reverse=True)      # stable, like the reference
+    B = len(batch)
+    lens = [int(np.asarray(s[0][0]).shape[0]) for s in batch]
+    T = lens[0] if B else 0
+    dv = np.asarray(batch[0][0][1]).shape[1]; da = np.asarray(batch[0][0][2]).shape[1]
+    sent = np.full((T, B), PAD, dtype=np.int64)
+    vis = np.zeros((T, B, dv), dtype=np.float32)
+    aco = np.zeros((T, B, da), dtype=np.float32)
+    for b, s in enumerate(batch):
+        L = lens[b]
+        sent[:L, b] = np.asarray(s[0][0], dtype=np.int64)
+        vis[:L, b] = np.asarray(s[0][1], dtype=np.float32)
+        aco[:L, b] = np.asarray(s[0][2], dtype=np.float32)
+    lab = np.stack([np.nan_to_num(np.asarray(s[1], dtype=np.float64))[0] for s in batch]) if B else np.zeros((0, 1))
+    if lab.shape[1] == 7:
+        emo = (lab[:, 1:] > 0.0).astype(np.float32)
+        labels = lab[:, 0].astype(np.float32)
+        emo_t = torch.from_numpy(emo)
+    else:
+        labels = lab[:, 0].astype(np.float32)
+        emo_t = None
+    ids = [s[2] for s in batch]
+    bert = torch.zeros(B, T + 2, dtype=torch.int64)
+    return (torch.from_numpy(sent), torch.from_numpy(vis), torch.from_numpy(aco), torch.from_numpy(labels), emo_t,
+            torch.tensor(lens, dtype=torch.int64), bert, bert, bert, ids)
+
+
+class DevicePrefetcher:
+    """Wraps a loader of reference-style host batches and copies each batch to the device ONE BATCH AHEAD on a dedicated HIP
+    stream, so the copies of batch i+1 run beside the kernels of batch i and the training loop only ever sees device tensors.
+    ``lengths`` stays on the host like the reference (pack_padded_sequence wants it there); ids pass through.
+
+    Source tensors are copied as they are: pageable ones through the runtime's own staging (the call returns when the data has
+    left the tensor), page-locked ones asynchronously.  Staging through our own page-locked buffers was measured and dropped:
+    CPU writes into hipHostMalloc memory ran at ~0.2 GB/s on the MI355X hosts (3.3 ms for a 0.75 MB batch), against 0.35 ms
+    for the plain pageable copies of the same batch.
+    """
+
+    def __init__(self, loader, device):
+        self.loader = loader
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _stage(self, batch):
+        if self.stream is None:
+            return batch, None
+        out = []
+        with torch.cuda.stream(self.stream):
+            for i, x in enumerate(batch):
+                if torch.is_tensor(x) and i != 5 and not x.is_cuda:        # index 5 = lengths: host side
+                    out.append(x.to(self.device, non_blocking=x.is_pinned()))
+                else:
+                    out.append(x)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return tuple(out), ev
+
+    def __iter__(self):
+        it = iter(self.loader)
+        try:
+            nxt = self._stage(next(it))
+        except StopIteration:
+            return
+        for batch in it:
+            cur, ev = nxt
+            nxt = self._stage(batch)                  # the next batch's copies run beside this batch's compute
+            yield self._hand_over(cur, ev)
+        yield self._hand_over(*nxt)
+
+    def _hand_over(self, cur, ev):
+        """Make the compute stream wait for the copies and tell the caching allocator that the compute stream uses these
+        tensors: they were allocated on the copy stream, and without record_stream their memory could be handed to the next
+        batch's copy while kernels of this step (the host runs several steps ahead of the GPU) have not read them yet."""
+        if ev is not None:
+            cs = torch.cuda.current_stream(self.device)
+            cs.wait_event(ev)
+            for x in cur:
+                if torch.is_tensor(x) and x.is_cuda:
+                    x.record_stream(cs)
+        return cur

@@ -332,3 +332,35 @@ def test_solver_eval_device_side_metrics_match_oracle_forward():
     ref = get_metrics(y_true, y_pred)
     for k, vv in s.last_eval_metrics.items():
         assert abs(vv - ref[k]) < 1e-12, k
+
+
+def test_device_prefetcher_hands_over_identical_batches_and_trains():
+    """DevicePrefetcher (pinned async H2D on a copy stream, double buffered): every device batch equals its host batch, lengths
+    stay on the host, and a training epoch driven through it gives the same parameters as the same epoch from resident tensors."""
+    from mmda_amd import make_config, MISA
+    from mmda_amd.data import SyntheticLoader, DevicePrefetcher
+    cfg = orc.default_config(vocab_size=70)
+    c = make_config(device=DEV, precision="fp32", **vars(cfg))
+    loader = SyntheticLoader(c, 4, 6, 9, seed=9, ragged=True, device="cpu")
+    for hb, db in zip(loader, DevicePrefetcher(loader, DEV)):
+        for i, (h, d_) in enumerate(zip(hb, db)):
+            if torch.is_tensor(h):
+                assert (d_.device.type == "cpu") == (i == 5)
+                assert torch.equal(h, d_.cpu())
+            else:
+                assert h == d_
+    P = orc.synth_params(cfg, 3)
+    runs = []
+    for pf in (False, True):
+        m = MISA(c); m.load_state_dict(P); m.to(DEV); m.train()
+        src = DevicePrefetcher(loader, DEV) if pf else loader
+        losses = []
+        for rep in range(3):                          # 12 steps: the host runs ahead of the GPU, buffers get recycled
+            for (t, v, a, y, emo, l, *_) in src:
+                m.train_step(t.to(DEV), v.to(DEV), a.to(DEV), l, emo.to(DEV), lr=1e-4, clip=1.0, training=False)
+                losses.append(m.read_losses())
+        runs.append(losses)
+    # same data, same start: the per-step losses agree (float-atomic summation order is the only difference between the runs)
+    for a_, b_ in zip(*runs):
+        for k in ("cls", "diff", "sim", "recon", "total"):
+            assert abs(a_[k] - b_[k]) <= 2e-4 * max(1.0, abs(a_[k])), (k, a_[k], b_[k])

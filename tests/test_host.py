@@ -131,3 +131,29 @@ def test_eval_metrics_host_match_reference_golden():
         for k, r in zip(E.KEYS, G[c + "/metrics"]):
             assert abs(m[k] - r) < 1e-12, (c, k)
         assert E.get_accuracy(G[c + "/y"], G[c + "/pred"]) == G[c + "/metrics"][0]
+
+
+def test_collate_fn_matches_reference_restatement():
+    """mmda_amd.data.collate_fn (vectorised) against the line-by-line restatement of the reference's collate
+    (oracle/collate_oracle.py, reference data_loader.py:59-122): ordering, padding values, label handling, dtypes."""
+    import numpy as np
+    import torch
+    from mmda_amd.data import collate_fn
+    from oracle import collate_oracle as co
+    rng = np.random.default_rng(11)
+    samples = []
+    for i, L in enumerate([5, 9, 1, 9, 3, 7]):                        # a tie in length: the sort must be stable
+        lab = rng.normal(size=(1, 7)).astype(np.float32)
+        if i == 2:
+            lab[0, 3] = np.nan                                        # NaN annotations are replaced by 0
+        if i == 4:
+            lab[:] = 0.0
+        samples.append(((rng.integers(2, 50, size=L), rng.normal(size=(L, 35)).astype(np.float32),
+                         rng.normal(size=(L, 74)).astype(np.float32), ["w"] * L), lab, f"seg{i}"))
+    got = collate_fn(list(samples))
+    ref = co.collate(list(samples))
+    for g, r, name in zip(got[:6], ref[:6], ["sentences", "visual", "acoustic", "labels", "emo_labels", "lengths"]):
+        assert g.dtype == r.dtype and tuple(g.shape) == tuple(r.shape), name
+        assert torch.equal(g, r), name
+    assert got[9] == ref[6]
+    assert got[0].shape == (9, 6) and got[6].shape == (6, 11) and got[5].tolist() == [9, 9, 7, 5, 3, 1]
