@@ -129,6 +129,10 @@ typedef struct mmda_skinny_args {
 } mmda_skinny_args;
 int mmda_gemm_skinny(const mmda_skinny_args* args, int n, void* stream);
 
+/* fp32 transposes, up to 16 per launch: dst[c * ldd + r] = src[r * ld + c] for r < rows, c < cols. */
+typedef struct mmda_transpose_job { const float* src; int rows, cols, ld; float* dst; int ldd; } mmda_transpose_job;
+int mmda_transpose_f32(const mmda_transpose_job* jobs, int n, void* stream);
+
 /* column sums: out[n] += sum_m X[m*ld + n] (and out2[n] += the same, if out2 != NULL)   (bias gradients; atomics) */
 int mmda_colsum(const float* X, int ld, int M, int N, float* out, float* out2, void* stream);
 

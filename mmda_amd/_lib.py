@@ -54,6 +54,10 @@ class SkinnyArgs(C.Structure):
                 ("dsig", C.c_void_p), ("dsig2", C.c_void_p), ("lddsig", C.c_int)]
 
 
+class TransposeJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("ld", C.c_int), ("dst", C.c_void_p), ("ldd", C.c_int)]
+
+
 class LnArgs(C.Structure):
     _fields_ = [("rows", C.c_int), ("n", C.c_int), ("x", C.c_void_p), ("res", C.c_void_p), ("gamma", C.c_void_p),
                 ("beta", C.c_void_p), ("y", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("act", C.c_int),
@@ -95,6 +99,7 @@ SIGNATURES = {
     "mmda_gemm_bf16_grouped": (_I, [C.POINTER(GemmBf16Args), _I, _P]),
     "mmda_convert_bf16": (_I, [C.POINTER(ConvertJob), _I, _P]),
     "mmda_gemm_skinny": (_I, [C.POINTER(SkinnyArgs), _I, _P]),
+    "mmda_transpose_f32": (_I, [C.POINTER(TransposeJob), _I, _P]),
     "mmda_colsum": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "mmda_embed_gather": (_I, [_P, _P, _I, _I, _P, _P]),
     "mmda_embed_scatter_add": (_I, [_P, _P, _I, _I, _P, _P]),

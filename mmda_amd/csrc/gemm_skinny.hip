@@ -133,6 +133,72 @@ __device__ __forceinline__ void skinny_epilogue(const mmda_skinny_args& g, int m
   }
 }
 
+// Short K, wide N (the FFN up-projection and its input gradient: M = 6B, N = 2048, K = 128): no K split.  The block's eight
+// waves tile a 64 x 128 output (2 x 4 waves of 32 x 32 = 2 x 2 MFMA tiles each), every wave walks the whole K with four
+// float4 loads (two A row tiles, two B column tiles) per 16-deep chunk feeding 16 MFMAs, and writes its tile straight from
+// the accumulators.  The K-split form spends 768 workgroups on one chunk each for this shape.  NT, 16-byte aligned operands only.
+__device__ __forceinline__ void skinny_wide(const mmda_skinny_args& g, int row0, int col0, int lane) {
+  const int r = lane & 15, q = lane >> 4;
+  const int M = g.M, N = g.N, K = g.K;
+  const int nchunks = (K + 15) >> 4;
+  const int ar0 = min(row0 + r, M - 1), ar1 = min(row0 + 16 + r, M - 1);
+  const int bc0 = min(col0 + r, N - 1), bc1 = min(col0 + 16 + r, N - 1);
+  const bool a0_ok = row0 + r < M, a1_ok = row0 + 16 + r < M, b0_ok = col0 + r < N, b1_ok = col0 + 16 + r < N;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int PF = 4;
+  f4 ra0[PF], ra1[PF], rb0[PF], rb1[PF];
+  const f4 z = {0.f, 0.f, 0.f, 0.f};
+  auto load = [&](int slot, int c) {
+    const int k = c * 16 + 4 * q;
+    const int kc = min(k, K - 4);
+    const bool k_ok = k < K;
+    f4 a0 = *reinterpret_cast<const f4*>(g.A + (int64_t)ar0 * g.lda + kc);
+    f4 a1 = *reinterpret_cast<const f4*>(g.A + (int64_t)ar1 * g.lda + kc);
+    if (g.A2) {
+      a0 += *reinterpret_cast<const f4*>(g.A2 + (int64_t)ar0 * g.lda + kc);
+      a1 += *reinterpret_cast<const f4*>(g.A2 + (int64_t)ar1 * g.lda + kc);
+    }
+    const f4 b0 = *reinterpret_cast<const f4*>(g.B + (int64_t)bc0 * g.ldb + kc);
+    const f4 b1 = *reinterpret_cast<const f4*>(g.B + (int64_t)bc1 * g.ldb + kc);
+    ra0[slot] = (a0_ok && k_ok) ? a0 : z; ra1[slot] = (a1_ok && k_ok) ? a1 : z;
+    rb0[slot] = (b0_ok && k_ok) ? b0 : z; rb1[slot] = (b1_ok && k_ok) ? b1 : z;
+  };
+  auto mma = [&](int slot) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra0[slot][s], rb0[slot][s], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra0[slot][s], rb1[slot][s], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra1[slot][s], rb0[slot][s], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra1[slot][s], rb1[slot][s], acc[1][1], 0, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int p = 0; p < PF; ++p) load(p, p);
+  for (int base = 0; base < nchunks; base += PF) {
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      if (base + p < nchunks) mma(p);
+      if (base + p + PF < nchunks) load(p, base + p + PF);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = col0 + j * 16 + (lane & 15);
+      if (n >= N) continue;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int m = row0 + i * 16 + (lane >> 4) * 4 + rg;
+        if (m < M) skinny_epilogue(g, m, n, acc[i][j][rg]);
+      }
+    }
+}
+
 template <int WK>
 __device__ __forceinline__ void skinny_products(f32x4 (&acc)[2], const mmda_skinny_args& g, int row0, int col0, int wave, int lane) {
   for (int prod = 0; prod < 2; ++prod) {
@@ -163,6 +229,13 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyLaunch L) {
   const int bx = local % L.tx[pi], by = local / L.tx[pi];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  if (L.nsplit[pi] == 2) {
+    // 64 x 128 block tile, wave (wr, wc) = (wave >> 2, wave & 3) owns 32 x 32
+    const int row0 = by * 64 + (wave >> 2) * 32, col0 = bx * 128 + (wave & 3) * 32;
+    if (row0 >= g.M || col0 >= g.N) return;              // wave-uniform; no barrier on this path
+    skinny_wide(g, row0, col0, lane);
+    return;
+  }
   if (L.nsplit[pi]) {
     // short K, wide N: the eight waves take eight adjacent 16-column tiles and each walks the whole K; no cross-wave sum
     const int row0 = by * SK_TM, col0 = (bx * SK_WAVES + wave) * SK_TN;
@@ -196,6 +269,32 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyLaunch L) {
   skinny_epilogue(g, m, n, raw);
 }
 
+// fp32 transposes (up to 16 per launch): dst[c][r] = src[r][c] through 32 x 33 LDS tiles, coalesced on both sides.  Used once per
+// step (side stream) for the K-major copies of the fusion block's weights that its input-gradient GEMMs read.
+struct TrLaunch { mmda_transpose_job j[16]; int start[17]; int tx[16]; int n; };
+__global__ __launch_bounds__(256) void transpose_kernel(TrLaunch L) {
+  __shared__ float tile[32][33];
+  int pi = 0;
+#pragma unroll
+  for (int k = 1; k < 16; ++k)
+    if (k < L.n && (int)blockIdx.x >= L.start[k]) pi = k;
+  const mmda_transpose_job& J = L.j[pi];
+  const int local = blockIdx.x - L.start[pi];
+  const int bx = local % L.tx[pi], by = local / L.tx[pi];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = by * 32 + ty + 8 * i, c = bx * 32 + tx;
+    tile[ty + 8 * i][tx] = (r < J.rows && c < J.cols) ? J.src[(int64_t)min(r, J.rows - 1) * J.ld + min(c, J.cols - 1)] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = bx * 32 + ty + 8 * i, r = by * 32 + tx;
+    if (c < J.cols && r < J.rows) J.dst[(int64_t)c * J.ldd + r] = tile[tx][ty + 8 * i];
+  }
+}
+
 }  // namespace
 
 extern "C" int mmda_gemm_skinny(const mmda_skinny_args* args, int n, void* stream) {
@@ -223,15 +322,44 @@ extern "C" int mmda_gemm_skinny(const mmda_skinny_args* args, int n, void* strea
       // step with it on for N >= 128, 1.37 for N >= 1024): eight waves sharing one k-walk's latency beat eight walking alone.
       static const int nsplit_min_n = getenv("MMDA_SKINNY_NSPLIT_MIN_N") ? atoi(getenv("MMDA_SKINNY_NSPLIT_MIN_N")) : (1 << 30);
       L.nsplit[k] = (a.K <= 256 && a.K2 <= 256 && a.N >= nsplit_min_n) ? 1 : 0;
-      L.tx[k] = L.nsplit[k] ? ceil_div(a.N, SK_WAVES * SK_TN) : ceil_div(a.N, SK_TN);
+      // wide form: NT, single product, K <= 256 and a multiple of 4, N >= 1024, 16-byte aligned operands
+      static const int wide_min_n = getenv("MMDA_SKINNY_WIDE_MIN_N") ? atoi(getenv("MMDA_SKINNY_WIDE_MIN_N")) : (1 << 30);    // OFF by default: measured +15 us per step against the K-split form at N = 2048
+      const bool al = ((((uintptr_t)a.A | (uintptr_t)a.B | (uintptr_t)a.A2) & 15) == 0) && !(a.lda & 3) && !(a.ldb & 3) && !(a.K & 3);
+      if (a.transB && a.K2 <= 0 && a.K <= 256 && a.N >= wide_min_n && al && !a.C2) L.nsplit[k] = 2;
+      int rows_per_block = SK_TM;
+      if (L.nsplit[k] == 2) { L.tx[k] = ceil_div(a.N, 128); rows_per_block = 64; }
+      else L.tx[k] = L.nsplit[k] ? ceil_div(a.N, SK_WAVES * SK_TN) : ceil_div(a.N, SK_TN);
       L.start[k] = blocks;
-      blocks += L.tx[k] * ceil_div(a.M, SK_TM);
+      blocks += L.tx[k] * ceil_div(a.M, rows_per_block);
     }
     for (int k = L.n; k <= SK_MAXP; ++k) L.start[k] = blocks;
     for (int k = L.n; k < SK_MAXP; ++k) { L.p[k] = L.p[0]; L.tx[k] = 1; L.nsplit[k] = 0; }
     if (blocks == 0) continue;
     hipLaunchKernelGGL(gemm_skinny_kernel, dim3(blocks), dim3(512), 0, s, L);
     MMDA_CHECK_LAUNCH("mmda_gemm_skinny");
+  }
+  return MMDA_OK;
+}
+
+extern "C" int mmda_transpose_f32(const mmda_transpose_job* jobs, int n, void* stream) {
+  if (!jobs || n < 0) return MMDA_EINVAL;
+  for (int base = 0; base < n; base += 16) {
+    TrLaunch L;
+    L.n = 0;
+    int blocks = 0;
+    for (int i = base; i < n && i < base + 16; ++i) {
+      const mmda_transpose_job& j = jobs[i];
+      if (!j.src || !j.dst || j.rows < 0 || j.cols < 0 || j.ld < j.cols || j.ldd < j.rows) return MMDA_EINVAL;
+      if (j.rows == 0 || j.cols == 0) continue;
+      const int k = L.n++;
+      L.j[k] = j; L.tx[k] = ceil_div(j.cols, 32); L.start[k] = blocks;
+      blocks += L.tx[k] * ceil_div(j.rows, 32);
+    }
+    for (int k = L.n; k <= 16; ++k) L.start[k] = blocks;
+    for (int k = L.n; k < 16; ++k) { L.j[k] = L.j[0]; L.tx[k] = 1; }
+    if (blocks == 0) continue;
+    hipLaunchKernelGGL(transpose_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
+    MMDA_CHECK_LAUNCH("mmda_transpose_f32");
   }
   return MMDA_OK;
 }

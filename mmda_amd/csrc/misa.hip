@@ -55,6 +55,9 @@ struct mmda_misa {
   int64_t zero_begin = 0, zero_end = 0;      // activation-gradient region that is zeroed per step
   int64_t z, pmean, prstd, orig, x6, rsum, recon, dom_z, dom_h, dom, qkv, probs, ctx, attn_out, ln1_mean, ln1_rstd, x1, f1, f2,
       ln2_mean, ln2_rstd, hfused, logits, tcp, scores, labels, losses, diff_work;
+  // K-major (transposed) fp32 copies of the fusion block's weights for its input-gradient GEMMs (made once per step)
+  int64_t head_wT, l2_wT, l1_wT, out_wT, in_wT, rec_wT, priv_wT, sh_wT, d1_wT = -1, d2_wT = -1, pwT[3];
+  int wT_valid = 0;
   int64_t d_scores, d_tcp, d_x6, d_orig, d_recon, d_dom, d_logits, d_hfused, d_x1, d_f2, d_f1, d_attn_out, d_ctx, d_qkv, d_z,
       d_dom_h, d_dom_z;
   // state of the last forward (dropout replay in backward)
@@ -228,6 +231,11 @@ int64_t layout(mmda_misa* m, int B, int T, bool commit) {
   o->f1 = k.take((int64_t)6 * B * FFN); o->f2 = k.take(6 * BH); o->ln2_mean = k.take(6 * B); o->ln2_rstd = k.take(6 * B);
   o->hfused = k.take(6 * BH); o->logits = k.take((int64_t)B * NC);
   o->diff_work = k.take(mmda_loss_diff_work_floats(B, hs));
+  o->head_wT = k.take((int64_t)6 * hs * NC); o->l2_wT = k.take((int64_t)FFN * hs); o->l1_wT = k.take((int64_t)hs * FFN);
+  o->out_wT = k.take((int64_t)hs * hs); o->in_wT = k.take((int64_t)hs * 3 * hs); o->rec_wT = k.take((int64_t)3 * hs * hs);
+  o->priv_wT = k.take((int64_t)3 * hs * hs); o->sh_wT = k.take((int64_t)hs * hs);
+  if (!c.use_cmd_sim) { o->d1_wT = k.take((int64_t)hs * hs); o->d2_wT = k.take((int64_t)hs * 3); }
+  for (int i = 0; i < 3; ++i) o->pwT[i] = k.take((int64_t)4 * o->mod[i].H * hs);
   // ---- the loss sums and the activation gradients seeded by the losses (zeroed every step by ONE memset, contiguous)
   o->zero_begin = k.cur;
   o->losses = k.take(8);
@@ -314,6 +322,12 @@ mmda_skinny_args sk_nt(int M, int N, int K, const float* x, int ldx, const float
 mmda_skinny_args sk_nn(int M, int N, int K, const float* dy, int lddy, const float* W, float* dx, int lddx, int acc) {
   mmda_skinny_args g = {};
   g.M = M; g.N = K; g.K = N; g.transB = 0; g.A = dy; g.lda = lddy; g.B = W; g.ldb = K; g.C = dx; g.ldc = lddx; g.accumulate = acc;
+  return g;
+}
+// dx(M,K) (+)= dy(M,N) W(N,K) through the K-major copy WT(K,N): an NT problem (float4 loads along the reduction for both operands)
+mmda_skinny_args sk_dx(int M, int N, int K, const float* dy, int lddy, const float* WT, float* dx, int lddx, int acc) {
+  mmda_skinny_args g = {};
+  g.M = M; g.N = K; g.K = N; g.transB = 1; g.A = dy; g.lda = lddy; g.B = WT; g.ldb = N; g.C = dx; g.ldc = lddx; g.accumulate = acc;
   return g;
 }
 void sk_launch(Ctx& c, const mmda_skinny_args* p, int n) {
@@ -496,6 +510,23 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
     x.rc = side_fork(m, stream, &ss);
     if (!x.rc) x.rc = mmda_lstm_pack_whh_multi(mode, 12, Hs, Wp, Fp, Bp, want_c ? Cp : nullptr, ss);
     m->packed_c_valid = want_c ? 1 : 0;
+    m->wT_valid = 0;
+    if (!x.rc && B <= SKINNY_MAX_B && !m->inference) {
+      // K-major copies of the fusion block's weights for the backward pass, also underneath the first input GEMM
+      const int hs_ = c.hidden, NC_ = 6 + c.ncls;
+      std::vector<mmda_transpose_job> tj;
+      auto T_ = [&](int64_t src, int rows, int cols, int64_t dst) { tj.push_back(mmda_transpose_job{PP(src), rows, cols, cols, WS(dst), rows}); };
+      T_(m->head_w, NC_, 6 * hs_, m->head_wT); T_(m->l2_w, hs_, FFN, m->l2_wT); T_(m->l1_w, FFN, hs_, m->l1_wT);
+      T_(m->out_w, hs_, hs_, m->out_wT); T_(m->in_w, 3 * hs_, hs_, m->in_wT); T_(m->sh_w, hs_, hs_, m->sh_wT);
+      for (int i = 0; i < 3; ++i) {
+        T_(m->rec_w + (int64_t)i * hs_ * hs_, hs_, hs_, m->rec_wT + (int64_t)i * hs_ * hs_);
+        T_(m->priv_w + (int64_t)i * hs_ * hs_, hs_, hs_, m->priv_wT + (int64_t)i * hs_ * hs_);
+        T_(m->mod[i].pw, hs_, 4 * m->mod[i].H, m->pwT[i]);
+      }
+      if (!c.use_cmd_sim) { T_(m->d1_w, hs_, hs_, m->d1_wT); T_(m->d2_w, 3, hs_, m->d2_wT); }
+      x.rc = mmda_transpose_f32(tj.data(), (int)tj.size(), ss);
+      m->wT_valid = 1;
+    }
   }
   if (x.rc) return x.rc;
   // bf16 mode: the input GEMMs read bf16 operand copies (K-major, 16-B rows): W_ih of both layers (plain for the forward,
@@ -788,7 +819,9 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
     mmda_skinny_args g[8];
     x.rc = mmda_heads_bwd(WS(m->tcp), WS(m->scores), WS(m->d_tcp), WS(m->d_scores), B, c.ncls, WS(m->d_logits), p_cls, seed, SITE_CLS,
                           stream);
-    g[0] = sk_nn(B, NC, 6 * hs, WS(m->d_logits), NC, PP(m->head_w), WS(m->d_hfused), 6 * hs, 0);
+    const bool wt = m->wT_valid != 0;                   // K-major weight copies from this step's forward (side stream, joined there)
+    g[0] = wt ? sk_dx(B, NC, 6 * hs, WS(m->d_logits), NC, WS(m->head_wT), WS(m->d_hfused), 6 * hs, 0)
+              : sk_nn(B, NC, 6 * hs, WS(m->d_logits), NC, PP(m->head_w), WS(m->d_hfused), 6 * hs, 0);
     sk_launch(x, g, 1);
     lin_dw(x, fmode, B, NC, 6 * hs, WS(m->d_logits), WS(m->hfused), GG(m->head_w), GG(m->head_b));
     // norm2 + FFN
@@ -801,11 +834,13 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
       x.rc = mmda_layernorm_bwd(&l, stream);
     }
     // d f1 = (d f2 W2) * [f1 > 0] / (1-p): f1 is stored post-relu, post-dropout, so f1 > 0 <=> kept and pre-activation > 0
-    g[0] = sk_nn(6 * B, hs, FFN, WS(m->d_f2), hs, PP(m->l2_w), WS(m->d_f1), FFN, 0);
+    g[0] = wt ? sk_dx(6 * B, hs, FFN, WS(m->d_f2), hs, WS(m->l2_wT), WS(m->d_f1), FFN, 0)
+              : sk_nn(6 * B, hs, FFN, WS(m->d_f2), hs, PP(m->l2_w), WS(m->d_f1), FFN, 0);
     g[0].gate = WS(m->f1); g[0].ldgate = FFN; g[0].gate_scale = p_tf > 0.f ? 1.f / (1.f - p_tf) : 1.f;
     sk_launch(x, g, 1);
     lin_dw(x, fmode, 6 * B, hs, FFN, WS(m->d_f2), WS(m->f1), GG(m->l2_w), GG(m->l2_b));
-    g[0] = sk_nn(6 * B, FFN, hs, WS(m->d_f1), FFN, PP(m->l1_w), WS(m->d_x1), hs, 1);
+    g[0] = wt ? sk_dx(6 * B, FFN, hs, WS(m->d_f1), FFN, WS(m->l1_wT), WS(m->d_x1), hs, 1)
+              : sk_nn(6 * B, FFN, hs, WS(m->d_f1), FFN, PP(m->l1_w), WS(m->d_x1), hs, 1);
     sk_launch(x, g, 1);
     lin_dw(x, fmode, 6 * B, FFN, hs, WS(m->d_f1), WS(m->x1), GG(m->l1_w), GG(m->l1_b));
     // norm1 + self-attention
@@ -817,8 +852,10 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
       x.rc = mmda_layernorm_bwd(&l, stream);
     }
     int n = 0;
-    g[n++] = sk_nn(6 * B, hs, hs, WS(m->d_attn_out), hs, PP(m->out_w), WS(m->d_ctx), hs, 0);
-    if (!c.use_cmd_sim) g[n++] = sk_nn(3 * B, 3, hs, WS(m->d_dom), 3, PP(m->d2_w), WS(m->d_dom_h), hs, 0);
+    g[n++] = wt ? sk_dx(6 * B, hs, hs, WS(m->d_attn_out), hs, WS(m->out_wT), WS(m->d_ctx), hs, 0)
+                : sk_nn(6 * B, hs, hs, WS(m->d_attn_out), hs, PP(m->out_w), WS(m->d_ctx), hs, 0);
+    if (!c.use_cmd_sim) g[n++] = wt ? sk_dx(3 * B, 3, hs, WS(m->d_dom), 3, WS(m->d2_wT), WS(m->d_dom_h), hs, 0)
+                                    : sk_nn(3 * B, 3, hs, WS(m->d_dom), 3, PP(m->d2_w), WS(m->d_dom_h), hs, 0);
     sk_launch(x, g, n);
     lin_dw(x, fmode, 6 * B, hs, hs, WS(m->d_attn_out), WS(m->ctx), GG(m->out_w), GG(m->out_b));
     if (!x.rc) x.rc = mmda_attn_bwd(WS(m->qkv), WS(m->probs), WS(m->d_ctx), S6, B, hs, NHEAD, WS(m->d_qkv), p_tf, seed, SITE_ATTN, stream);
@@ -828,7 +865,8 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
       lin_dw(x, fmode, 3 * B, 3, hs, WS(m->d_dom), WS(m->dom_h), GG(m->d2_w), GG(m->d2_b));
       if (!x.rc) x.rc = mmda_act_dropout_bwd(WS(m->d_dom_h), WS(m->dom_z), WS(m->d_dom_z), 3 * BH, c.act, p_cls, seed, SITE_DISC, stream);
       lin_dw(x, fmode, 3 * B, hs, hs, WS(m->d_dom_z), WS(m->x6 + 3 * BH), GG(m->d1_w), GG(m->d1_b));
-      g[0] = sk_nn(3 * B, hs, hs, WS(m->d_dom_z), hs, PP(m->d1_w), WS(m->d_x6 + 3 * BH), hs, 1);
+      g[0] = wt ? sk_dx(3 * B, hs, hs, WS(m->d_dom_z), hs, WS(m->d1_wT), WS(m->d_x6 + 3 * BH), hs, 1)
+                : sk_nn(3 * B, hs, hs, WS(m->d_dom_z), hs, PP(m->d1_w), WS(m->d_x6 + 3 * BH), hs, 1);
       g[0].alpha = -c.reverse_grad_weight;
       sk_launch(x, g, 1);
     }
@@ -836,8 +874,10 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
     // reconstruction's input gradients (the latter flows into BOTH private and shared) and the sigmoid backward, six problems
     for (int j = 0; j < 6; ++j) {
       const int i = j % 3;
-      g[j] = sk_nn(B, 3 * hs, hs, WS(m->d_qkv + (int64_t)j * B * 3 * hs), 3 * hs, PP(m->in_w), WS(m->d_x6 + j * BH), hs, 1);
-      g[j].K2 = hs; g[j].A_2nd = WS(m->d_recon + i * BH); g[j].lda_2nd = hs; g[j].B_2nd = PP(m->rec_w + (int64_t)i * hs * hs); g[j].ldb_2nd = hs;
+      g[j] = wt ? sk_dx(B, 3 * hs, hs, WS(m->d_qkv + (int64_t)j * B * 3 * hs), 3 * hs, WS(m->in_wT), WS(m->d_x6 + j * BH), hs, 1)
+                : sk_nn(B, 3 * hs, hs, WS(m->d_qkv + (int64_t)j * B * 3 * hs), 3 * hs, PP(m->in_w), WS(m->d_x6 + j * BH), hs, 1);
+      g[j].K2 = hs; g[j].A_2nd = WS(m->d_recon + i * BH); g[j].lda_2nd = hs; g[j].ldb_2nd = hs;
+      g[j].B_2nd = wt ? WS(m->rec_wT + (int64_t)i * hs * hs) : PP(m->rec_w + (int64_t)i * hs * hs);
       g[j].dsig = WS(m->x6 + j * BH); g[j].lddsig = hs;
     }
     sk_launch(x, g, 6);
@@ -849,8 +889,9 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
     }
     // d_orig[i] += d_private[i] W_priv[i] + d_shared[i] W_shared
     for (int i = 0; i < 3; ++i) {
-      g[i] = sk_nn(B, hs, hs, WS(m->d_x6 + i * BH), hs, PP(m->priv_w + (int64_t)i * hs * hs), WS(m->d_orig + i * BH), hs, 1);
-      g[i].K2 = hs; g[i].A_2nd = WS(m->d_x6 + (3 + i) * BH); g[i].lda_2nd = hs; g[i].B_2nd = PP(m->sh_w); g[i].ldb_2nd = hs;
+      g[i] = wt ? sk_dx(B, hs, hs, WS(m->d_x6 + i * BH), hs, WS(m->priv_wT + (int64_t)i * hs * hs), WS(m->d_orig + i * BH), hs, 1)
+                : sk_nn(B, hs, hs, WS(m->d_x6 + i * BH), hs, PP(m->priv_w + (int64_t)i * hs * hs), WS(m->d_orig + i * BH), hs, 1);
+      g[i].K2 = hs; g[i].A_2nd = WS(m->d_x6 + (3 + i) * BH); g[i].lda_2nd = hs; g[i].B_2nd = wt ? WS(m->sh_wT) : PP(m->sh_w); g[i].ldb_2nd = hs;
     }
     sk_launch(x, g, 3);
     {
@@ -874,7 +915,8 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
     }
     for (int i = 0; i < 3; ++i) {
       Mod& md = m->mod[i];
-      g[i] = sk_nn(B, hs, 4 * md.H, WS(m->d_z + i * BH), hs, PP(md.pw), WS(md.d_utt), 4 * md.H, 0);
+      g[i] = wt ? sk_dx(B, hs, 4 * md.H, WS(m->d_z + i * BH), hs, WS(m->pwT[i]), WS(md.d_utt), 4 * md.H, 0)
+                : sk_nn(B, hs, 4 * md.H, WS(m->d_z + i * BH), hs, PP(md.pw), WS(md.d_utt), 4 * md.H, 0);
       lin_dw(x, fmode, B, hs, 4 * md.H, WS(m->d_z + i * BH), WS(md.utt), GG(md.pw), GG(md.pb));
     }
     sk_launch(x, g, 3);

@@ -17,6 +17,9 @@ constexpr int LN_MAXP = 4;      // problems per launch (the three modalities' La
 struct LnMulti { mmda_ln_args a[LN_MAXP]; int start[LN_MAXP + 1]; int n; };
 struct LnBwdMulti { mmda_ln_bwd_args a[LN_MAXP]; int start[LN_MAXP + 1]; int nblk[LN_MAXP]; int n; };
 
+// NQ = values per lane kept in registers (64 NQ >= n): the loops below are fully unrolled over it, so a launch is instantiated
+// for the smallest NQ that covers its widest problem (n = 128 needs 2; the generic 16 costs 8x the instructions)
+template <int NQ>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(LnMulti L) {
   int pi = 0;
 #pragma unroll
@@ -27,10 +30,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnMulti L) {
   const int row = ((int)blockIdx.x - L.start[pi]) * 4 + wave;
   if (row >= a.rows) return;
   const int n = a.n;
-  float v[LN_MAXQ];
+  float v[NQ];
   float s = 0.f;
 #pragma unroll
-  for (int q = 0; q < LN_MAXQ; ++q) {
+  for (int q = 0; q < NQ; ++q) {
     int i = lane + 64 * q;
     float x = 0.f;
     if (i < n) {
@@ -44,7 +47,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnMulti L) {
   const float mean = wave_sum(s) / n;
   float ss = 0.f;
 #pragma unroll
-  for (int q = 0; q < LN_MAXQ; ++q) {
+  for (int q = 0; q < NQ; ++q) {
     int i = lane + 64 * q;
     float d = (i < n) ? v[q] - mean : 0.f;
     ss += d * d;
@@ -57,14 +60,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnMulti L) {
   }
   const int64_t orow = perm_row(row, a.permute_S, a.permute_B);
 #pragma unroll
-  for (int q = 0; q < LN_MAXQ; ++q) {
+  for (int q = 0; q < NQ; ++q) {
     int i = lane + 64 * q;
     if (i < n) a.y[orow * n + i] = (v[q] - mean) * rstd * a.gamma[i] + a.beta[i];
   }
 }
 
+template <int NQ>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdMulti L) {
-  __shared__ float red[2][4][LN_MAXQ * 64];
+  __shared__ float red[2][4][NQ * 64];
   int pi = 0;
 #pragma unroll
   for (int k = 1; k < LN_MAXP; ++k)
@@ -74,16 +78,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdMulti L) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = a.n;
   const bool want_pg = a.dgamma != nullptr || a.dbeta != nullptr;
-  float dg[LN_MAXQ], db[LN_MAXQ];
+  float dg[NQ], db[NQ];
 #pragma unroll
-  for (int q = 0; q < LN_MAXQ; ++q) { dg[q] = 0.f; db[q] = 0.f; }
+  for (int q = 0; q < NQ; ++q) { dg[q] = 0.f; db[q] = 0.f; }
   for (int row = blk * 4 + wave; row < a.rows; row += nblk * 4) {
     const float mean = a.mean[row], rstd = a.rstd[row];
     const int64_t drow = perm_row(row, a.permute_S, a.permute_B);
-    float xh[LN_MAXQ], gdy[LN_MAXQ];
+    float xh[NQ], gdy[NQ];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int q = 0; q < LN_MAXQ; ++q) {
+    for (int q = 0; q < NQ; ++q) {
       int i = lane + 64 * q;
       xh[q] = 0.f; gdy[q] = 0.f;
       if (i < n) {
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdMulti L) {
     s1 = wave_sum(s1) / n;
     s2 = wave_sum(s2) / n;
 #pragma unroll
-    for (int q = 0; q < LN_MAXQ; ++q) {
+    for (int q = 0; q < NQ; ++q) {
       int i = lane + 64 * q;
       if (i < n) {
         int64_t idx = (int64_t)row * n + i;
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdMulti L) {
   // reduce the per-wave column partials across the block's 4 waves, then one atomic per column per block
   const int nq = (n + 63) / 64;
 #pragma unroll
-  for (int q = 0; q < LN_MAXQ; ++q) {
+  for (int q = 0; q < NQ; ++q) {
     if (q < nq) { red[0][wave][q * 64 + lane] = dg[q]; red[1][wave][q * 64 + lane] = db[q]; }
   }
   __syncthreads();
@@ -240,7 +244,12 @@ extern "C" int mmda_layernorm_fwd_multi(const mmda_ln_args* a, int n, void* stre
     for (int k = L.n; k <= LN_MAXP; ++k) L.start[k] = blocks;
     for (int k = L.n; k < LN_MAXP; ++k) L.a[k] = L.a[0];
     if (blocks == 0) continue;
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
+    int nq = 1;
+    for (int k = 0; k < L.n; ++k) nq = max(nq, ceil_div(L.a[k].n, 64));
+    if (nq <= 2) hipLaunchKernelGGL(ln_fwd_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
+    else if (nq <= 4) hipLaunchKernelGGL(ln_fwd_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
+    else if (nq <= 10) hipLaunchKernelGGL(ln_fwd_kernel<10>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
+    else hipLaunchKernelGGL(ln_fwd_kernel<LN_MAXQ>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
     MMDA_CHECK_LAUNCH("mmda_layernorm_fwd");
   }
   return MMDA_OK;
@@ -266,7 +275,12 @@ extern "C" int mmda_layernorm_bwd_multi(const mmda_ln_bwd_args* a, int n, void* 
     for (int k = L.n; k <= LN_MAXP; ++k) L.start[k] = blocks;
     for (int k = L.n; k < LN_MAXP; ++k) { L.a[k] = L.a[0]; L.nblk[k] = 1; }
     if (blocks == 0) continue;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
+    int nq = 1;
+    for (int k = 0; k < L.n; ++k) nq = max(nq, ceil_div(L.a[k].n, 64));
+    if (nq <= 2) hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
+    else if (nq <= 4) hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
+    else if (nq <= 10) hipLaunchKernelGGL(ln_bwd_kernel<10>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
+    else hipLaunchKernelGGL(ln_bwd_kernel<LN_MAXQ>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
     MMDA_CHECK_LAUNCH("mmda_layernorm_bwd");
   }
   return MMDA_OK;

@@ -139,6 +139,20 @@ def gemm_skinny(problems):
     check(lib.mmda_gemm_skinny(arr, len(problems), stream_ptr()), "mmda_gemm_skinny")
     return outs
 
+
+def transpose_f32(mats):
+    """fp32 transposes of several matrices in one launch."""
+    lib = load()
+    arr = (_lib.TransposeJob * len(mats))()
+    outs = []
+    for j, x in zip(arr, mats):
+        r, c = x.shape
+        o = torch.full((c, r), float("nan"), device=x.device)
+        j.src = ptr(_f(x)); j.rows = r; j.cols = c; j.ld = x.stride(0); j.dst = ptr(o); j.ldd = r
+        outs.append(o)
+    check(lib.mmda_transpose_f32(arr, len(mats), stream_ptr()), "mmda_transpose_f32")
+    return outs
+
 def colsum(X, out=None, out2=None):
     lib = load()
     M, N = X.shape

@@ -669,3 +669,12 @@ def test_device_eval_counts_match_reference_golden():
     assert np.array_equal(tp, ((y > 0) & (p > 0)).sum(0).cpu().numpy().astype(np.float64))
     assert np.array_equal(tp + fn, (y > 0).sum(0).cpu().numpy().astype(np.float64))
     assert np.array_equal(tp + fp, (p > 0).sum(0).cpu().numpy().astype(np.float64)) and st[19] == N
+
+
+def test_transpose_f32_multi():
+    from mmda_amd import ops
+    torch.manual_seed(2)
+    mats = [torch.randn(12, 768), torch.randn(2048, 128), torch.randn(128, 2048), torch.randn(33, 70), torch.randn(3, 128), torch.randn(1, 1)]
+    outs = ops.transpose_f32([m.to(dev()) for m in mats])
+    for m, o in zip(mats, outs):
+        assert torch.equal(o.cpu(), m.t().contiguous())
