@@ -24,6 +24,10 @@ extern "C" {
 #define MMDA_F32 0
 #define MMDA_BF16 1
 
+/* recurrent cell (reference config.py:147 --rnncell, models.py:39: nn.LSTM if 'lstm' else nn.GRU) */
+#define MMDA_CELL_LSTM 0
+#define MMDA_CELL_GRU 1
+
 #define MMDA_OK 0
 #define MMDA_EINVAL (-1)   /* bad argument / unsupported shape */
 #define MMDA_ELAUNCH (-2)  /* hipLaunch / runtime error (hipGetLastError text via mmda_last_error) */
@@ -216,6 +220,11 @@ typedef struct mmda_lstm_desc {
   int forward_only;    /* forward: 1 = no backward pass will follow (evaluation): the activated gates and the cell states need not be
                           stashed; `gates` / `cstash` contents are then unspecified after the call.  hseq and utt are written as usual.
                           Honoured by the wave-autonomous kernel, ignored (stash written) by the others. */
+  int cell;            /* MMDA_CELL_LSTM (0) or MMDA_CELL_GRU.  GRU: the caller pads torch's three gate blocks into the four slots,
+                          W_ih / b_ih rows [r; z; n; 0] and W_hh / b_hh rows [r; z; 0; n] (so `gates` slot 2 = x W_in^T + b_in and slot 3 =
+                          b_hn), see mmda_gru_pad_params.  Stash after forward: gates = [r, z, n, h W_hn^T + b_hn], cstash = h_t;
+                          after backward gates = d[pre_r, pre_z, pre_n, h W_hn^T + b_hn].  Streaming kernels only (xchg is ignored,
+                          gate_minor must be 0); all descriptors of one launch share the cell. */
 } mmda_lstm_desc;
 int64_t mmda_lstm_xchg_bytes(int H, int B);
 /* 1 if mmda_lstm_fwd/bwd would run these descriptors on the resident-weights kernels (so gate_minor = 1 may be used), else 0 */
@@ -227,6 +236,23 @@ int mmda_lstm_fwd(int mode, int n, const mmda_lstm_desc* descs, int B, int T, co
 /* backward: reads gates/cstash (forward stash), utt = d(utterance), d_hseq; overwrites `gates` with d(pre-activation)
  * (zero at padded positions) for the time-batched weight/input gradient GEMMs. */
 int mmda_lstm_bwd(int mode, int n, const mmda_lstm_desc* descs, int B, int T, const int32_t* lengths, void* stream);
+
+/* GRU parameters <-> the four-slot layout the recurrent kernels and the time-batched GEMMs work on (mmda_lstm_desc.cell).
+ * torch side (per direction d): w_ih[d] (3H, D), w_hh[d] (3H, H), b_ih[d] (3H), b_hh[d] (3H), gate blocks r, z, n (nn.GRU).
+ * padded side: pw_ih (8H, D) rows [dir][r; z; n; 0], pw_hh[d] (4H, H) rows [r; z; 0; n], pb_ih / pb_hh (8H) alike.
+ * mmda_gru_pad_params : padded <- torch.
+ * mmda_gru_unpad_grads: the same pointers name GRADIENTS: torch-side += padded, padded <- 0.  The padded bias gradient is ONE
+ *   vector, pb_ih (8H) = column sums of the four-slot gate gradients (what the weight-gradient GEMMs emit); it feeds both b_ih
+ *   (slots r, z, n) and b_hh (slots r, z and the fourth); pb_hh is not read.  Rows of the padded weight gradients that have no
+ *   torch gate (W_ih slot 4, W_hh slot 3) hold by-products of the padded GEMMs and are dropped. */
+#define MMDA_GRU_PAD_MAX 6
+typedef struct mmda_gru_pad_job {
+  int H, D;
+  float* w_ih[2]; float* w_hh[2]; float* b_ih[2]; float* b_hh[2];
+  float* pw_ih; float* pw_hh[2]; float* pb_ih; float* pb_hh;
+} mmda_gru_pad_job;
+int mmda_gru_pad_params(const mmda_gru_pad_job* jobs, int n, void* stream);
+int mmda_gru_unpad_grads(const mmda_gru_pad_job* jobs, int n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- fusion attention
  * Self-attention core of nn.TransformerEncoderLayer(d_model=E, nhead) on (S,B,E) with S small (6): softmax(QK^T/sqrt(hd))V
@@ -322,6 +348,7 @@ typedef struct mmda_misa_config {
   float threshold, reverse_grad_weight;         /* config.threshold, config.reverse_grad_weight */
   float diff_weight, sim_weight, recon_weight, conf_weight;   /* config.py:134-138 */
   int mode;                                     /* MMDA_F32 / MMDA_BF16 for the encoder + fusion GEMMs and the recurrences */
+  int rnncell;                                  /* MMDA_CELL_LSTM / MMDA_CELL_GRU (config.rnncell, models.py:39) */
 } mmda_misa_config;
 
 int mmda_misa_create(const mmda_misa_config* cfg, mmda_misa** out);

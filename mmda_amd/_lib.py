@@ -77,7 +77,13 @@ class LnBwdArgs(C.Structure):
 class LstmDesc(C.Structure):
     _fields_ = [("H", C.c_int), ("gates", C.c_void_p), ("cstash", C.c_void_p), ("hseq", C.c_void_p),
                 ("wpack", C.c_void_p * 2), ("wpack_c", C.c_void_p * 2), ("utt", C.c_void_p), ("layer", C.c_int), ("d_hseq", C.c_void_p),
-                ("xchg", C.c_void_p), ("epoch_base", C.c_uint32), ("gate_minor", C.c_int), ("forward_only", C.c_int)]
+                ("xchg", C.c_void_p), ("epoch_base", C.c_uint32), ("gate_minor", C.c_int), ("forward_only", C.c_int),
+                ("cell", C.c_int)]
+
+
+class GruPadJob(C.Structure):
+    _fields_ = [("H", C.c_int), ("D", C.c_int), ("w_ih", C.c_void_p * 2), ("w_hh", C.c_void_p * 2), ("b_ih", C.c_void_p * 2),
+                ("b_hh", C.c_void_p * 2), ("pw_ih", C.c_void_p), ("pw_hh", C.c_void_p * 2), ("pb_ih", C.c_void_p), ("pb_hh", C.c_void_p)]
 
 
 class MisaConfig(C.Structure):
@@ -86,8 +92,10 @@ class MisaConfig(C.Structure):
                 ("dropout", C.c_float), ("fusion_dropout", C.c_float), ("threshold", C.c_float),
                 ("reverse_grad_weight", C.c_float),
                 ("diff_weight", C.c_float), ("sim_weight", C.c_float), ("recon_weight", C.c_float), ("conf_weight", C.c_float),
-                ("mode", C.c_int)]
+                ("mode", C.c_int), ("rnncell", C.c_int)]
 
+
+CELL = {"lstm": 0, "gru": 1}
 
 # name -> (restype, argtypes).  Every symbol include/mmda_hip.h declares appears here (tests/test_abi.py checks it).
 _P, _I, _I64, _F, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
@@ -118,6 +126,8 @@ SIGNATURES = {
     "mmda_lstm_pack_whh_cluster": (_I, [_I, _P, _P, _P]),
     "mmda_lstm_fwd": (_I, [_I, _I, C.POINTER(LstmDesc), _I, _I, _P, _P]),
     "mmda_lstm_bwd": (_I, [_I, _I, C.POINTER(LstmDesc), _I, _I, _P, _P]),
+    "mmda_gru_pad_params": (_I, [C.POINTER(GruPadJob), _I, _P]),
+    "mmda_gru_unpad_grads": (_I, [C.POINTER(GruPadJob), _I, _P]),
     "mmda_attn_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _U64, _I, _P]),
     "mmda_attn_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _F, _U64, _I, _P]),
     "mmda_add": (_I, [_P, _P, _P, _I64, _P]),

@@ -128,7 +128,11 @@ template <int MODE> __device__ __forceinline__ float sig_(float x) { return MODE
 template <int MODE> __device__ __forceinline__ float tanh_(float x) { return MODE == MMDA_BF16 ? tanh_fast(x) : tanhf_(x); }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int MODE, int MAXT>
+// CELL = MMDA_CELL_GRU: nn.GRU (reference models.py:39) on the same machinery.  The caller lays the GRU's three gate blocks out
+// in the four LSTM slots: W_ih rows [r; z; n; 0], W_hh rows [r; z; 0; n], so slot 2 of `gates` holds x W_in^T + b_in, slot 3
+// of `gates` holds b_hn and the matrix cores add h W_hn^T to it:  r = s(s0), z = s(s1), q = s3, n = tanh(s2 + r q),
+// h' = (1 - z) n + z h.  Stash: gates <- [r, z, n, q], cstash <- h'.
+template <int MODE, int MAXT, int CELL>
 __global__ __launch_bounds__(NW * 64) void lstm_fwd_kernel(LstmLaunch L) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int per_mod = 2 * L.nbt;
@@ -227,10 +231,18 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_kernel(LstmLaunch L) {
         if (act) {
           float gi = sig_<MODE>(acc[0][r] + pre[0][r]);
           float gf = sig_<MODE>(acc[1][r] + pre[1][r]);
-          float gg = tanh_<MODE>(acc[2][r] + pre[2][r]);
-          float go = sig_<MODE>(acc[3][r] + pre[3][r]);
-          float cn = gf * c_reg[ti][r] + gi * gg;
-          float hn = go * tanh_<MODE>(cn);
+          float gg, go, cn, hn;
+          if (CELL == MMDA_CELL_GRU) {
+            go = acc[3][r] + pre[3][r];
+            gg = tanh_<MODE>(acc[2][r] + pre[2][r] + gi * go);
+            hn = (1.f - gf) * gg + gf * h_reg[ti][r];
+            cn = hn;
+          } else {
+            gg = tanh_<MODE>(acc[2][r] + pre[2][r]);
+            go = sig_<MODE>(acc[3][r] + pre[3][r]);
+            cn = gf * c_reg[ti][r] + gi * gg;
+            hn = go * tanh_<MODE>(cn);
+          }
           c_reg[ti][r] = cn;
           h_reg[ti][r] = hn;
           D.gates[gbase[r]] = gi;
@@ -268,7 +280,10 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_kernel(LstmLaunch L) {
 // Walks time in the reverse of the forward order.  Per step: (1) lane-local gate gradients from dh, dc and the
 // stash, written in place over `gates` (fp32, for the weight/input gradient GEMMs) and to LDS as the MFMA A operand;
 // (2) dh_{t-1}(16 x H) = dG(16 x 4H) * W_hh on the matrix cores with W_hh streamed in the backward packing.
-template <int MODE, int MAXT>
+// CELL = MMDA_CELL_GRU (stash [r, z, n, q], cstash = h): with dh the total gradient of h_t,
+//   dn = dh (1 - z), dz = dh (h_{t-1} - n), dpre_n = dn (1 - n^2), dq = dpre_n r, dr = dpre_n q;
+//   gates <- [dr r (1 - r), dz z (1 - z), dpre_n, dq]; the direct path dh z to h_{t-1} rides in the `dc` carry.
+template <int MODE, int MAXT, int CELL>
 __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmLaunch L) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int per_mod = 2 * L.nbt;
@@ -330,13 +345,23 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmLaunch L) {
           float dh = dh_rec[ti][r] + l_dh;
           bool fin = dir ? (t == 0) : (t == len_r[r] - 1);
           dh += fin ? l_ut : 0.f;
-          float tc = tanh_<MODE>(ct);
-          float dct = dc[ti][r] + dh * go * (1.f - tc * tc);
-          dp[0] = dct * gg * gi * (1.f - gi);
-          dp[1] = dct * cp * gf * (1.f - gf);
-          dp[2] = dct * gi * (1.f - gg * gg);
-          dp[3] = dh * tc * go * (1.f - go);
-          dc[ti][r] = dct * gf;
+          if (CELL == MMDA_CELL_GRU) {
+            dh += dc[ti][r];
+            float dpn = dh * (1.f - gf) * (1.f - gg * gg);
+            dp[0] = dpn * go * gi * (1.f - gi);
+            dp[1] = dh * (cp - gg) * gf * (1.f - gf);
+            dp[2] = dpn;
+            dp[3] = dpn * gi;
+            dc[ti][r] = dh * gf;
+          } else {
+            float tc = tanh_<MODE>(ct);
+            float dct = dc[ti][r] + dh * go * (1.f - tc * tc);
+            dp[0] = dct * gg * gi * (1.f - gi);
+            dp[1] = dct * cp * gf * (1.f - gf);
+            dp[2] = dct * gi * (1.f - gg * gg);
+            dp[3] = dh * tc * go * (1.f - go);
+            dc[ti][r] = dct * gf;
+          }
         }
         if (inb) {
 #pragma unroll
@@ -396,12 +421,12 @@ int pick_maxt(int n, const mmda_lstm_desc* d) {
   return ceil_div(nht, NW);
 }
 
-template <int MODE, bool BWD>
+template <int MODE, bool BWD, int CELL>
 int launch(int maxt, const LstmLaunch& L, size_t lds, hipStream_t s) {
   dim3 grid(L.n * 2 * L.nbt), block(NW * 64);
 #define LAUNCH_T(MT)                                                                                      \
   do {                                                                                                    \
-    auto kfn = BWD ? lstm_bwd_kernel<MODE, MT> : lstm_fwd_kernel<MODE, MT>;                               \
+    auto kfn = BWD ? lstm_bwd_kernel<MODE, MT, CELL> : lstm_fwd_kernel<MODE, MT, CELL>;                   \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, \
                             (int)lds) != hipSuccess) { (void)hipGetLastError(); }                         \
     hipLaunchKernelGGL(kfn, grid, block, lds, s, L);                                                      \
@@ -428,6 +453,7 @@ int lstm_common(int mode, int n, const mmda_lstm_desc* descs, int B, int T, cons
     if (d.H <= 0 || d.H > 512 || !d.gates || !d.cstash || !d.wpack[0] || !d.wpack[1] || !d.utt) return MMDA_EINVAL;
     if (!bwd && !d.hseq) return MMDA_EINVAL;
     if (d.layer != 0 && d.layer != 1) return MMDA_EINVAL;
+    if ((d.cell != MMDA_CELL_LSTM && d.cell != MMDA_CELL_GRU) || d.cell != descs[0].cell) return MMDA_EINVAL;
     L.d[i] = d;
     maxH = d.H > maxH ? d.H : maxH;
   }
@@ -448,8 +474,13 @@ int lstm_common(int mode, int n, const mmda_lstm_desc* descs, int B, int T, cons
   int maxt = pick_maxt(n, descs);
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  if (mode == MMDA_BF16) rc = bwd ? launch<MMDA_BF16, true>(maxt, L, lds, s) : launch<MMDA_BF16, false>(maxt, L, lds, s);
-  else rc = bwd ? launch<MMDA_F32, true>(maxt, L, lds, s) : launch<MMDA_F32, false>(maxt, L, lds, s);
+  const bool gru = descs[0].cell == MMDA_CELL_GRU;
+#define PICK(MODE_)                                                                                              \
+  (gru ? (bwd ? launch<MODE_, true, MMDA_CELL_GRU>(maxt, L, lds, s) : launch<MODE_, false, MMDA_CELL_GRU>(maxt, L, lds, s))  \
+       : (bwd ? launch<MODE_, true, MMDA_CELL_LSTM>(maxt, L, lds, s) : launch<MODE_, false, MMDA_CELL_LSTM>(maxt, L, lds, s)))
+  if (mode == MMDA_BF16) rc = PICK(MMDA_BF16);
+  else rc = PICK(MMDA_F32);
+#undef PICK
   if (rc != MMDA_OK) return rc;
   MMDA_CHECK_LAUNCH(bwd ? "mmda_lstm_bwd" : "mmda_lstm_fwd");
   return MMDA_OK;
@@ -525,6 +556,86 @@ extern "C" int mmda_lstm_pack_whh_cluster(int H, const float* whh, void* packed_
   MMDA_CHECK_LAUNCH("mmda_lstm_pack_whh_cluster");
   return MMDA_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ GRU <-> four-slot layout
+namespace {
+struct GruPad { mmda_gru_pad_job j[MMDA_GRU_PAD_MAX]; int start[MMDA_GRU_PAD_MAX + 1]; int n; };
+
+// One thread per element of the padded tensors of one layer: [W_ih (8H,D) | W_hh fwd (4H,H) | W_hh rev (4H,H) | bias (8H)].
+// UNPAD = false: padded <- torch layout (zero rows where a slot has no torch gate).
+// UNPAD = true : torch-layout gradient += padded gradient, padded gradient <- 0 (so the next step accumulates from zero).
+template <bool UNPAD>
+__global__ void gru_pad_kernel(GruPad P) {
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < MMDA_GRU_PAD_MAX; ++k)
+    if (k < P.n && (int)blockIdx.x >= P.start[k]) i = k;
+  const mmda_gru_pad_job& J = P.j[i];
+  const int H = J.H, D = J.D;
+  const int64_t nih = (int64_t)8 * H * D, nhh = (int64_t)4 * H * H, nb = 8 * H;
+  int64_t e = (int64_t)(blockIdx.x - P.start[i]) * blockDim.x + threadIdx.x;
+  if (e < nih) {
+    const int row = (int)(e / D), col = (int)(e % D);
+    const int dir = row / (4 * H), slot = (row % (4 * H)) / H, u = row % H;
+    float* t = J.w_ih[dir] + ((int64_t)slot * H + u) * D + col;            // slots 0..2 = torch's r, z, n
+    if (!UNPAD) J.pw_ih[e] = slot < 3 ? *t : 0.f;
+    else { float v = J.pw_ih[e]; J.pw_ih[e] = 0.f; if (slot < 3) *t += v; }
+    return;
+  }
+  e -= nih;
+  if (e < 2 * nhh) {
+    const int dir = (int)(e / nhh);
+    const int64_t e3 = e % nhh;
+    const int row = (int)(e3 / H), col = (int)(e3 % H), slot = row / H, u = row % H;
+    const int tg = slot == 3 ? 2 : slot;                                    // slot 3 = torch's n; slot 2 has no W_hh rows
+    float* t = J.w_hh[dir] + ((int64_t)tg * H + u) * H + col;
+    if (!UNPAD) J.pw_hh[dir][e3] = slot != 2 ? *t : 0.f;
+    else { float v = J.pw_hh[dir][e3]; J.pw_hh[dir][e3] = 0.f; if (slot != 2) *t += v; }
+    return;
+  }
+  e -= 2 * nhh;
+  if (e < nb) {
+    const int dir = (int)e / (4 * H), slot = ((int)e % (4 * H)) / H, u = (int)e % H;
+    const int tg = slot == 3 ? 2 : slot;
+    float* ti = J.b_ih[dir] + slot * H + u;
+    float* th = J.b_hh[dir] + tg * H + u;
+    if (!UNPAD) {
+      J.pb_ih[e] = slot < 3 ? *ti : 0.f;
+      J.pb_hh[e] = slot != 2 ? *th : 0.f;
+    } else {
+      float v = J.pb_ih[e]; J.pb_ih[e] = 0.f;                               // column sums of the four-slot gate gradients
+      if (slot < 3) *ti += v;
+      if (slot != 2) *th += v;
+    }
+  }
+}
+
+int gru_pad_common(const mmda_gru_pad_job* jobs, int n, void* stream, bool unpad) {
+  if (!jobs || n <= 0 || n > MMDA_GRU_PAD_MAX) return MMDA_EINVAL;
+  GruPad P;
+  P.n = n;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const mmda_gru_pad_job& j = jobs[i];
+    if (j.H <= 0 || j.H > 512 || j.D <= 0 || !j.pw_ih || !j.pb_ih || (!unpad && !j.pb_hh)) return MMDA_EINVAL;
+    for (int d = 0; d < 2; ++d)
+      if (!j.w_ih[d] || !j.w_hh[d] || !j.b_ih[d] || !j.b_hh[d] || !j.pw_hh[d]) return MMDA_EINVAL;
+    P.j[i] = j;
+    P.start[i] = blocks;
+    int64_t total = (int64_t)8 * j.H * j.D + (int64_t)8 * j.H * j.H + 8 * j.H;
+    blocks += (int)((total + 255) / 256);
+  }
+  for (int i = n; i < MMDA_GRU_PAD_MAX; ++i) P.j[i] = P.j[0];
+  for (int i = n; i <= MMDA_GRU_PAD_MAX; ++i) P.start[i] = blocks;
+  if (unpad) hipLaunchKernelGGL(gru_pad_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P);
+  else hipLaunchKernelGGL(gru_pad_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P);
+  MMDA_CHECK_LAUNCH(unpad ? "mmda_gru_unpad_grads" : "mmda_gru_pad_params");
+  return MMDA_OK;
+}
+}  // namespace
+
+extern "C" int mmda_gru_pad_params(const mmda_gru_pad_job* jobs, int n, void* stream) { return gru_pad_common(jobs, n, stream, false); }
+extern "C" int mmda_gru_unpad_grads(const mmda_gru_pad_job* jobs, int n, void* stream) { return gru_pad_common(jobs, n, stream, true); }
 
 extern "C" int mmda_lstm_fwd(int mode, int n, const mmda_lstm_desc* descs, int B, int T, const int32_t* lengths, void* stream) {
   return lstm_common(mode, n, descs, B, T, lengths, stream, false);

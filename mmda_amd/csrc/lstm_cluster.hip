@@ -1170,6 +1170,7 @@ bool cluster_applicable(int n, const mmda_lstm_desc* descs, int B, int T, bool b
   size_t lds = 0;
   for (int i = 0; i < n; ++i) {
     if (!descs[i].xchg) return false;
+    if (descs[i].cell != MMDA_CELL_LSTM) return false;          // the GRU cell runs on the streaming kernels (lstm.hip)
     if (bwd && (!descs[i].wpack_c[0] || !descs[i].wpack_c[1])) return false;
     if (descs[i].gate_minor != descs[0].gate_minor) return false;
     plans[i] = plan_for(descs[i].H);

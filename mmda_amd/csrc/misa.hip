@@ -22,6 +22,8 @@ struct Rnn {           // one bidirectional LSTM layer
   int64_t dgb, dgbT;                         // gate gradients (R, ldG) and transpose (8H, ldR)
   int64_t hbT;                               // hseq^T (2H, ldR)
   int ldD, ldG;
+  // GRU (cfg.rnncell): workspace offsets of the parameters / gradients in the four-slot layout (mmda_gru_pad_job); -1 for LSTM
+  int64_t pw_ih = -1, pw_hh[2] = {-1, -1}, pb_ih = -1, pb_hh = -1, gw_ih = -1, gw_hh[2] = {-1, -1}, gb = -1;
 };
 
 struct Mod {           // one modality: two stacked biLSTMs with a LayerNorm between, then a projection
@@ -53,6 +55,7 @@ struct mmda_misa {
   float* ws = nullptr; int64_t ws_floats = 0; int B = 0, T = 0;
   std::map<std::string, int64_t> tens;
   int64_t zero_begin = 0, zero_end = 0;      // activation-gradient region that is zeroed per step
+  int64_t gpad_begin = 0, gpad_end = 0;      // GRU: four-slot weight gradients (zeroed at set_workspace, re-zeroed by the unpad kernel)
   int64_t z, pmean, prstd, orig, x6, rsum, recon, dom_z, dom_h, dom, qkv, probs, ctx, attn_out, ln1_mean, ln1_rstd, x1, f1, f2,
       ln2_mean, ln2_rstd, hfused, logits, tcp, scores, labels, losses, diff_work;
   // K-major (transposed) fp32 copies of the fusion block's weights for its input-gradient GEMMs (made once per step)
@@ -98,15 +101,16 @@ void build_params(mmda_misa* m) {
     for (int l = 0; l < 2; ++l) {
       Rnn& r = md.rnn[l];
       r.H = md.H; r.D = l == 0 ? md.D : 2 * md.H;
+      const int ng = c.rnncell == MMDA_CELL_GRU ? 3 : 4;      // gate blocks per direction in the torch-layout parameters
       std::string pre = std::string(mn[i]) + "rnn" + (l == 0 ? "1" : "2") + ".";
-      r.w_ih = add_param(m, pre + "weight_ih_l0", 4 * r.H, r.D);
-      add_param(m, pre + "weight_ih_l0_reverse", 4 * r.H, r.D);
-      r.w_hh[0] = add_param(m, pre + "weight_hh_l0", 4 * r.H, r.H);
-      r.w_hh[1] = add_param(m, pre + "weight_hh_l0_reverse", 4 * r.H, r.H);
-      r.b_ih = add_param(m, pre + "bias_ih_l0", 4 * r.H, 0);
-      add_param(m, pre + "bias_ih_l0_reverse", 4 * r.H, 0);
-      r.b_hh = add_param(m, pre + "bias_hh_l0", 4 * r.H, 0);
-      add_param(m, pre + "bias_hh_l0_reverse", 4 * r.H, 0);
+      r.w_ih = add_param(m, pre + "weight_ih_l0", ng * r.H, r.D);
+      add_param(m, pre + "weight_ih_l0_reverse", ng * r.H, r.D);
+      r.w_hh[0] = add_param(m, pre + "weight_hh_l0", ng * r.H, r.H);
+      r.w_hh[1] = add_param(m, pre + "weight_hh_l0_reverse", ng * r.H, r.H);
+      r.b_ih = add_param(m, pre + "bias_ih_l0", ng * r.H, 0);
+      add_param(m, pre + "bias_ih_l0_reverse", ng * r.H, 0);
+      r.b_hh = add_param(m, pre + "bias_hh_l0", ng * r.H, 0);
+      add_param(m, pre + "bias_hh_l0_reverse", ng * r.H, 0);
     }
   }
   for (int i = 0; i < 3; ++i) {
@@ -201,6 +205,13 @@ int64_t layout(mmda_misa* m, int B, int T, bool commit) {
       r.dgb = k.take(R * r.ldG / 2); r.dgbT = k.take((int64_t)8 * r.H * ldR / 2);
       r.hbT = k.take((int64_t)2 * r.H * ldR / 2);
     }
+    if (c.rnncell == MMDA_CELL_GRU) {
+      for (int l = 0; l < 2; ++l) {
+        Rnn& r = md.rnn[l];
+        r.pw_ih = k.take((int64_t)8 * r.H * r.D); r.pw_hh[0] = k.take((int64_t)4 * r.H * r.H); r.pw_hh[1] = k.take((int64_t)4 * r.H * r.H);
+        r.pb_ih = k.take(8 * r.H); r.pb_hh = k.take(8 * r.H);
+      }
+    }
     md.xchg_floats = (mmda_lstm_xchg_bytes(md.H, B) + 3) / 4;
     md.xchg = md.xchg_floats > 0 ? k.take(md.xchg_floats) : -1;
     md.x = (i == 0) ? k.take(R * md.D) : -1;
@@ -236,6 +247,16 @@ int64_t layout(mmda_misa* m, int B, int T, bool commit) {
   o->priv_wT = k.take((int64_t)3 * hs * hs); o->sh_wT = k.take((int64_t)hs * hs);
   if (!c.use_cmd_sim) { o->d1_wT = k.take((int64_t)hs * hs); o->d2_wT = k.take((int64_t)hs * 3); }
   for (int i = 0; i < 3; ++i) o->pwT[i] = k.take((int64_t)4 * o->mod[i].H * hs);
+  o->gpad_begin = k.cur;
+  if (c.rnncell == MMDA_CELL_GRU) {
+    for (int i = 0; i < 3; ++i)
+      for (int l = 0; l < 2; ++l) {
+        Rnn& r = o->mod[i].rnn[l];
+        r.gw_ih = k.take((int64_t)8 * r.H * r.D); r.gw_hh[0] = k.take((int64_t)4 * r.H * r.H); r.gw_hh[1] = k.take((int64_t)4 * r.H * r.H);
+        r.gb = k.take(8 * r.H);
+      }
+  }
+  o->gpad_end = k.cur;
   // ---- the loss sums and the activation gradients seeded by the losses (zeroed every step by ONE memset, contiguous)
   o->zero_begin = k.cur;
   o->losses = k.take(8);
@@ -377,6 +398,38 @@ int side_join(mmda_misa* m, void* main_stream) {
 #define PP(off) (m->P + (off))
 #define GG(off) (m->G + (off))
 
+// Recurrent-layer parameters / gradients as the kernels see them: the bound flat buffers (LSTM) or the four-slot workspace
+// copies (GRU; filled by mmda_gru_pad_params at the top of forward, folded back by mmda_gru_unpad_grads at the end of backward).
+inline bool is_gru(const mmda_misa* m) { return m->cfg.rnncell == MMDA_CELL_GRU; }
+inline float* rW_ih(mmda_misa* m, const Rnn& r) { return is_gru(m) ? WS(r.pw_ih) : PP(r.w_ih); }
+inline float* rW_hh(mmda_misa* m, const Rnn& r, int d) { return is_gru(m) ? WS(r.pw_hh[d]) : PP(r.w_hh[d]); }
+inline float* rB_ih(mmda_misa* m, const Rnn& r) { return is_gru(m) ? WS(r.pb_ih) : PP(r.b_ih); }
+inline float* rB_hh(mmda_misa* m, const Rnn& r) { return is_gru(m) ? WS(r.pb_hh) : PP(r.b_hh); }
+inline float* gW_ih(mmda_misa* m, const Rnn& r) { return is_gru(m) ? WS(r.gw_ih) : GG(r.w_ih); }
+inline float* gW_hh(mmda_misa* m, const Rnn& r, int d) { return is_gru(m) ? WS(r.gw_hh[d]) : GG(r.w_hh[d]); }
+inline float* gB_ih(mmda_misa* m, const Rnn& r) { return is_gru(m) ? WS(r.gb) : GG(r.b_ih); }
+inline float* gB_hh(mmda_misa* m, const Rnn& r) { return is_gru(m) ? nullptr : GG(r.b_hh); }
+
+// GRU: jobs for the pad / unpad kernels; `base` is the flat parameter (pad) or gradient (unpad) buffer
+int gru_jobs(mmda_misa* m, float* base, bool grads, mmda_gru_pad_job* j) {
+  int n = 0;
+  for (int i = 0; i < 3; ++i)
+    for (int l = 0; l < 2; ++l, ++n) {
+      const Rnn& r = m->mod[i].rnn[l];
+      j[n] = mmda_gru_pad_job{};
+      j[n].H = r.H; j[n].D = r.D;
+      for (int d = 0; d < 2; ++d) {
+        j[n].w_ih[d] = base + r.w_ih + (int64_t)d * 3 * r.H * r.D; j[n].w_hh[d] = base + r.w_hh[d];
+        j[n].b_ih[d] = base + r.b_ih + (int64_t)d * 3 * r.H; j[n].b_hh[d] = base + r.b_hh + (int64_t)d * 3 * r.H;
+        j[n].pw_hh[d] = grads ? WS(r.gw_hh[d]) : WS(r.pw_hh[d]);
+      }
+      j[n].pw_ih = grads ? WS(r.gw_ih) : WS(r.pw_ih);
+      j[n].pb_ih = grads ? WS(r.gb) : WS(r.pb_ih);
+      j[n].pb_hh = grads ? nullptr : WS(r.pb_hh);
+    }
+  return n;
+}
+
 int check_ready(const mmda_misa* m) {
   if (!m || !m->P || !m->ws) return MMDA_EINVAL;
   return MMDA_OK;
@@ -390,6 +443,7 @@ extern "C" int mmda_misa_create(const mmda_misa_config* cfg, mmda_misa** out) {
   if (cfg->vocab <= 0 || cfg->d_t <= 0 || cfg->d_v <= 0 || cfg->d_a <= 0 || cfg->hidden <= 0 || cfg->ncls <= 0) return MMDA_EINVAL;
   if (cfg->d_t > 512 || cfg->d_v > 512 || cfg->d_a > 512 || cfg->hidden % NHEAD || cfg->hidden > 1024) return MMDA_EINVAL;
   if (cfg->mode != MMDA_F32 && cfg->mode != MMDA_BF16) return MMDA_EINVAL;
+  if (cfg->rnncell != MMDA_CELL_LSTM && cfg->rnncell != MMDA_CELL_GRU) return MMDA_EINVAL;
   mmda_misa* m = new mmda_misa();
   m->cfg = *cfg;
   build_params(m);
@@ -435,6 +489,8 @@ extern "C" int mmda_misa_set_workspace(mmda_misa* m, float* ws, int64_t floats, 
   // cluster-exchange flags must start at zero (setup time, not on the step path)
   for (int i = 0; i < 3; ++i)
     if (m->mod[i].xchg >= 0 && hipMemset(ws + m->mod[i].xchg, 0, sizeof(float) * m->mod[i].xchg_floats) != hipSuccess) return MMDA_ELAUNCH;
+  if (m->gpad_end > m->gpad_begin && hipMemset(ws + m->gpad_begin, 0, sizeof(float) * (m->gpad_end - m->gpad_begin)) != hipSuccess)
+    return MMDA_ELAUNCH;
   return MMDA_OK;
 }
 extern "C" int64_t mmda_misa_tensor_offset(const mmda_misa* m, const char* name) {
@@ -496,6 +552,12 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
 
   // W_hh -> MFMA fragment order (weights changed since the last step): all twelve matrices in one launch, on the side stream
   // underneath the embedding gather and the first input GEMM; joined before the first recurrent kernel.
+  if (is_gru(m)) {          // GRU parameters -> four-slot layout (everything below reads the padded copies)
+    mmda_gru_pad_job gj[MMDA_GRU_PAD_MAX];
+    int n = gru_jobs(m, m->P, false, gj);
+    x.rc = mmda_gru_pad_params(gj, n, stream);
+    if (x.rc) return x.rc;
+  }
   {
     int Hs[12]; const float* Wp[12]; void* Fp[12]; void* Bp[12]; void* Cp[12];
     int k = 0;
@@ -503,7 +565,7 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
       for (int l = 0; l < 2; ++l)
         for (int d = 0; d < 2; ++d, ++k) {
           Rnn& r = m->mod[i].rnn[l];
-          Hs[k] = r.H; Wp[k] = PP(r.w_hh[d]); Fp[k] = WS(r.pack_f[d]); Bp[k] = WS(r.pack_b[d]); Cp[k] = WS(r.pack_c[d]);
+          Hs[k] = r.H; Wp[k] = rW_hh(m, r, d); Fp[k] = WS(r.pack_f[d]); Bp[k] = WS(r.pack_b[d]); Cp[k] = WS(r.pack_c[d]);
         }
     const bool want_c = m->use_cluster && mode == MMDA_BF16;
     void* ss = nullptr;
@@ -549,6 +611,7 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
       probe[i].wpack[0] = WS(r.pack_f[0]); probe[i].wpack[1] = WS(r.pack_f[1]);
       probe[i].wpack_c[0] = WS(r.pack_c[0]); probe[i].wpack_c[1] = WS(r.pack_c[1]); probe[i].utt = WS(md.utt);
       probe[i].xchg = (m->use_cluster && md.xchg >= 0) ? (void*)WS(md.xchg) : nullptr; probe[i].gate_minor = 1;
+      probe[i].cell = c.rnncell;
     }
     gm = mmda_lstm_resident_applicable(mode, 3, probe, B, T, 0) && mmda_lstm_resident_applicable(mode, 3, probe, B, T, 1);
   }
@@ -561,7 +624,7 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
     for (int i = 0; i < 3; ++i) {
       for (int l = 0; l < 2; ++l) {
         Rnn& r = m->mod[i].rnn[l];
-        cj[n++] = mmda_convert_job{PP(r.w_ih), r.D, 8 * r.H, r.D, nullptr, WS(r.wb), r.ldD, inf ? nullptr : WS(r.wbT), r.ldG, gm ? r.H : 0};
+        cj[n++] = mmda_convert_job{rW_ih(m, r), r.D, 8 * r.H, r.D, nullptr, WS(r.wb), r.ldD, inf ? nullptr : WS(r.wbT), r.ldG, gm ? r.H : 0};
       }
       Rnn& r0 = m->mod[i].rnn[0];
       if (i == 0) cj[n++] = mmda_convert_job{PP(m->embed), c.d_t, R, c.d_t, t_ids, WS(r0.xb), r0.ldD, inf ? nullptr : WS(r0.xbT), ldR};
@@ -583,17 +646,17 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
       if (bfg) {
         bg[i] = mmda_gemm_bf16_args{};
         bg[i].M = R; bg[i].N = 8 * r.H; bg[i].K = r.D; bg[i].A = WS(r.xb); bg[i].lda = r.ldD; bg[i].B = WS(r.wb); bg[i].ldb = r.ldD;
-        bg[i].C = WS(md.gates[l]); bg[i].ldc = 8 * r.H; bg[i].bias = PP(r.b_ih); bg[i].bias2 = PP(r.b_hh);
+        bg[i].C = WS(md.gates[l]); bg[i].ldc = 8 * r.H; bg[i].bias = rB_ih(m, r); bg[i].bias2 = rB_hh(m, r);
         bg[i].perm_n_H = gm ? r.H : 0;
       } else {
-        gemm(x, mode, 0, 1, R, 8 * r.H, r.D, in, r.D, PP(r.w_ih), r.D, WS(md.gates[l]), 8 * r.H, PP(r.b_ih), PP(r.b_hh));
+        gemm(x, mode, 0, 1, R, 8 * r.H, r.D, in, r.D, rW_ih(m, r), r.D, WS(md.gates[l]), 8 * r.H, rB_ih(m, r), rB_hh(m, r));
       }
       desc[i] = mmda_lstm_desc{};
       desc[i].H = r.H; desc[i].gates = WS(md.gates[l]); desc[i].cstash = WS(md.c[l]); desc[i].hseq = WS(md.hseq[l]);
       desc[i].wpack[0] = WS(r.pack_f[0]); desc[i].wpack[1] = WS(r.pack_f[1]);
       desc[i].utt = WS(md.utt); desc[i].layer = l; desc[i].d_hseq = nullptr;
       desc[i].xchg = (m->use_cluster && md.xchg >= 0) ? (void*)WS(md.xchg) : nullptr; desc[i].epoch_base = m->epoch;
-      desc[i].gate_minor = gm; desc[i].forward_only = inf;
+      desc[i].gate_minor = gm; desc[i].forward_only = inf; desc[i].cell = c.rnncell;
     }
     if (bfg && !x.rc) x.rc = mmda_gemm_bf16_grouped(bg, 3, stream);
     m->epoch += (unsigned)T + 2u;
@@ -1029,7 +1092,7 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
       desc[i].wpack_c[0] = m->packed_c_valid ? WS(r.pack_c[0]) : nullptr; desc[i].wpack_c[1] = m->packed_c_valid ? WS(r.pack_c[1]) : nullptr;
       desc[i].utt = WS(md.d_utt); desc[i].layer = l; desc[i].d_hseq = l == 0 ? WS(md.d_hseq1) : nullptr;
       desc[i].xchg = (m->use_cluster && md.xchg >= 0) ? (void*)WS(md.xchg) : nullptr; desc[i].epoch_base = m->epoch;
-      desc[i].gate_minor = m->gate_minor;
+      desc[i].gate_minor = m->gate_minor; desc[i].cell = c.rnncell;
     }
     m->epoch += (unsigned)T + 2u;
     ev_rec(m, m->ev_bwd, l == 1 ? 2 : 3, 0, stream);
@@ -1066,13 +1129,13 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
       // dW_ih (both directions stacked); db_ih = db_hh = column sums of dG ride along as a virtual ones-column
       if (bfg) {
         mmda_gemm_bf16_args g = {};
-        g.M = G8; g.N = r.D; g.K = R; g.A = dgT; g.lda = m->ldR; g.B = WS(r.xbT); g.ldb = m->ldR; g.C = GG(r.w_ih); g.ldc = r.D;
-        g.accumulate = 1; g.bias_grad = GG(r.b_ih); g.bias_grad2 = GG(r.b_hh); g.perm_m_H = m->gate_minor ? H : 0;
+        g.M = G8; g.N = r.D; g.K = R; g.A = dgT; g.lda = m->ldR; g.B = WS(r.xbT); g.ldb = m->ldR; g.C = gW_ih(m, r); g.ldc = r.D;
+        g.accumulate = 1; g.bias_grad = gB_ih(m, r); g.bias_grad2 = gB_hh(m, r); g.perm_m_H = m->gate_minor ? H : 0;
         wq.push_back(g);
       } else {
         mmda_gemm_args e = {};
-        e.bias_grad = GG(r.b_ih); e.bias_grad2 = GG(r.b_hh);
-        gemm(x, mode, 1, 0, G8, r.D, R, dG, G8, in, r.D, GG(r.w_ih), r.D, nullptr, nullptr, 1, 0, 1, 0, 0, 0, 0, &e);
+        e.bias_grad = gB_ih(m, r); e.bias_grad2 = gB_hh(m, r);
+        gemm(x, mode, 1, 0, G8, r.D, R, dG, G8, in, r.D, gW_ih(m, r), r.D, nullptr, nullptr, 1, 0, 1, 0, 0, 0, 0, &e);
       }
       // dW_hh: forward direction pairs dG[t] with h[t-1]; reverse direction pairs dG[t] with h[t+1] (zero past len)
       if (T > 1) {
@@ -1080,14 +1143,14 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
           mmda_gemm_bf16_args g = {};
           g.M = 4 * H; g.N = H; g.K = (T - 1) * B; g.lda = m->ldR; g.ldb = m->ldR; g.ldc = H; g.accumulate = 1;
           g.perm_m_H = m->gate_minor ? H : 0;
-          g.A = dgT + B; g.B = hT; g.C = GG(r.w_hh[0]);
+          g.A = dgT + B; g.B = hT; g.C = gW_hh(m, r, 0);
           wq.push_back(g);
-          g.A = dgT + (int64_t)4 * H * m->ldR; g.B = hT + (int64_t)H * m->ldR + B; g.C = GG(r.w_hh[1]);
+          g.A = dgT + (int64_t)4 * H * m->ldR; g.B = hT + (int64_t)H * m->ldR + B; g.C = gW_hh(m, r, 1);
           wq.push_back(g);
         } else {
           const float* hs_ = WS(md.hseq[l]);
-          gemm(x, mode, 1, 0, 4 * H, H, (T - 1) * B, dG + (int64_t)B * G8, G8, hs_, 2 * H, GG(r.w_hh[0]), H, nullptr, nullptr, 1);
-          gemm(x, mode, 1, 0, 4 * H, H, (T - 1) * B, dG + 4 * H, G8, hs_ + (int64_t)B * 2 * H + H, 2 * H, GG(r.w_hh[1]), H, nullptr,
+          gemm(x, mode, 1, 0, 4 * H, H, (T - 1) * B, dG + (int64_t)B * G8, G8, hs_, 2 * H, gW_hh(m, r, 0), H, nullptr, nullptr, 1);
+          gemm(x, mode, 1, 0, 4 * H, H, (T - 1) * B, dG + 4 * H, G8, hs_ + (int64_t)B * 2 * H + H, 2 * H, gW_hh(m, r, 1), H, nullptr,
                nullptr, 1);
         }
       }
@@ -1099,7 +1162,7 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
           g.M = R; g.N = r.D; g.K = G8; g.A = WS(r.dgb); g.lda = r.ldG; g.B = WS(r.wbT); g.ldb = r.ldG; g.C = dst; g.ldc = r.D;
           bmain.push_back(g);
         } else {
-          gemm(x, mode, 0, 0, R, r.D, G8, dG, G8, PP(r.w_ih), r.D, dst, r.D);
+          gemm(x, mode, 0, 0, R, r.D, G8, dG, G8, rW_ih(m, r), r.D, dst, r.D);
         }
       }
     }
@@ -1133,6 +1196,11 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
   }
   if (!m->ev.empty()) { if (m->ev_seen_b % m->ev_stride == 0) m->ev_bwd++; m->ev_seen_b++; }
   if (!x.rc) x.rc = side_join(m, stream);      // every gradient is complete on `stream` when backward returns
+  if (!x.rc && is_gru(m)) {                    // fold the four-slot weight gradients into the torch-layout gradient buffer
+    mmda_gru_pad_job gj[MMDA_GRU_PAD_MAX];
+    int n = gru_jobs(m, m->G, true, gj);
+    x.rc = mmda_gru_unpad_grads(gj, n, stream);
+  }
   return x.rc;
 }
 

@@ -65,8 +65,8 @@ class MISA(nn.Module):
         if getattr(config, "extractor", "lstm") == "transformer":
             # the reference prints a TODO and calls exit() here (models.py:33-36)
             raise NotImplementedError("extractor='transformer' is a TODO in the reference as well")
-        if getattr(config, "rnncell", "lstm") != "lstm":
-            raise NotImplementedError("only rnncell='lstm' has HIP kernels (GRU is SURVEY.md 8f row f4)")
+        # reference models.py:39: nn.LSTM if config.rnncell == 'lstm' else nn.GRU
+        self.rnncell = "lstm" if getattr(config, "rnncell", "lstm") == "lstm" else "gru"
         if getattr(config, "use_bert", False):
             raise NotImplementedError("use_bert=True needs a hub download; the GloVe/LSTM text branch is the hot path")
         self.activation_name = activation_name(config.activation)
@@ -83,7 +83,7 @@ class MISA(nn.Module):
             reverse_grad_weight=float(getattr(config, "reverse_grad_weight", 1.0)),
             diff_weight=float(getattr(config, "diff_weight", 0.3)), sim_weight=float(getattr(config, "sim_weight", 0.7)),
             recon_weight=float(getattr(config, "recon_weight", 0.7)), conf_weight=float(getattr(config, "conf_weight", 0.3)),
-            mode=_lib.BF16 if self.precision == "bf16" else _lib.F32)
+            mode=_lib.BF16 if self.precision == "bf16" else _lib.F32, rnncell=_lib.CELL[self.rnncell])
         h = C.c_void_p()
         _lib.check(lib.mmda_misa_create(C.byref(cc), C.byref(h)), "mmda_misa_create")
         self._h = h

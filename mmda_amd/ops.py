@@ -281,9 +281,42 @@ def _from_gate_minor(x, H):
     return x.reshape(*x.shape[:-1], H, 4).transpose(-1, -2).reshape(*x.shape[:-1], 4 * H).contiguous()
 
 
-def lstm_bidir_fwd(pre, whh_f, whh_r, lengths, *, mode="fp32", layer=0, utt=None, resident=False, gate_minor=False):
+def gru_pad(rnn_params, H, D, device):
+    """torch nn.GRU(bidirectional) parameters -> the four-slot layout (mmda_gru_pad_params).  rnn_params: dict with
+    weight_ih_l0, weight_hh_l0, bias_ih_l0, bias_hh_l0 and their _reverse twins.  Returns (job, padded dict); the job can be
+    handed to gru_unpad_grads with gradient tensors of the same shapes."""
+    lib = load()
+    t = {k: _f(v.detach().to(device)) for k, v in rnn_params.items()}
+    pad = dict(w_ih=torch.full((8 * H, D), float("nan"), device=device), w_hh_f=torch.full((4 * H, H), float("nan"), device=device),
+               w_hh_r=torch.full((4 * H, H), float("nan"), device=device), b_ih=torch.full((8 * H,), float("nan"), device=device),
+               b_hh=torch.full((8 * H,), float("nan"), device=device))
+    check(lib.mmda_gru_pad_params((_lib.GruPadJob * 1)(_gru_job(t, pad, H, D)), 1, stream_ptr()), "gru_pad_params")
+    return pad, t
+
+
+def _gru_job(t, pad, H, D):
+    j = _lib.GruPadJob()
+    j.H, j.D = H, D
+    for d, sfx in enumerate(("", "_reverse")):
+        j.w_ih[d] = ptr(t["weight_ih_l0" + sfx]); j.w_hh[d] = ptr(t["weight_hh_l0" + sfx])
+        j.b_ih[d] = ptr(t["bias_ih_l0" + sfx]); j.b_hh[d] = ptr(t["bias_hh_l0" + sfx])
+    j.pw_ih = ptr(pad["w_ih"]); j.pw_hh[0] = ptr(pad["w_hh_f"]); j.pw_hh[1] = ptr(pad["w_hh_r"])
+    j.pb_ih = ptr(pad["b_ih"]); j.pb_hh = ptr(pad["b_hh"]) if pad.get("b_hh") is not None else None
+    return j
+
+
+def gru_unpad_grads(grads, pad_grads, H, D):
+    """grads (torch-layout dict, accumulated into) += pad_grads (four-slot: w_ih, w_hh_f, w_hh_r, b_ih = gate-gradient column
+    sums); pad_grads are zeroed."""
+    lib = load()
+    check(lib.mmda_gru_unpad_grads((_lib.GruPadJob * 1)(_gru_job(grads, dict(pad_grads, b_hh=None), H, D)), 1, stream_ptr()),
+          "gru_unpad_grads")
+
+
+def lstm_bidir_fwd(pre, whh_f, whh_r, lengths, *, mode="fp32", layer=0, utt=None, resident=False, gate_minor=False, cell="lstm"):
     """pre: (T,B,2,4H) = x W_ih^T + b_ih + b_hh per direction.  Returns dict(hseq, gates, cstash, utt, packs).
-    gate_minor (resident only): the kernels see `gates` as [dir][unit][gate]; inputs/outputs here stay in torch's order."""
+    gate_minor (resident only): the kernels see `gates` as [dir][unit][gate]; inputs/outputs here stay in torch's order.
+    cell="gru": pre / whh_* are in the four-slot layout (gru_pad)."""
     lib = load()
     T, B, _, G4 = pre.shape
     H = G4 // 4
@@ -299,9 +332,10 @@ def lstm_bidir_fwd(pre, whh_f, whh_r, lengths, *, mode="fp32", layer=0, utt=None
     pcs = (lstm_pack_cluster(whh_f), lstm_pack_cluster(whh_r)) if (resident and MODE[mode] == BF16) else (None, None)
     d = (_lib.LstmDesc * 1)(_desc(H, gates, cst, hseq, pf0, pf1, utt, layer, None, xchg, 0))
     d[0].gate_minor = int(gate_minor)
+    d[0].cell = _lib.CELL[cell]
     check(lib.mmda_lstm_fwd(MODE[mode], 1, d, B, T, ptr(len_dev), stream_ptr()), "lstm_fwd")
     return dict(hseq=hseq, gates=gates, cstash=cst, utt=utt, packs=(pf0, pb0, pf1, pb1), len_dev=len_dev, xchg=xchg, T=T, pcs=pcs,
-                gate_minor=bool(gate_minor), H=H)
+                gate_minor=bool(gate_minor), H=H, cell=cell)
 
 
 def lstm_bidir_bwd(fw, d_utt, d_hseq, *, mode="fp32", layer=0):
@@ -314,6 +348,7 @@ def lstm_bidir_bwd(fw, d_utt, d_hseq, *, mode="fp32", layer=0):
     pc0, pc1 = fw.get("pcs", (None, None))
     d = (_lib.LstmDesc * 1)(_desc(H, gates, fw["cstash"], fw["hseq"], pb0, pb1, d_utt, layer, d_hseq, fw.get("xchg"), T + 2, pc0, pc1))
     d[0].gate_minor = int(fw.get("gate_minor", False))
+    d[0].cell = _lib.CELL[fw.get("cell", "lstm")]
     check(lib.mmda_lstm_bwd(MODE[mode], 1, d, B, T, ptr(fw["len_dev"]), stream_ptr()), "lstm_bwd")
     return _from_gate_minor(gates, H) if fw.get("gate_minor") else gates
 

@@ -73,12 +73,14 @@ def param_shapes(cfg) -> Dict[str, tuple]:
     dt, dv, da, hs = cfg.embedding_size, cfg.visual_size, cfg.acoustic_size, cfg.hidden_size
     s: Dict[str, tuple] = {"embed.weight": (cfg.vocab_size, dt)}
 
+    ng = 4 if getattr(cfg, "rnncell", "lstm") == "lstm" else 3      # models.py:39: nn.LSTM if rnncell == 'lstm' else nn.GRU
+
     def rnn(prefix, din, h):
         for sfx in ("", "_reverse"):
-            s[f"{prefix}.weight_ih_l0{sfx}"] = (4 * h, din)
-            s[f"{prefix}.weight_hh_l0{sfx}"] = (4 * h, h)
-            s[f"{prefix}.bias_ih_l0{sfx}"] = (4 * h,)
-            s[f"{prefix}.bias_hh_l0{sfx}"] = (4 * h,)
+            s[f"{prefix}.weight_ih_l0{sfx}"] = (ng * h, din)
+            s[f"{prefix}.weight_hh_l0{sfx}"] = (ng * h, h)
+            s[f"{prefix}.bias_ih_l0{sfx}"] = (ng * h,)
+            s[f"{prefix}.bias_hh_l0{sfx}"] = (ng * h,)
 
     rnn("trnn1", dt, dt); rnn("trnn2", 2 * dt, dt)
     rnn("vrnn1", dv, dv); rnn("vrnn2", 2 * dv, dv)
@@ -165,22 +167,22 @@ def synth_batch(cfg, B: int, T: int, seed: int, ragged: bool):
 
 
 # ----------------------------------------------------------------------------- encoders
-def _bilstm(x, lengths, P: Params, prefix: str, din: int, h: int):
-    """nn.LSTM(bidirectional) over a packed sequence (reference models.py:164-171)."""
-    rnn = nn.LSTM(din, h, bidirectional=True)
+def _bilstm(x, lengths, P: Params, prefix: str, din: int, h: int, cell: str = "lstm"):
+    """nn.LSTM / nn.GRU (bidirectional) over a packed sequence (reference models.py:39, 164-178)."""
+    rnn = nn.LSTM(din, h, bidirectional=True) if cell == "lstm" else nn.GRU(din, h, bidirectional=True)
     names = [n for n, _ in rnn.named_parameters()]
     packed = pack_padded_sequence(x, lengths, enforce_sorted=False)
-    out, (hn, _) = torch.func.functional_call(rnn, {n: P[f"{prefix}.{n}"] for n in names}, (packed,))
-    return out, hn
+    out, hn = torch.func.functional_call(rnn, {n: P[f"{prefix}.{n}"] for n in names}, (packed,))
+    return out, (hn[0] if cell == "lstm" else hn)          # models.py:166-169
 
 
-def encode_modality(x, lengths, P: Params, m: str, d: int):
-    """Two stacked biLSTMs with LayerNorm between (models.py:163-180) and the utterance vector
+def encode_modality(x, lengths, P: Params, m: str, d: int, cell: str = "lstm"):
+    """Two stacked bidirectional RNNs with LayerNorm between (models.py:163-180) and the utterance vector
     [h1_fwd, h2_fwd, h1_bwd, h2_bwd] per sample (models.py:203)."""
-    out1, h1 = _bilstm(x, lengths, P, f"{m}rnn1", x.shape[-1], d)
+    out1, h1 = _bilstm(x, lengths, P, f"{m}rnn1", x.shape[-1], d, cell)
     padded, _ = pad_packed_sequence(out1)
     normed = F.layer_norm(padded, (2 * d,), P[f"{m}layer_norm.weight"], P[f"{m}layer_norm.bias"], LN_EPS)
-    _, h2 = _bilstm(normed, lengths, P, f"{m}rnn2", 2 * d, d)
+    _, h2 = _bilstm(normed, lengths, P, f"{m}rnn2", 2 * d, d, cell)
     B = x.shape[1]
     return torch.cat((h1, h2), dim=2).permute(1, 0, 2).reshape(B, 4 * d)
 
@@ -251,9 +253,10 @@ def forward(P: Params, cfg, t, v, a, lengths) -> SimpleNamespace:
     o = SimpleNamespace()
     lengths = lengths.cpu()
     emb = P["embed.weight"][t]                                          # models.py:201
-    utt = {"t": encode_modality(emb, lengths, P, "t", dt),
-           "v": encode_modality(v, lengths, P, "v", dv),
-           "a": encode_modality(a, lengths, P, "a", da)}
+    cell = "lstm" if getattr(cfg, "rnncell", "lstm") == "lstm" else "gru"
+    utt = {"t": encode_modality(emb, lengths, P, "t", dt, cell),
+           "v": encode_modality(v, lengths, P, "v", dv, cell),
+           "a": encode_modality(a, lengths, P, "a", da, cell)}
     o.utterance_t, o.utterance_v, o.utterance_a = utt["t"], utt["v"], utt["a"]
     priv_names = {"t": "private_t.private_t_1", "v": "private_v.private_v_1", "a": "private_a.private_a_3"}
     for m in "tva":

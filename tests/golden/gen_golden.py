@@ -9,7 +9,8 @@ What runs the reference's own code: ``models.MISA`` (src/models.py), ``utils.Dif
 criteria objects the solver constructs (solver.py:108-118), one class at a time like the solver
 does.  The oracle (oracle/misa_oracle.py) states the same losses in closed form; the two must agree.
 
-Usage:  python tests/golden/gen_golden.py            (writes next to this file)
+Usage:  python tests/golden/gen_golden.py [substring]   (writes next to this file; with an argument only the cases whose
+                                                         name contains it are regenerated)
 """
 import json
 import os
@@ -23,6 +24,7 @@ import torch.nn as nn
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
+ONLY = sys.argv[1] if len(sys.argv) > 1 else ""
 sys.argv = sys.argv[:1]
 sys.path.insert(0, "/root/reference/src")
 
@@ -106,6 +108,8 @@ SIDE = ["utt_t_orig", "utt_v_orig", "utt_a_orig", "utt_private_t", "utt_private_
 
 
 def run_case(name, cfg, B, T, seed, ragged, full_tensors, steps=3):
+    if ONLY not in name:
+        return
     params = orc.synth_params(cfg, seed)
     model = build_reference(cfg, params)
     losses = SolverLosses(cfg)
@@ -176,6 +180,12 @@ def main():
              full_tensors=False, steps=3)
     run_case("real_b16_t20_adv_confid", orc.default_config(use_cmd_sim=False, use_confidNet=True, **real),
              B=16, T=20, seed=6, ragged=True, full_tensors=False)
+    # config.rnncell != 'lstm' -> nn.GRU encoders (reference models.py:39)
+    run_case("tiny_gru_ragged", orc.default_config(rnncell="gru", use_confidNet=True, **tiny), B=5, T=8, seed=7, ragged=True,
+             full_tensors=True)
+    run_case("real_gru_b8_t12_ragged", orc.default_config(rnncell="gru", **real), B=8, T=12, seed=8, ragged=True, full_tensors=False)
+    run_case("real_gru_b16_t20_adv", orc.default_config(rnncell="gru", use_cmd_sim=False, **real), B=16, T=20, seed=9, ragged=False,
+             full_tensors=False)
 
 
 if __name__ == "__main__":

@@ -10,8 +10,15 @@ from oracle import misa_oracle as orc
 from golden_util import batch_of, load_case
 
 
-def test_bf16_weight_rounding_floor_on_gradients():
-    z, meta, cfg = load_case("real_b8_t12_ragged")
+import pytest
+
+
+@pytest.mark.parametrize("name,lo,hi", [("real_b8_t12_ragged", 5e-3, 8e-2), ("real_gru_b16_t20_adv", 5e-2, 1.3e-1)])
+def test_bf16_weight_rounding_floor_on_gradients(name, lo, hi):
+    """The GRU fixture sits higher (1.0e-1 on vrnn1.weight_hh_l0_reverse): its candidate gate multiplies the recurrent product by
+    the reset gate inside the tanh, one more place where a rounded W_hh enters each step.  test_bf16_path_within_1e2 bounds the
+    GRU fixtures' gradients at 1.5e-1 accordingly."""
+    z, meta, cfg = load_case(name)
     P = orc.synth_params(cfg, meta["seed"])
     batch = batch_of(z)
     o, L, G = orc.loss_and_grads(P, cfg, batch)
@@ -24,4 +31,4 @@ def test_bf16_weight_rounding_floor_on_gradients():
         worst = max(worst, float((Gq[k] - G[k]).norm() / G[k].norm()))
     # outputs barely move, gradients move by percents
     assert float((oq.scores - o.scores).abs().max()) < 1e-2
-    assert 5e-3 < worst < 8e-2, worst
+    assert lo < worst < hi, worst

@@ -164,7 +164,8 @@ def test_fp32_fused_step_matches_golden(name):
             assert np.abs(upd).max() == 0.0, k
 
 
-@pytest.mark.parametrize("name", ["real_b8_t12_ragged", "real_b32_t50_full", "real_b16_t20_adv_confid"])
+@pytest.mark.parametrize("name", ["real_b8_t12_ragged", "real_b32_t50_full", "real_b16_t20_adv_confid", "real_gru_b8_t12_ragged",
+                                  "real_gru_b16_t20_adv"])
 def test_bf16_path_within_1e2(name):
     """bf16 mode = bf16 MFMA operands (weights, inputs, h, dG rounded to bf16) with fp32 accumulate/state in the LSTM
     GEMMs and recurrences; the fusion block stays on the exact path.  Against the fp32 oracle on identical inputs:

@@ -473,6 +473,76 @@ def test_lstm_fwd_bwd_vs_nn_lstm(mode, T, B, H, ragged):
         assert relerr(dwf, rnn.weight_hh_l0.grad) < btol
         assert relerr(dwr, rnn.weight_hh_l0_reverse.grad) < btol
 
+@pytest.mark.parametrize("mode,T,B,H,ragged", [("fp32", 6, 5, 20, True), ("fp32", 9, 33, 74, True), ("bf16", 9, 33, 74, True),
+                                               ("fp32", 5, 16, 300, False), ("bf16", 12, 32, 300, True), ("fp32", 1, 3, 35, False)])
+def test_gru_fwd_bwd_vs_nn_gru(mode, T, B, H, ragged):
+    """rnncell='gru' (reference models.py:39): nn.GRU's three gate blocks padded into the four-slot layout the LSTM machinery
+    works on (mmda_gru_pad_params), the GRU cell in the streaming recurrent kernels, gradients folded back by
+    mmda_gru_unpad_grads.  Checked against nn.GRU on packed sequences + autograd."""
+    from mmda_amd import ops
+    D = H if H < 100 else 40
+    torch.manual_seed(11)
+    rnn = torch.nn.GRU(D, H, bidirectional=True)
+    with torch.no_grad():
+        k = 2.0 / math.sqrt(H)
+        for p in rnn.parameters():
+            p.uniform_(-k, k)
+    x = torch.randn(T, B, D, requires_grad=True)
+    lengths = torch.full((B,), T)
+    if ragged:
+        lengths = torch.sort(torch.randint(1, T + 1, (B,)), descending=True).values
+        lengths[0] = T
+    pk = torch.nn.utils.rnn.pack_padded_sequence(x, lengths, enforce_sorted=False)
+    out, hn = rnn(pk)
+    pad, _ = torch.nn.utils.rnn.pad_packed_sequence(out, total_length=T)
+    d_out = torch.randn(T, B, 2 * H); d_hn = torch.randn(2, B, H)
+    (pad * d_out).sum().add((hn * d_hn).sum()).backward()
+    d = dev()
+    params = dict(rnn.named_parameters())
+    P, _ = ops.gru_pad(params, H, D, d)
+    # the pad kernel against its definition: W_ih rows [r; z; n; 0], W_hh rows [r; z; 0; n] per direction
+    for dr, sfx in enumerate(("", "_reverse")):
+        wi, wh = params["weight_ih_l0" + sfx].detach(), params["weight_hh_l0" + sfx].detach()
+        bi, bh = params["bias_ih_l0" + sfx].detach(), params["bias_hh_l0" + sfx].detach()
+        z2, z1 = torch.zeros(H, D), torch.zeros(H)
+        assert torch.equal(P["w_ih"].cpu()[dr * 4 * H:(dr + 1) * 4 * H], torch.cat((wi, z2), 0))
+        assert torch.equal(P["w_hh_r" if dr else "w_hh_f"].cpu(), torch.cat((wh[:2 * H], torch.zeros(H, H), wh[2 * H:]), 0))
+        assert torch.equal(P["b_ih"].cpu()[dr * 4 * H:(dr + 1) * 4 * H], torch.cat((bi, z1), 0))
+        assert torch.equal(P["b_hh"].cpu()[dr * 4 * H:(dr + 1) * 4 * H], torch.cat((bh[:2 * H], z1, bh[2 * H:]), 0))
+    xd = x.detach().reshape(T * B, D).to(d)
+    pre = ops.gemm(xd, P["w_ih"], mode=mode, bias=P["b_ih"], bias2=P["b_hh"]).view(T, B, 2, 4 * H)
+    fw = ops.lstm_bidir_fwd(pre, P["w_hh_f"], P["w_hh_r"], lengths, mode=mode, layer=0, cell="gru")
+    tol = TOL[mode]
+    assert relerr(fw["hseq"], pad) < tol
+    utt = fw["utt"].cpu().view(B, 4, H)
+    assert relerr(utt[:, 0], hn[0]) < tol and relerr(utt[:, 2], hn[1]) < tol
+    # backward: four-slot gate gradients -> padded weight gradients -> torch layout
+    d_utt = torch.zeros(B, 4, H); d_utt[:, 0] = d_hn[0]; d_utt[:, 2] = d_hn[1]
+    dG = ops.lstm_bidir_bwd(fw, d_utt.view(B, 4 * H).to(d), d_out.to(d), mode=mode, layer=0).view(T * B, 8 * H)
+    mask = (torch.arange(T)[:, None] < lengths[None, :]).reshape(T * B)
+    assert float(dG.cpu()[~mask].abs().max() if (~mask).any() else 0.0) == 0.0, "dG must be zero at padded positions"
+    btol = tol * (3 if mode == "bf16" else 1)
+    dx = ops.gemm(dG, P["w_ih"], mode=mode, transB=False).view(T, B, D)
+    assert relerr(dx, x.grad) < btol
+    G = dict(w_ih=ops.gemm(dG, xd, mode=mode, transA=True, transB=False), b_ih=ops.colsum(dG),
+             w_hh_f=torch.zeros(4 * H, H, device=d), w_hh_r=torch.zeros(4 * H, H, device=d))
+    if T > 1:
+        dG3 = dG.view(T, B, 8 * H); hs3 = fw["hseq"].view(T, B, 2 * H)
+        G["w_hh_f"] = ops.gemm(dG3[1:, :, :4 * H].reshape(-1, 4 * H).contiguous(), hs3[:-1, :, :H].reshape(-1, H).contiguous(), mode=mode,
+                               transA=True, transB=False)
+        G["w_hh_r"] = ops.gemm(dG3[:-1, :, 4 * H:].reshape(-1, 4 * H).contiguous(), hs3[1:, :, H:].reshape(-1, H).contiguous(), mode=mode,
+                               transA=True, transB=False)
+    # accumulate semantics: start the torch-layout gradients at 1 and expect 1 + grad
+    grads = {n: torch.ones_like(p, device=d) for n, p in params.items()}
+    ops.gru_unpad_grads(grads, G, H, D)
+    for n, p in params.items():
+        if T == 1 and "weight_hh" in n:
+            assert float((grads[n] - 1).abs().max()) == 0.0
+            continue
+        assert relerr(grads[n] - 1, p.grad) < btol, n
+    for v in G.values():
+        assert float(v.abs().max()) == 0.0, "unpad must leave the padded gradients zeroed"
+
 
 def test_lstm_three_modalities_one_launch_matches_separate():
     """The production launch packs text/visual/acoustic into one grid; results must equal per-modality launches."""

@@ -64,8 +64,10 @@ def test_config_mirror_defaults_and_errors(monkeypatch):
     assert activation_name(torch.nn.LeakyReLU) == "leakyrelu" and activation_name(torch.nn.ReLU()) == "relu"
     with pytest.raises(NotImplementedError):
         activation_name("prelu")
-    with pytest.raises(NotImplementedError):
-        MISA(make_config(vocab_size=10, rnncell="gru"))
+    g = MISA(make_config(vocab_size=10, rnncell="gru"))          # reference models.py:39: anything but 'lstm' is nn.GRU
+    sd = g.state_dict()
+    assert sd["trnn1.weight_ih_l0"].shape == (900, 300) and sd["vrnn2.weight_hh_l0_reverse"].shape == (105, 35)
+    assert sd["arnn2.weight_ih_l0"].shape == (222, 148) and sd["arnn1.bias_hh_l0"].shape == (222,)
     with pytest.raises(NotImplementedError):
         MISA(make_config(vocab_size=10, extractor="transformer"))
 
