@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--ragged", type=int, default=0)
     ap.add_argument("--confidnet", type=int, default=0)
+    ap.add_argument("--rnncell", default="lstm", choices=["lstm", "gru"], help="config.rnncell (the headline config is lstm)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streaming-recurrence", action="store_true", help="bf16: stream W_hh from L2 per step instead of LDS-resident")
     ap.add_argument("--cpu-steps", type=int, default=0, help="0 = pick a count that takes ~10-30 s")
@@ -61,7 +62,7 @@ def main():
 
     torch.manual_seed(0)
     cfg = make_config(vocab_size=args.vocab, precision=args.precision, device=str(dev), batch_size=args.batch,
-                      seq_len=args.seq_len, use_confidNet=bool(args.confidnet), pretrained_emb=torch.randn(args.vocab, 300))
+                      seq_len=args.seq_len, use_confidNet=bool(args.confidnet), rnncell=args.rnncell, pretrained_emb=torch.randn(args.vocab, 300))
     solver = Solver(cfg, cfg, cfg, None, None, None, is_train=True).build()
     model = solver.model
     model.train()
@@ -121,6 +122,8 @@ def main():
     sumH2 = 300 ** 2 + 35 ** 2 + 74 ** 2
     real_steps = float(lengths.sum().item())            # sum_b len_b (= T*B when not ragged)
     flops_per_launch = 16.0 * real_steps * sumH2        # 2 dirs * 2 FLOP/MAC * 4H*H per (sample, step), summed over modalities
+    if args.rnncell == "gru":
+        flops_per_launch *= 0.75                        # three gate blocks (the padded fourth slot is not algorithmic work)
     names = ["lstm_fwd_kernel(layer1)", "lstm_fwd_kernel(layer2)", "lstm_bwd_kernel(layer2)", "lstm_bwd_kernel(layer1)"]
     k = max(range(4), key=lambda i: ms[i])
     peak = 2500.0 if args.precision == "bf16" else 157.3
@@ -151,7 +154,8 @@ def main():
                                f"hidden=128 V={args.vocab}, {args.precision} MFMA operands fp32 accumulate, dropout on, "
                                f"{'ragged' if args.ragged else 'full'} lengths",
                    "global_batch": args.batch * world, "seq_len": args.seq_len,
-                   "parallelism": f"dp{world}" if world > 1 else "single", "use_confidNet": bool(args.confidnet)},
+                   "parallelism": f"dp{world}" if world > 1 else "single", "use_confidNet": bool(args.confidnet),
+                   "rnncell": args.rnncell},
         "gflop_per_sample": 1.184 if args.seq_len == 50 else round(3 * (7736080 * args.seq_len + 7832576) / 1e9, 3),
         "roofline": roofline,
         "losses": {k_: round(v_, 5) for k_, v_ in losses.items()},
@@ -168,7 +172,7 @@ def main():
             ncores = os.cpu_count() or 1
         ncores = max(1, min(ncores, int(os.environ.get("MMDA_CPU_THREADS", "16"))))
         torch.set_num_threads(ncores)
-        ocfg = orc.default_config(vocab_size=args.vocab, use_confidNet=bool(args.confidnet))
+        ocfg = orc.default_config(vocab_size=args.vocab, use_confidNet=bool(args.confidnet), rnncell=args.rnncell)
         cb = {"t": t.cpu(), "v": v.cpu(), "a": a.cpu(), "l": lengths.cpu(), "emo": emo.cpu()}
         nsteps = args.cpu_steps
         if nsteps <= 0:

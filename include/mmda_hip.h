@@ -223,8 +223,9 @@ typedef struct mmda_lstm_desc {
   int cell;            /* MMDA_CELL_LSTM (0) or MMDA_CELL_GRU.  GRU: the caller pads torch's three gate blocks into the four slots,
                           W_ih / b_ih rows [r; z; n; 0] and W_hh / b_hh rows [r; z; 0; n] (so `gates` slot 2 = x W_in^T + b_in and slot 3 =
                           b_hn), see mmda_gru_pad_params.  Stash after forward: gates = [r, z, n, h W_hn^T + b_hn], cstash = h_t;
-                          after backward gates = d[pre_r, pre_z, pre_n, h W_hn^T + b_hn].  Streaming kernels only (xchg is ignored,
-                          gate_minor must be 0); all descriptors of one launch share the cell. */
+                          after backward gates = d[pre_r, pre_z, pre_n, h W_hn^T + b_hn].  Runs on the streaming kernels and on the
+                          wave-autonomous resident-weights kernels (H <= 320; gate_minor allowed there), not on the barrier-form
+                          resident kernels; all descriptors of one launch share the cell. */
 } mmda_lstm_desc;
 int64_t mmda_lstm_xchg_bytes(int H, int B);
 /* 1 if mmda_lstm_fwd/bwd would run these descriptors on the resident-weights kernels (so gate_minor = 1 may be used), else 0 */

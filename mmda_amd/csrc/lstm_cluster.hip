@@ -435,7 +435,7 @@ __device__ __forceinline__ bool poll_tiles(const unsigned char* poll_flag, const
 //   publish the wave's 16 x 16 bf16 tile goes through 512 B of wave-private LDS (fragment order -> row order) and out as 32
 //           16-byte write-through stores covering whole 64-byte sectors; the wave drains them and raises ITS OWN flag
 //           (line m-tile*2 + local tile of its workgroup's flag block)
-template <int KSM, bool GM>
+template <int KSM, bool GM, int CELL>
 __global__ __launch_bounds__(256, 1) void lstm_fwd_wave_kernel(CLaunch L) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __builtin_amdgcn_s_setprio(3);
@@ -595,10 +595,18 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wave_kernel(CLaunch L) {
       const bool act = t < len_r[r];
       const float gi = sigmoid_fast(acc[0][r] + P[0][r]);
       const float gf = sigmoid_fast(acc[1][r] + P[1][r]);
-      const float gg = tanh_fast(acc[2][r] + P[2][r]);
-      const float go = sigmoid_fast(acc[3][r] + P[3][r]);
-      const float cn = gf * c_reg[r] + gi * gg;
-      const float hn = go * tanh_fast(cn);
+      float gg, go, cn, hn;
+      if (CELL == MMDA_CELL_GRU) {       // four-slot GRU (see lstm.hip): slots r, z, x-part of n, h-part of n; stash [r, z, n, q], h
+        go = acc[3][r] + P[3][r];
+        gg = tanh_fast(acc[2][r] + P[2][r] + gi * go);
+        hn = (1.f - gf) * gg + gf * h_reg[r];
+        cn = hn;
+      } else {
+        gg = tanh_fast(acc[2][r] + P[2][r]);
+        go = sigmoid_fast(acc[3][r] + P[3][r]);
+        cn = gf * c_reg[r] + gi * gg;
+        hn = go * tanh_fast(cn);
+      }
       c_reg[r] = act ? cn : c_reg[r];
       h_reg[r] = act ? hn : h_reg[r];
       Tr[(fq * 4 + r) * 16 + fr] = f2bf(h_reg[r]);
@@ -920,7 +928,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(CLaunch L) {
 // four bf16 = 8 bytes per lane).  The consumer of tile nt reads its nHT partials with one 8-byte sc1 load per lane and
 // producer, sums them in fp32 straight in fragment order and runs the lane-local cell backward: no workgroup barrier, no
 // LDS staging of gathered data, no transposition on the consumer side.
-template <int NTM, bool GM>
+template <int NTM, bool GM, int CELL>
 __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __builtin_amdgcn_s_setprio(3);
@@ -1073,15 +1081,25 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
       const bool act = t < len_r[r];
       const bool fin = dir ? (t == 0) : (t == len_r[r] - 1);
       const float gi = S.g[0][r], gf = S.g[1][r], gg = S.g[2][r], go = S.g[3][r];
-      const float dh = dh_rec[r] + S.dh[r] + (fin ? d_fin[r] : 0.f);
-      const float tc = tanh_fast(S.c[r]);
-      const float dct = dc[r] + dh * go * (1.f - tc * tc);
+      float dh = dh_rec[r] + S.dh[r] + (fin ? d_fin[r] : 0.f);
       float dp[4];
-      dp[0] = act ? dct * gg * gi * (1.f - gi) : 0.f;
-      dp[1] = act ? dct * S.cp[r] * gf * (1.f - gf) : 0.f;
-      dp[2] = act ? dct * gi * (1.f - gg * gg) : 0.f;
-      dp[3] = act ? dh * tc * go * (1.f - go) : 0.f;
-      dc[r] = act ? dct * gf : dc[r];
+      if (CELL == MMDA_CELL_GRU) {       // stash [r, z, n, q], S.cp = h_{t-1}; `dc` carries the direct path dh z
+        dh += dc[r];
+        const float dpn = dh * (1.f - gf) * (1.f - gg * gg);
+        dp[0] = act ? dpn * go * gi * (1.f - gi) : 0.f;
+        dp[1] = act ? dh * (S.cp[r] - gg) * gf * (1.f - gf) : 0.f;
+        dp[2] = act ? dpn : 0.f;
+        dp[3] = act ? dpn * gi : 0.f;
+        dc[r] = act ? dh * gf : dc[r];
+      } else {
+        const float tc = tanh_fast(S.c[r]);
+        const float dct = dc[r] + dh * go * (1.f - tc * tc);
+        dp[0] = act ? dct * gg * gi * (1.f - gi) : 0.f;
+        dp[1] = act ? dct * S.cp[r] * gf * (1.f - gf) : 0.f;
+        dp[2] = act ? dct * gi * (1.f - gg * gg) : 0.f;
+        dp[3] = act ? dh * tc * go * (1.f - go) : 0.f;
+        dc[r] = act ? dct * gf : dc[r];
+      }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         Tr[(fq * 4 + r) * 64 + g * 16 + fr] = f2bf(dp[g]);
@@ -1163,6 +1181,27 @@ static unsigned long long* g_dbg = nullptr;
 extern "C" int mmda_debug_set_lstm_stamps(void* device_buffer) { g_dbg = (unsigned long long*)device_buffer; return MMDA_OK; }
 
 namespace {
+// The wave-autonomous kernels run when every descriptor's W_hh k-steps fit their register-resident form.  Their blocks hold
+// 1, 2 or 4 waves (one (hidden tile, m-tile) each): the fewest waves per block that still fit one launch, because the waves
+// of a block share the CU's address unit and the per-step memory instructions are what they queue on.
+bool wave_form_ok(int n, const mmda_lstm_desc* descs, bool bwd, int* wpb_out) {
+  static const int no_wave = getenv("MMDA_LSTM_BARRIER_FWD") ? 1 : 0;        // ablation: the barrier-synchronised forward kernel
+  static const int force_wpb = getenv("MMDA_LSTM_WPB") ? atoi(getenv("MMDA_LSTM_WPB")) : 0;
+  static const int no_wave_b = getenv("MMDA_LSTM_BARRIER_BWD") ? 1 : 0;      // ablation: the barrier-synchronised backward kernel
+  bool ok = bwd ? !no_wave_b : !no_wave;
+  for (int i = 0; i < n; ++i) ok = ok && round_up(descs[i].H, 32) / 32 <= 10;
+  auto count_wgs = [&](int w) { int t = 0; for (int i = 0; i < n; ++i) t += 2 * ceil_div(2 * (round_up(descs[i].H, 16) / 16), w); return t; };
+  int wpb = 4;
+  if (ok) {
+    wpb = 1;
+    while (wpb < 4 && count_wgs(wpb) > MAX_WG_PER_LAUNCH) wpb *= 2;
+    if (force_wpb == 1 || force_wpb == 2 || force_wpb == 4) wpb = force_wpb;
+    if (count_wgs(wpb) > MAX_WG_PER_LAUNCH) ok = false;
+  }
+  if (wpb_out) *wpb_out = ok ? wpb : 4;
+  return ok;
+}
+
 // the checks that decide whether the resident-weights kernels can run these descriptors
 bool cluster_applicable(int n, const mmda_lstm_desc* descs, int B, int T, bool bwd, Plan* plans, size_t* lds_out) {
   if (n > MAXD || n <= 0) return false;
@@ -1170,7 +1209,9 @@ bool cluster_applicable(int n, const mmda_lstm_desc* descs, int B, int T, bool b
   size_t lds = 0;
   for (int i = 0; i < n; ++i) {
     if (!descs[i].xchg) return false;
-    if (descs[i].cell != MMDA_CELL_LSTM) return false;          // the GRU cell runs on the streaming kernels (lstm.hip)
+    if (descs[i].cell != descs[0].cell) return false;
+    // the GRU cell exists in the wave-autonomous kernels only (and in the streaming kernels of lstm.hip)
+    if (descs[i].cell != MMDA_CELL_LSTM && !wave_form_ok(n, descs, bwd, nullptr)) return false;
     if (bwd && (!descs[i].wpack_c[0] || !descs[i].wpack_c[1])) return false;
     if (descs[i].gate_minor != descs[0].gate_minor) return false;
     plans[i] = plan_for(descs[i].H);
@@ -1206,23 +1247,10 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
   size_t lds = 0;
   if (!cluster_applicable(n, descs, B, T, bwd, plans, &lds)) return MMDA_OK;
   const int ngt = ceil_div(B, GROUP);
-  // forward: the wave-autonomous kernel when every descriptor's W_hh k-steps fit its register-resident form.  Its blocks hold
-  // 1, 2 or 4 waves (one (hidden tile, m-tile) each): the fewest waves per block that still fit one launch, because the waves
-  // of a block share the CU's address unit and the per-step memory instructions are what they queue on.
-  static const int no_wave = getenv("MMDA_LSTM_BARRIER_FWD") ? 1 : 0;        // ablation: the barrier-synchronised forward kernel
-  static const int force_wpb = getenv("MMDA_LSTM_WPB") ? atoi(getenv("MMDA_LSTM_WPB")) : 0;
-  static const int no_wave_b = getenv("MMDA_LSTM_BARRIER_BWD") ? 1 : 0;      // ablation: the barrier-synchronised backward kernel
-  bool fwd_wave = bwd ? !no_wave_b : !no_wave;            // (named for the forward kernel; selects the wave-autonomous form of either pass)
-  for (int i = 0; i < n; ++i) fwd_wave = fwd_wave && round_up(descs[i].H, 32) / 32 <= 10;
   int wpb = 4;
+  const bool fwd_wave = wave_form_ok(n, descs, bwd, &wpb);   // (named for the forward kernel; selects the wave-autonomous form of either pass)
+  const bool gru = descs[0].cell == MMDA_CELL_GRU;            // cluster_applicable() admitted GRU only together with the wave form
   int members[MAXD];                       // workgroups per cluster
-  auto count_wgs = [&](int w) { int t = 0; for (int i = 0; i < n; ++i) t += 2 * ceil_div(2 * (round_up(descs[i].H, 16) / 16), w); return t; };
-  if (fwd_wave) {
-    wpb = 1;
-    while (wpb < 4 && count_wgs(wpb) > MAX_WG_PER_LAUNCH) wpb *= 2;
-    if (force_wpb == 1 || force_wpb == 2 || force_wpb == 4) wpb = force_wpb;
-    if (count_wgs(wpb) > MAX_WG_PER_LAUNCH) fwd_wave = false;
-  }
   int wg_per_group = 0;
   for (int i = 0; i < n; ++i) {
     members[i] = fwd_wave ? ceil_div(2 * (round_up(descs[i].H, 16) / 16), wpb) : plans[i].NC;
@@ -1284,10 +1312,12 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
     dim3 grid(grid_blocks), block(fwd_wave ? 64 * wpb : 256);
 #define LAUNCH_C()                                                                                               \
   do {                                                                                                           \
-    auto kfn = bwd ? (fwd_wave ? (L.gate_minor ? lstm_bwd_wave_kernel<20, true> : lstm_bwd_wave_kernel<20, false>)                       \
+    auto kfn = gru ? (bwd ? (L.gate_minor ? lstm_bwd_wave_kernel<20, true, MMDA_CELL_GRU> : lstm_bwd_wave_kernel<20, false, MMDA_CELL_GRU>) \
+                          : (L.gate_minor ? lstm_fwd_wave_kernel<10, true, MMDA_CELL_GRU> : lstm_fwd_wave_kernel<10, false, MMDA_CELL_GRU>)) \
+             : bwd ? (fwd_wave ? (L.gate_minor ? lstm_bwd_wave_kernel<20, true, MMDA_CELL_LSTM> : lstm_bwd_wave_kernel<20, false, MMDA_CELL_LSTM>) \
                     : bwd_regs ? (L.gate_minor ? lstm_bwd_cluster_kernel<10, true> : lstm_bwd_cluster_kernel<10, false>)                \
                               : (L.gate_minor ? lstm_bwd_cluster_kernel<0, true> : lstm_bwd_cluster_kernel<0, false>))                  \
-                   : fwd_wave ? (L.gate_minor ? lstm_fwd_wave_kernel<10, true> : lstm_fwd_wave_kernel<10, false>)                        \
+                   : fwd_wave ? (L.gate_minor ? lstm_fwd_wave_kernel<10, true, MMDA_CELL_LSTM> : lstm_fwd_wave_kernel<10, false, MMDA_CELL_LSTM>) \
                               : (L.gate_minor ? lstm_fwd_cluster_kernel<10, true> : lstm_fwd_cluster_kernel<10, false>);                 \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,     \
                             (int)lds_launch) != hipSuccess) { (void)hipGetLastError(); }                         \

@@ -430,8 +430,10 @@ class ModuleBaseline(nn.Module):
         self.cfg = cfg
         dt, dv, da, hs = cfg.embedding_size, cfg.visual_size, cfg.acoustic_size, cfg.hidden_size
         self.embed = nn.Embedding(cfg.vocab_size, dt)
-        self.rnn1 = nn.ModuleList([nn.LSTM(d, d, bidirectional=True) for d in (dt, dv, da)])
-        self.rnn2 = nn.ModuleList([nn.LSTM(2 * d, d, bidirectional=True) for d in (dt, dv, da)])
+        self.lstm = getattr(cfg, "rnncell", "lstm") == "lstm"
+        rnn = nn.LSTM if self.lstm else nn.GRU                         # models.py:39
+        self.rnn1 = nn.ModuleList([rnn(d, d, bidirectional=True) for d in (dt, dv, da)])
+        self.rnn2 = nn.ModuleList([rnn(2 * d, d, bidirectional=True) for d in (dt, dv, da)])
         self.ln = nn.ModuleList([nn.LayerNorm(2 * d) for d in (dt, dv, da)])
         self.proj = nn.ModuleList([nn.Sequential(nn.Linear(4 * d, hs), nn.LeakyReLU(), nn.LayerNorm(hs))
                                    for d in (dt, dv, da)])
@@ -450,10 +452,12 @@ class ModuleBaseline(nn.Module):
         utt = []
         for i, x in enumerate(xs):
             pk = pack_padded_sequence(x, lengths, enforce_sorted=False)
-            o1, (h1, _) = self.rnn1[i](pk)
+            o1, h1 = self.rnn1[i](pk)
             pad, _ = pad_packed_sequence(o1)
             pk2 = pack_padded_sequence(self.ln[i](pad), lengths, enforce_sorted=False)
-            _, (h2, _) = self.rnn2[i](pk2)
+            _, h2 = self.rnn2[i](pk2)
+            if self.lstm:
+                h1, h2 = h1[0], h2[0]
             utt.append(torch.cat((h1, h2), dim=2).permute(1, 0, 2).reshape(x.shape[1], -1))
         for i, m in enumerate("tva"):
             orig = self.proj[i](utt[i])

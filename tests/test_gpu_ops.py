@@ -474,12 +474,17 @@ def test_lstm_fwd_bwd_vs_nn_lstm(mode, T, B, H, ragged):
         assert relerr(dwr, rnn.weight_hh_l0_reverse.grad) < btol
 
 @pytest.mark.parametrize("mode,T,B,H,ragged", [("fp32", 6, 5, 20, True), ("fp32", 9, 33, 74, True), ("bf16", 9, 33, 74, True),
-                                               ("fp32", 5, 16, 300, False), ("bf16", 12, 32, 300, True), ("fp32", 1, 3, 35, False)])
+                                               ("fp32", 5, 16, 300, False), ("bf16", 12, 32, 300, True), ("fp32", 1, 3, 35, False),
+                                               ("bf16-resident", 12, 32, 300, True), ("bf16-resident-gateminor", 12, 32, 300, True),
+                                               ("bf16-resident-gateminor", 9, 40, 74, True), ("bf16-resident", 7, 19, 35, False)])
 def test_gru_fwd_bwd_vs_nn_gru(mode, T, B, H, ragged):
     """rnncell='gru' (reference models.py:39): nn.GRU's three gate blocks padded into the four-slot layout the LSTM machinery
     works on (mmda_gru_pad_params), the GRU cell in the streaming recurrent kernels, gradients folded back by
     mmda_gru_unpad_grads.  Checked against nn.GRU on packed sequences + autograd."""
     from mmda_amd import ops
+    resident = "resident" in mode                # the wave-autonomous resident-weights kernels (W_hh fragments in registers)
+    gate_minor = mode.endswith("gateminor")
+    mode = mode.split("-")[0]
     D = H if H < 100 else 40
     torch.manual_seed(11)
     rnn = torch.nn.GRU(D, H, bidirectional=True)
@@ -511,7 +516,15 @@ def test_gru_fwd_bwd_vs_nn_gru(mode, T, B, H, ragged):
         assert torch.equal(P["b_hh"].cpu()[dr * 4 * H:(dr + 1) * 4 * H], torch.cat((bh[:2 * H], z1, bh[2 * H:]), 0))
     xd = x.detach().reshape(T * B, D).to(d)
     pre = ops.gemm(xd, P["w_ih"], mode=mode, bias=P["b_ih"], bias2=P["b_hh"]).view(T, B, 2, 4 * H)
-    fw = ops.lstm_bidir_fwd(pre, P["w_hh_f"], P["w_hh_r"], lengths, mode=mode, layer=0, cell="gru")
+    fw = ops.lstm_bidir_fwd(pre, P["w_hh_f"], P["w_hh_r"], lengths, mode=mode, layer=0, cell="gru", resident=resident,
+                            gate_minor=gate_minor)
+    assert not ops.lstm_aborted(fw), "cluster exchange timed out in forward"
+    if resident:
+        from mmda_amd import _lib
+        d0 = (_lib.LstmDesc * 1)(ops._desc(H, fw["gates"], fw["cstash"], fw["hseq"], fw["packs"][0], fw["packs"][2], fw["utt"], 0, None,
+                                           fw["xchg"], 0))
+        d0[0].cell = 1; d0[0].gate_minor = int(gate_minor)
+        assert _lib.load().mmda_lstm_resident_applicable(_lib.BF16, 1, d0, B, T, 0) == 1, "expected the resident-weights kernel to run"
     tol = TOL[mode]
     assert relerr(fw["hseq"], pad) < tol
     utt = fw["utt"].cpu().view(B, 4, H)
