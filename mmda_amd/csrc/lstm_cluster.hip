@@ -998,9 +998,17 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
     d_fin[r] = ldf(ru, inb[r] ? ((unsigned)b * 4u * H + (dir * 2 + D.layer) * H + col) * 4u : OOB);
   }
   float dc[4] = {0.f, 0.f, 0.f, 0.f};
-  struct Stash { float g[4][4], c[4], cp[4], dh[4]; };
-  Stash sb[2];                                          // forward stash of the coming steps
-  auto load_stash = [&](Stash& S, int step) {
+  // Forward stash of the NEXT step as loaded (raw), and of the current step folded into the factors the gate gradients are
+  // linear in (dv): the folding (tanh, products, masks) depends on the stash alone, so it is done at the end of the previous
+  // step, while the other waves' partial sums are still on their way; what stays between "partials arrived" and "own partial
+  // published" is a handful of multiplies.
+  struct Raw { float g[4][4], cp[4], dh[4]; };
+  struct Dv { float a[6][4], dh[4]; };
+  Raw raw;
+  Dv dv;
+  float c_keep[4] = {0.f, 0.f, 0.f, 0.f};               // cell state of the step being derived (LSTM)
+  const bool has_dh = D.d_hseq != nullptr;
+  auto load_raw = [&](int step) {
     const int t = dir ? step : T - 1 - step;
     const int tp = dir ? t + 1 : t - 1;
 #pragma unroll
@@ -1010,18 +1018,59 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
       if (gm) {
         const f32x4 v = ldf4(rg, act ? o : OOB);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) S.g[g][r] = v[g];
+        for (int g = 0; g < 4; ++g) raw.g[g][r] = v[g];
       } else {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) S.g[g][r] = ldf(rg, act ? o + g * H * 4u : OOB);
+        for (int g = 0; g < 4; ++g) raw.g[g][r] = ldf(rg, act ? o + g * H * 4u : OOB);
       }
-      S.c[r] = ldf(rc, act ? oc[r] + (unsigned)t * sc : OOB);
-      S.cp[r] = ldf(rc, (act && tp >= 0 && tp < len_r[r]) ? oc[r] + (unsigned)tp * sc : OOB);
-      S.dh[r] = ldf(rd, act ? oh[r] + (unsigned)t * sc : OOB);          // zero-record descriptor when d_hseq == NULL
+      // the state of the step that follows in this walk (= the previous one in time); derive() hands it on as that step's own
+      // state, so every state is read once
+      raw.cp[r] = ldf(rc, (step < T && tp >= 0 && tp < len_r[r]) ? oc[r] + (unsigned)tp * sc : OOB);
+      raw.dh[r] = has_dh ? ldf(rd, act ? oh[r] + (unsigned)t * sc : OOB) : 0.f;      // has_dh is workgroup-uniform
     }
   };
-  load_stash(sb[0], 0);
-  load_stash(sb[1], 1);
+  // raw (step `step`) + c_keep -> dv.  With dh the total gradient of h_t and dc the carried one:
+  //   LSTM: dct = dc + dh a4;  dG = [dct a0, dct a1, dct a2, dh a3];  dc' = dct a5
+  //   GRU : dh += dc;          dG = [dh a0 a1, dh a2, dh a0, dh a0 a3];  dc' = dh a5       (stash [r, z, n, q], cp = h_{t-1})
+  // Everything is zero at inactive (t >= len) positions: the loads were masked, a0 is masked here.  The carry needs no mask: the
+  // inactive steps of a sample come first in this walk (forward direction, carry still zero) or last (reverse direction).
+  auto derive = [&](int step) {
+    const int t = dir ? step : T - 1 - step;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool act = step < T && t < len_r[r];
+      const bool fin = dir ? (t == 0) : (t == len_r[r] - 1);
+      const float gi = raw.g[0][r], gf = raw.g[1][r], gg = raw.g[2][r], go = raw.g[3][r];
+      dv.dh[r] = raw.dh[r] + ((act && fin) ? d_fin[r] : 0.f);
+      if (CELL == MMDA_CELL_GRU) {
+        dv.a[0][r] = act ? (1.f - gf) * (1.f - gg * gg) : 0.f;
+        dv.a[1][r] = go * gi * (1.f - gi);
+        dv.a[2][r] = (raw.cp[r] - gg) * gf * (1.f - gf);
+        dv.a[3][r] = gi;
+        dv.a[4][r] = 0.f;
+        dv.a[5][r] = gf;
+      } else {
+        const float tc = tanh_fast(c_keep[r]);
+        dv.a[0][r] = gg * gi * (1.f - gi);
+        dv.a[1][r] = raw.cp[r] * gf * (1.f - gf);
+        dv.a[2][r] = gi * (1.f - gg * gg);
+        dv.a[3][r] = tc * go * (1.f - go);
+        dv.a[4][r] = go * (1.f - tc * tc);
+        dv.a[5][r] = gf;
+        c_keep[r] = raw.cp[r];
+      }
+    }
+  };
+  if (CELL == MMDA_CELL_LSTM) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int t0 = dir ? 0 : T - 1;
+      c_keep[r] = ldf(rc, t0 < len_r[r] ? oc[r] + (unsigned)t0 * sc : OOB);
+    }
+  }
+  load_raw(0);
+  derive(0);
+  load_raw(1);
   // exchange image per parity: [consumer tile nt][m-tile][producer tile][64 lanes] x 8 B
   const unsigned slot_b = (unsigned)xchg_slot(NC, Hp);
   const unsigned img_b = (unsigned)(nHT * 2 * nHT) * 512u;
@@ -1035,7 +1084,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
   if (L.dbg && tid == 0) last = __builtin_readcyclecounter();
   bool alive = true;
   float dgv[4][4];                                      // fp32 dG of the previous step, stored behind the next step's gather loads
-  auto flush = [&](int ps, Stash& Sp) {
+  auto flush = [&](int ps) {
     const int t = dir ? ps : T - 1 - ps;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -1047,11 +1096,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
         for (int g = 0; g < 4; ++g) stf(rg, inb[r] ? o + g * H * 4u : OOB, dgv[r][g]);
       }
     }
-    load_stash(Sp, ps + 2);
   };
   typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
-  auto do_step = [&](int step, Stash& S, Stash& Sp) {
-    const int t = dir ? step : T - 1 - step;
+  auto do_step = [&](int step) {
     const unsigned epoch = L.epoch_base + (unsigned)step + 1u;
     float dh_rec[4] = {0.f, 0.f, 0.f, 0.f};
     if (step > 0) {
@@ -1064,7 +1111,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
 #pragma unroll
       for (int p = 0; p < NTM; ++p)
         gv[p] = __builtin_amdgcn_raw_buffer_load_b64(xr, p < nHT ? par + gat_base + (unsigned)p * 512u : OOB, 0, 16);
-      flush(step - 1, Sp);
+      flush(step - 1);
+      load_raw(step + 1);                                // consumed by derive() at the end of this step
       STAMP(1);
 #pragma unroll
       for (int p = 0; p < NTM; ++p) {
@@ -1075,30 +1123,26 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
       }
     }
     if (L.dbg) { asm volatile("s_nop 0" :: "v"(dh_rec[0]), "v"(dh_rec[1]), "v"(dh_rec[2]), "v"(dh_rec[3])); STAMP(2); }
-    // lane-local gate gradients of the own hidden units (branch-free)
+    // lane-local gate gradients of the own hidden units: linear in dh / dc with the factors derive() prepared
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const bool act = t < len_r[r];
-      const bool fin = dir ? (t == 0) : (t == len_r[r] - 1);
-      const float gi = S.g[0][r], gf = S.g[1][r], gg = S.g[2][r], go = S.g[3][r];
-      float dh = dh_rec[r] + S.dh[r] + (fin ? d_fin[r] : 0.f);
+      float dh = dh_rec[r] + dv.dh[r];
       float dp[4];
-      if (CELL == MMDA_CELL_GRU) {       // stash [r, z, n, q], S.cp = h_{t-1}; `dc` carries the direct path dh z
+      if (CELL == MMDA_CELL_GRU) {
         dh += dc[r];
-        const float dpn = dh * (1.f - gf) * (1.f - gg * gg);
-        dp[0] = act ? dpn * go * gi * (1.f - gi) : 0.f;
-        dp[1] = act ? dh * (S.cp[r] - gg) * gf * (1.f - gf) : 0.f;
-        dp[2] = act ? dpn : 0.f;
-        dp[3] = act ? dpn * gi : 0.f;
-        dc[r] = act ? dh * gf : dc[r];
+        const float dpn = dh * dv.a[0][r];
+        dp[0] = dpn * dv.a[1][r];
+        dp[1] = dh * dv.a[2][r];
+        dp[2] = dpn;
+        dp[3] = dpn * dv.a[3][r];
+        dc[r] = dh * dv.a[5][r];
       } else {
-        const float tc = tanh_fast(S.c[r]);
-        const float dct = dc[r] + dh * go * (1.f - tc * tc);
-        dp[0] = act ? dct * gg * gi * (1.f - gi) : 0.f;
-        dp[1] = act ? dct * S.cp[r] * gf * (1.f - gf) : 0.f;
-        dp[2] = act ? dct * gi * (1.f - gg * gg) : 0.f;
-        dp[3] = act ? dh * tc * go * (1.f - go) : 0.f;
-        dc[r] = act ? dct * gf : dc[r];
+        const float dct = dc[r] + dh * dv.a[4][r];
+        dp[0] = dct * dv.a[0][r];
+        dp[1] = dct * dv.a[1][r];
+        dp[2] = dct * dv.a[2][r];
+        dp[3] = dh * dv.a[3][r];
+        dc[r] = dct * dv.a[5][r];
       }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -1128,16 +1172,14 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's write-through stores have landed
       STAMP(5);
       if (lane == 0) st_flag(my_flag, epoch);
+      __builtin_amdgcn_sched_barrier(0);                             // keep the folding behind the hand-off
+      derive(step + 1);
     }
   };
   {
     int step = 0;
-    for (; step + 1 < T && alive; step += 2) {
-      do_step(step, sb[0], sb[1]);
-      if (alive) do_step(step + 1, sb[1], sb[0]);
-    }
-    if (step < T && alive) { do_step(step, sb[0], sb[1]); ++step; }
-    if (alive && T > 0) flush(T - 1, (T - 1) & 1 ? sb[1] : sb[0]);
+    for (; step < T && alive; ++step) do_step(step);
+    if (alive && T > 0) flush(T - 1);
   }
   if (L.dbg && tid == 0)
     for (int i = 0; i < 8; ++i) L.dbg[(size_t)role * 8 + i] = ph[i];
