@@ -74,6 +74,7 @@ struct mmda_misa {
   int use_bf16_gemm = 1;           // bf16 mode: LSTM-sized GEMMs read bf16 operand copies (gemm_bf16.hip)
   int gate_minor = 0;              // layout of `gates` chosen by the last forward (see mmda_lstm_desc.gate_minor)
   int inference = 0, last_fwd_inference = 0;   // evaluation passes: no stash, no copies that only the backward pass reads
+  int zero_grad_pending = 0;       // train_step: the gradient bucket is cleared inside forward(), beside the fusion block
   int ldR = 0;
   std::vector<hipEvent_t> ev;      // [step][slot][start/stop]
   int ev_steps = 0, ev_fwd = 0, ev_bwd = 0;
@@ -686,16 +687,20 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
         }
         x.rc = mmda_convert_bf16(cj, inf ? 3 : 6, stream);
       }
-    } else if (bfg && !x.rc && !inf) {
-      // hseq^T of layer 2 for its dW_hh: on the side stream, beside the fusion block
-      mmda_convert_job cj[3];
-      for (int i = 0; i < 3; ++i) {
-        Mod& md = m->mod[i];
-        cj[i] = mmda_convert_job{WS(md.hseq[1]), 2 * md.H, R, 2 * md.H, nullptr, nullptr, 0, WS(md.rnn[1].hbT), ldR};
-      }
+    } else if (!x.rc && ((bfg && !inf) || m->zero_grad_pending)) {
+      // side stream, beside the fusion block: the gradient bucket is cleared (train_step) and hseq^T of layer 2 is made for its
+      // dW_hh.  Joined at the end of forward(), so everything the backward pass issues on either stream is ordered behind both.
       void* ss = nullptr;
       x.rc = side_fork(m, stream, &ss);
-      if (!x.rc) x.rc = mmda_convert_bf16(cj, 3, ss);
+      if (!x.rc && m->zero_grad_pending) { x.rc = mmda_misa_zero_grad(m, ss); m->zero_grad_pending = 0; }
+      if (bfg && !inf && !x.rc) {
+        mmda_convert_job cj[3];
+        for (int i = 0; i < 3; ++i) {
+          Mod& md = m->mod[i];
+          cj[i] = mmda_convert_job{WS(md.hseq[1]), 2 * md.H, R, 2 * md.H, nullptr, nullptr, 0, WS(md.rnn[1].hbT), ldR};
+        }
+        x.rc = mmda_convert_bf16(cj, 3, ss);
+      }
     }
   }
   if (x.rc) return x.rc;
@@ -820,6 +825,7 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
                             stream);
   }
   if (!m->ev.empty()) { if (m->ev_seen_f % m->ev_stride == 0) m->ev_fwd++; m->ev_seen_f++; }
+  if (!x.rc) x.rc = side_join(m, stream);      // (the side stream finished long ago: this only orders later work behind it)
   return x.rc;
 }
 
@@ -1250,17 +1256,16 @@ extern "C" int mmda_misa_adam_step(mmda_misa* m, float lr, float clip, float gra
 extern "C" int mmda_misa_train_step(mmda_misa* m, const int64_t* t_ids, const float* v, const float* a, const int32_t* lengths,
                                     const float* emo, int training, uint64_t seed, int do_adam, float lr, float clip, int step,
                                     void* stream) {
-  // the gradient bucket is cleared on the side stream underneath the first kernels of the forward pass; forward() joins the
-  // side stream (W_hh packing) before its first recurrent kernel, long before any gradient is accumulated
-  if (check_ready(m)) return MMDA_EINVAL;
+  // the gradient bucket is cleared on the side stream beside the forward pass's fusion block (not at the start of the step: the
+  // side stream's first job there, packing W_hh, is what the first recurrent kernel waits for)
+  if (check_ready(m) || !m->G) return MMDA_EINVAL;
   m->inference = 0;                                     // a training step always stashes
-  void* ss = nullptr;
-  int rc = side_fork(m, stream, &ss);
-  if (rc) return rc;
-  rc = mmda_misa_zero_grad(m, ss);
+  m->zero_grad_pending = m->T > 0 ? 1 : 0;
+  int rc = m->zero_grad_pending ? MMDA_OK : mmda_misa_zero_grad(m, stream);
   if (rc) return rc;
   rc = mmda_misa_forward(m, t_ids, v, a, lengths, training, seed, stream);
   if (rc) return rc;
+  if (m->zero_grad_pending) return MMDA_ELAUNCH;        // forward() always reaches its layer-2 branch when T > 0
   rc = mmda_misa_losses(m, emo, 1, stream);
   if (rc) return rc;
   rc = mmda_misa_backward(m, t_ids, v, a, lengths, stream);
