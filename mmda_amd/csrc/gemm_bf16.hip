@@ -9,6 +9,8 @@
 // 32 MFMAs per wave and k-tile against 16 ds_read_b128 and 4+4 16-byte global loads per thread.  Two register stages
 // of prefetch (k+1 and k+2) because these problems only offer ~1 workgroup per CU and cannot hide HBM latency by occupancy.
 #include "common.h"
+#include <algorithm>
+#include <vector>
 
 namespace {
 
@@ -349,9 +351,20 @@ extern "C" int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, vo
       G.n = 0; blocks = 0;
       return MMDA_OK;
     };
+    // Workgroups are dealt in block order: the problems with the longest K loops go first, so that their workgroups do not
+    // form the tail of the launch.  `crowded`: the launch fills the chip twice over without any split-K.
+    std::vector<int> order;
+    int64_t all_tiles = 0;
     for (int i = 0; i < n; ++i) {
       const mmda_gemm_bf16_args& a = args[i];
       if (a.M == 0 || a.N == 0 || tile_of(a) != T) continue;
+      order.push_back(i);
+      all_tiles += (int64_t)ceil_div(a.N + (a.bias_grad ? 1 : 0), T) * ceil_div(a.M, T);
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return args[x].K > args[y].K; });
+    const bool crowded = all_tiles >= 512;
+    for (int i : order) {
+      const mmda_gemm_bf16_args& a = args[i];
       if (G.n == GROUP_MAX) { int rc = flush(); if (rc) return rc; }
       const int k = G.n++;
       G.p[k] = a;
@@ -371,6 +384,9 @@ extern "C" int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, vo
         if (sk > 16) sk = 16;
         if (sk < 1) sk = 1;
       }
+      // a fresh (non-accumulated) output has to be cleared by a launch of its own before the slices can add into it: only worth
+      // it for a long K loop in a launch that would otherwise leave the chip underfilled
+      if (sk > 1 && !a.accumulate && (crowded || nk < 16)) sk = 1;
       if (sk > 1 && !a.accumulate) {
         if (a.ldc != a.N) sk = 1;
         else if (hipMemsetAsync(a.C, 0, sizeof(float) * (size_t)a.M * a.N, s) != hipSuccess) return MMDA_ELAUNCH;

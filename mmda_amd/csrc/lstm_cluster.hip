@@ -458,6 +458,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wave_kernel(CLaunch L) {
   const int H = D.H, Hp = D.Hp, KS = D.KS, nHT = D.nHT, NC = D.NC;
   const int B = L.B, T = L.T, dir = wh.dir;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __builtin_amdgcn_s_setprio(3);         // a serial chain: win issue arbitration against whatever else shares the CU
   const int fr = lane & 15, fq = lane >> 4;
   const int rho = wh.me * L.wpb + wave;
   const int mt = rho & 1, ht = rho >> 1;
@@ -950,6 +951,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
   const int H = D.H, Hp = D.Hp, nHT = D.nHT, NC = D.NC;
   const int B = L.B, T = L.T, dir = wh.dir;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __builtin_amdgcn_s_setprio(3);         // a serial chain: win issue arbitration against whatever else shares the CU
   const int fr = lane & 15, fq = lane >> 4;
   const int rho = wh.me * L.wpb + wave;
   const int mt = rho & 1, ht = rho >> 1;
@@ -1350,7 +1352,11 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
     }
     bool bwd_regs = true;                    // every descriptor's n-tiles fit the register-resident form (<= 10 per wave)
     for (int i = 0; i < n; ++i) bwd_regs = bwd_regs && L.d[i].nHT <= 20;
-    const size_t lds_launch = fwd_wave ? (size_t)4 * 2048 : lds;
+    // Wave form: the kernel needs 2 KB per wave.  With one wave per block it asks for the CU's whole LDS instead: that keeps every
+    // LDS-using workgroup of a concurrent kernel (weight-gradient GEMMs and conversions on the side stream) off the ~110 CUs
+    // that host a recurrent wave, and leaves them the other ~145.  (MMDA_LSTM_LDS_KB: ablation.)
+    static const int lds_kb = getenv("MMDA_LSTM_LDS_KB") ? atoi(getenv("MMDA_LSTM_LDS_KB")) : 160;
+    const size_t lds_launch = fwd_wave ? (wpb == 1 ? (size_t)(lds_kb < 8 ? 8 : lds_kb > 160 ? 160 : lds_kb) * 1024 : (size_t)4 * 2048) : lds;
     dim3 grid(grid_blocks), block(fwd_wave ? 64 * wpb : 256);
 #define LAUNCH_C()                                                                                               \
   do {                                                                                                           \

@@ -620,10 +620,11 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
   const bool inf = m->inference != 0;                   // no backward follows: transposed copies and stashes are not needed
   m->last_fwd_inference = inf;
   if (bfg) {
+    // layer 1's operands now; layer 2's W_ih on the side stream beside the layer-1 recurrence (see below)
     mmda_convert_job cj[9];
     int n = 0;
     for (int i = 0; i < 3; ++i) {
-      for (int l = 0; l < 2; ++l) {
+      for (int l = 0; l < (m->use_side ? 1 : 2); ++l) {
         Rnn& r = m->mod[i].rnn[l];
         cj[n++] = mmda_convert_job{rW_ih(m, r), r.D, 8 * r.H, r.D, nullptr, WS(r.wb), r.ldD, inf ? nullptr : WS(r.wbT), r.ldG, gm ? r.H : 0};
       }
@@ -664,6 +665,22 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
     group_end(x);
     if (!x.rc && l == 0) x.rc = side_join(m, stream);       // packed W_hh ready
     if (x.rc) return x.rc;
+    if (bfg && m->use_side) {
+      // Side stream, beside this layer's recurrent kernel (which leaves ~145 CUs idle): layer 1 -> W_ih of layer 2 (joined before
+      // its input GEMM below); layer 2 -> hseq^T of layer 1 for its dW_hh (joined at the end of forward()).
+      mmda_convert_job cj[3];
+      for (int i = 0; i < 3; ++i) {
+        Mod& md = m->mod[i]; Rnn& r1 = md.rnn[1];
+        if (l == 0) cj[i] = mmda_convert_job{rW_ih(m, r1), r1.D, 8 * r1.H, r1.D, nullptr, WS(r1.wb), r1.ldD, inf ? nullptr : WS(r1.wbT), r1.ldG, gm ? r1.H : 0};
+        else cj[i] = mmda_convert_job{WS(md.hseq[0]), 2 * md.H, R, 2 * md.H, nullptr, nullptr, 0, WS(md.rnn[0].hbT), ldR};
+      }
+      if (l == 0 || !inf) {
+        void* ss = nullptr;
+        x.rc = side_fork(m, stream, &ss);
+        if (!x.rc) x.rc = mmda_convert_bf16(cj, 3, ss);
+        if (x.rc) return x.rc;
+      }
+    }
     ev_rec(m, m->ev_fwd, l, 0, stream);
     x.rc = mmda_lstm_fwd(mode, 3, desc, B, T, lengths, stream);
     ev_rec(m, m->ev_fwd, l, 1, stream);
@@ -685,7 +702,8 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
           cj[i] = mmda_convert_job{WS(md.normed), 2 * md.H, R, 2 * md.H, nullptr, WS(r1.xb), r1.ldD, inf ? nullptr : WS(r1.xbT), ldR};
           cj[3 + i] = mmda_convert_job{WS(md.hseq[0]), 2 * md.H, R, 2 * md.H, nullptr, nullptr, 0, WS(r0.hbT), ldR};
         }
-        x.rc = mmda_convert_bf16(cj, inf ? 3 : 6, stream);
+        x.rc = mmda_convert_bf16(cj, (inf || m->use_side) ? 3 : 6, stream);
+        if (!x.rc) x.rc = side_join(m, stream);             // layer 2's W_ih copies (side stream) are ready
       }
     } else if (!x.rc && ((bfg && !inf) || m->zero_grad_pending)) {
       // side stream, beside the fusion block: the gradient bucket is cleared (train_step) and hseq^T of layer 2 is made for its
@@ -1083,10 +1101,11 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
   if (x.rc) return x.rc;
   // encoders, top layer first
   const float* xin[3] = {WS(m->mod[0].x), v, a};
-  // Layer 2's weight-gradient GEMMs: beside the layer-1 recurrent kernel on the side stream (MMDA_DW_OVERLAP=1), or held back
-  // and issued with layer 1's in one grouped launch after it.  The wave-autonomous recurrence runs one wave on each of ~110
-  // CUs and is bound by memory latency: a chip-filling GEMM beside it costs the recurrence about what the overlap hides.
-  static const int dw_overlap = getenv("MMDA_DW_OVERLAP") ? atoi(getenv("MMDA_DW_OVERLAP")) : 0;
+  // Layer 2's weight-gradient GEMMs run beside the layer-1 recurrent kernel on the side stream (MMDA_DW_OVERLAP=0: held back and
+  // issued with layer 1's in one grouped launch after it).  The wave-autonomous recurrence runs one wave on each of ~110 CUs,
+  // raises its priority and reserves those CUs' whole LDS, so the GEMM's workgroups land on the other ~145 CUs; what the two still
+  // share is L2 and fabric bandwidth (the recurrence slows by ~30 us, the GEMMs' ~65 us leave the critical path).
+  static const int dw_overlap = getenv("MMDA_DW_OVERLAP") ? atoi(getenv("MMDA_DW_OVERLAP")) : 1;
   std::vector<mmda_gemm_bf16_args> bside;
   for (int l = 1; l >= 0; --l) {
     mmda_lstm_desc desc[3];
