@@ -75,6 +75,9 @@ struct mmda_misa {
   int gate_minor = 0;              // layout of `gates` chosen by the last forward (see mmda_lstm_desc.gate_minor)
   int inference = 0, last_fwd_inference = 0;   // evaluation passes: no stash, no copies that only the backward pass reads
   int zero_grad_pending = 0;       // train_step: the gradient bucket is cleared inside forward(), beside the fusion block
+  // train_step: the losses that read only the private/shared representations (diff, CMD) are issued by forward() on the side
+  // stream as soon as those exist, beside the transformer layer and the heads; mmda_misa_losses() then adds the rest
+  int eager_losses = 0, eager_done = 0;
   int ldR = 0;
   std::vector<hipEvent_t> ev;      // [step][slot][start/stop]
   int ev_steps = 0, ev_fwd = 0, ev_bwd = 0;
@@ -538,6 +541,26 @@ extern "C" int mmda_misa_cluster_status(const mmda_misa* m, int* aborted_host) {
 }
 
 // =============================================================================================== forward
+namespace {
+// side stream, right after x6 = [private x3, shared x3] exists: clear the loss sums and the loss-seeded activation gradients,
+// then DiffLoss and CMD with their gradients (they read x6 only), then the gradient bucket if train_step left that to forward()
+int eager_side_losses(mmda_misa* m, void* stream) {
+  if (!m->eager_losses) return MMDA_OK;
+  const mmda_misa_config& c = m->cfg;
+  const int B = m->B, hs = c.hidden;
+  const int64_t BH = (int64_t)B * hs;
+  void* ss = nullptr;
+  int rc = side_fork(m, stream, &ss);
+  if (!rc) rc = mmda_misa_zero_act_grads(m, ss);
+  float* L = WS(m->losses);
+  if (!rc) rc = mmda_loss_diff(WS(m->x6), BH, B, hs, c.diff_weight, L + 1, WS(m->d_x6), WS(m->diff_work), ss);
+  if (!rc && c.use_cmd_sim) rc = mmda_loss_cmd(WS(m->x6 + 3 * BH), BH, B, hs, c.sim_weight, L + 2, WS(m->d_x6 + 3 * BH), ss);
+  if (!rc && m->zero_grad_pending) { rc = mmda_misa_zero_grad(m, ss); m->zero_grad_pending = 0; }
+  m->eager_done = 1;
+  return rc;
+}
+}  // namespace
+
 extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float* v, const float* a, const int32_t* lengths,
                                  int training, uint64_t seed, void* stream) {
   if (check_ready(m) || !t_ids || !v || !a || !lengths) return MMDA_EINVAL;
@@ -705,12 +728,12 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
         x.rc = mmda_convert_bf16(cj, (inf || m->use_side) ? 3 : 6, stream);
         if (!x.rc) x.rc = side_join(m, stream);             // layer 2's W_ih copies (side stream) are ready
       }
-    } else if (!x.rc && ((bfg && !inf) || m->zero_grad_pending)) {
+    } else if (!x.rc && ((bfg && !inf) || (m->zero_grad_pending && !m->eager_losses))) {
       // side stream, beside the fusion block: the gradient bucket is cleared (train_step) and hseq^T of layer 2 is made for its
       // dW_hh.  Joined at the end of forward(), so everything the backward pass issues on either stream is ordered behind both.
       void* ss = nullptr;
       x.rc = side_fork(m, stream, &ss);
-      if (!x.rc && m->zero_grad_pending) { x.rc = mmda_misa_zero_grad(m, ss); m->zero_grad_pending = 0; }
+      if (!x.rc && m->zero_grad_pending && !m->eager_losses) { x.rc = mmda_misa_zero_grad(m, ss); m->zero_grad_pending = 0; }
       if (bfg && !inf && !x.rc) {
         mmda_convert_job cj[3];
         for (int i = 0; i < 3; ++i) {
@@ -744,6 +767,7 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
                    MMDA_ACT_SIGMOID);
     g[3] = sk_nt(3 * B, hs, hs, WS(m->orig), hs, PP(m->sh_w), PP(m->sh_b), WS(m->x6 + 3 * BH), hs, MMDA_ACT_SIGMOID);
     sk_launch(x, g, 4);
+    if (!x.rc) x.rc = eager_side_losses(m, stream);
     // reconstruct from private + shared (models.py:254-262), the q/k/v projection of the six tokens (models.py:243) and the
     // discriminator's first layer all read x6 only
     int n = 0;
@@ -801,6 +825,7 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
          BH, (int64_t)hs * hs, BH, hs);
     gemm(x, fmode, 0, 1, 3 * B, hs, hs, WS(m->orig), hs, PP(m->sh_w), hs, WS(m->x6 + 3 * BH), hs, PP(m->sh_b), nullptr, 0,
          MMDA_ACT_SIGMOID);
+    if (!x.rc) x.rc = eager_side_losses(m, stream);
     // reconstruct (models.py:254-262)
     if (!x.rc) x.rc = mmda_add(WS(m->x6), WS(m->x6 + 3 * BH), WS(m->rsum), 3 * BH, stream);
     gemm(x, fmode, 0, 1, B, hs, hs, WS(m->rsum), hs, PP(m->rec_w), hs, WS(m->recon), hs, PP(m->rec_b), nullptr, 0, 0, 3, BH,
@@ -862,13 +887,23 @@ extern "C" int mmda_misa_losses(mmda_misa* m, const float* emo, int with_grads, 
   const int64_t BH = (int64_t)B * hs;
   hipStream_t s = (hipStream_t)stream;
   int rc = MMDA_OK;
-  if (with_grads) { rc = mmda_misa_zero_act_grads(m, stream); if (rc) return rc; }      // covers the loss sums too
-  else if (hipMemsetAsync(WS(m->losses), 0, sizeof(float) * 8, s) != hipSuccess) return MMDA_ELAUNCH;
   float* L = WS(m->losses);
-  rc = mmda_loss_diff(WS(m->x6), BH, B, hs, c.diff_weight, L + 1, with_grads ? WS(m->d_x6) : nullptr, WS(m->diff_work), stream);
-  if (rc) return rc;
-  if (c.use_cmd_sim) rc = mmda_loss_cmd(WS(m->x6 + 3 * BH), BH, B, hs, c.sim_weight, L + 2, with_grads ? WS(m->d_x6 + 3 * BH) : nullptr, stream);
-  else rc = mmda_loss_domain(WS(m->dom), B, c.sim_weight, L + 2, with_grads ? WS(m->d_dom) : nullptr, stream);
+  const bool eager = m->eager_done && with_grads;        // forward() already cleared the region and ran diff (+ CMD) on the side stream
+  m->eager_done = 0;
+  if (eager) {
+    rc = side_join(m, stream);                           // (forward() joined already; kept for callers that split the calls)
+    if (rc) return rc;
+  } else {
+    if (with_grads) { rc = mmda_misa_zero_act_grads(m, stream); if (rc) return rc; }      // covers the loss sums too
+    else if (hipMemsetAsync(WS(m->losses), 0, sizeof(float) * 8, s) != hipSuccess) return MMDA_ELAUNCH;
+    rc = mmda_loss_diff(WS(m->x6), BH, B, hs, c.diff_weight, L + 1, with_grads ? WS(m->d_x6) : nullptr, WS(m->diff_work), stream);
+    if (rc) return rc;
+  }
+  if (c.use_cmd_sim) {
+    if (!eager) rc = mmda_loss_cmd(WS(m->x6 + 3 * BH), BH, B, hs, c.sim_weight, L + 2, with_grads ? WS(m->d_x6 + 3 * BH) : nullptr, stream);
+  } else {
+    rc = mmda_loss_domain(WS(m->dom), B, c.sim_weight, L + 2, with_grads ? WS(m->d_dom) : nullptr, stream);
+  }
   if (rc) return rc;
   // cls, conf (computed every step like solver.py:168; it only seeds gradients with use_confidNet, solver.py:180-181), recon and
   // the weighted total in one launch
@@ -1280,11 +1315,13 @@ extern "C" int mmda_misa_train_step(mmda_misa* m, const int64_t* t_ids, const fl
   if (check_ready(m) || !m->G) return MMDA_EINVAL;
   m->inference = 0;                                     // a training step always stashes
   m->zero_grad_pending = m->T > 0 ? 1 : 0;
+  m->eager_losses = 1; m->eager_done = 0;
   int rc = m->zero_grad_pending ? MMDA_OK : mmda_misa_zero_grad(m, stream);
   if (rc) return rc;
   rc = mmda_misa_forward(m, t_ids, v, a, lengths, training, seed, stream);
+  m->eager_losses = 0;
   if (rc) return rc;
-  if (m->zero_grad_pending) return MMDA_ELAUNCH;        // forward() always reaches its layer-2 branch when T > 0
+  if (m->zero_grad_pending) return MMDA_ELAUNCH;        // forward() always reaches its fusion block
   rc = mmda_misa_losses(m, emo, 1, stream);
   if (rc) return rc;
   rc = mmda_misa_backward(m, t_ids, v, a, lengths, stream);
