@@ -195,7 +195,8 @@ int mmda_lstm_pack_whh(int mode, int H, const float* whh, void* packed_fwd, void
 int mmda_lstm_pack_whh_cluster(int H, const float* whh, void* packed_c, void* stream);
 /* n (<= 16) matrices in one launch */
 int mmda_lstm_pack_whh_multi(int mode, int n, const int* H, const float* const* whh, void* const* packed_fwd,
-                             void* const* packed_bwd, void* const* packed_c /* NULL or per-matrix (bf16) */, void* stream);
+                             void* const* packed_bwd /* entries may be NULL: that packing is skipped (as may packed_fwd's, not both) */,
+                             void* const* packed_c /* NULL or per-matrix (bf16) */, void* stream);
 
 typedef struct mmda_lstm_desc {
   int H;

@@ -106,6 +106,8 @@ __global__ void pack_multi_kernel(PackMulti P) {
     return;
   }
   const bool bwd = e0 >= nF;
+  void* dst = bwd ? P.Bk[i] : P.F[i];
+  if (!dst) return;                                    // this packing is not wanted
   const int64_t e = bwd ? e0 - nF : e0;
   const int j = e % per, lane = (e / per) % 64;
   const int64_t frag = e / (per * 64);
@@ -120,8 +122,8 @@ __global__ void pack_multi_kernel(PackMulti P) {
     int g = kk / Hp, jj = kk % Hp, n = ht * 16 + (lane & 15);
     if (jj < H && n < H) v = W[(int64_t)(g * H + jj) * H + n];
   }
-  if (MODE == MMDA_BF16) reinterpret_cast<unsigned short*>(bwd ? P.Bk[i] : P.F[i])[e] = f2bf(v);
-  else reinterpret_cast<float*>(bwd ? P.Bk[i] : P.F[i])[e] = v;
+  if (MODE == MMDA_BF16) reinterpret_cast<unsigned short*>(dst)[e] = f2bf(v);
+  else reinterpret_cast<float*>(dst)[e] = v;
 }
 
 template <int MODE> __device__ __forceinline__ float sig_(float x) { return MODE == MMDA_BF16 ? sigmoid_fast(x) : sigmoidf_(x); }
@@ -522,7 +524,7 @@ extern "C" int mmda_lstm_pack_whh_multi(int mode, int n, const int* H, const flo
   P.n = n;
   int blocks = 0;
   for (int i = 0; i < n; ++i) {
-    if (H[i] <= 0 || H[i] > 512 || !whh[i] || !packed_fwd[i] || !packed_bwd[i]) return MMDA_EINVAL;
+    if (H[i] <= 0 || H[i] > 512 || !whh[i] || (!packed_fwd[i] && !packed_bwd[i])) return MMDA_EINVAL;
     P.H[i] = H[i]; P.W[i] = whh[i]; P.F[i] = packed_fwd[i]; P.Bk[i] = packed_bwd[i];
     P.Ck[i] = (packed_c && mode == MMDA_BF16) ? packed_c[i] : nullptr;
     P.start[i] = blocks;

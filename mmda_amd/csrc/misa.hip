@@ -68,7 +68,8 @@ struct mmda_misa {
   // optional per-launch timing of the four recurrent kernels (bench.py roofline leg)
   unsigned epoch = 1;              // monotonic cluster-exchange epoch (never reset; see lstm_cluster.hip)
   hipStream_t side = nullptr;      // second stream for weight-gradient GEMMs (created lazily; no device memory)
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_pack = nullptr;
+  int pack_b_valid = 0;            // the streaming backward packing of W_hh was made by the last forward
   int side_pending = 0, use_side = 1;
   int use_cluster = 1, packed_c_valid = 0;
   int use_bf16_gemm = 1;           // bf16 mode: LSTM-sized GEMMs read bf16 operand copies (gemm_bf16.hip)
@@ -375,6 +376,7 @@ int side_fork(mmda_misa* m, void* main_stream, void** out) {
     if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess) return MMDA_ELAUNCH;
     if (hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess) return MMDA_ELAUNCH;
     if (hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess) return MMDA_ELAUNCH;
+    if (hipEventCreateWithFlags(&m->ev_pack, hipEventDisableTiming) != hipSuccess) return MMDA_ELAUNCH;
   }
   if (hipEventRecord(m->ev_fork, (hipStream_t)main_stream) != hipSuccess) return MMDA_ELAUNCH;
   if (hipStreamWaitEvent(m->side, m->ev_fork, 0) != hipSuccess) return MMDA_ELAUNCH;
@@ -458,6 +460,7 @@ extern "C" void mmda_misa_destroy(mmda_misa* m) {
   if (!m) return;
   if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
   if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+  if (m->ev_pack) (void)hipEventDestroy(m->ev_pack);
   if (m->side) (void)hipStreamDestroy(m->side);
   for (hipEvent_t e : m->ev) (void)hipEventDestroy(e);
   delete m;
@@ -582,19 +585,41 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
     x.rc = mmda_gru_pad_params(gj, n, stream);
     if (x.rc) return x.rc;
   }
+  // which recurrent kernels will run: decides the packings of W_hh that are made and the layout of `gates`
+  auto probe_resident = [&](int gate_minor, int backward) -> bool {
+    if (T <= 0 || mode != MMDA_BF16) return false;
+    mmda_lstm_desc probe[3];
+    for (int i = 0; i < 3; ++i) {
+      Mod& md = m->mod[i]; Rnn& r = md.rnn[0];
+      probe[i] = mmda_lstm_desc{};
+      probe[i].H = r.H; probe[i].gates = WS(md.gates[0]); probe[i].cstash = WS(md.c[0]); probe[i].hseq = WS(md.hseq[0]);
+      probe[i].wpack[0] = WS(r.pack_f[0]); probe[i].wpack[1] = WS(r.pack_f[1]);
+      probe[i].wpack_c[0] = WS(r.pack_c[0]); probe[i].wpack_c[1] = WS(r.pack_c[1]); probe[i].utt = WS(md.utt);
+      probe[i].xchg = (m->use_cluster && md.xchg >= 0) ? (void*)WS(md.xchg) : nullptr; probe[i].gate_minor = gate_minor;
+      probe[i].cell = c.rnncell;
+    }
+    return mmda_lstm_resident_applicable(mode, 3, probe, B, T, backward) != 0;
+  };
   {
+    // The forward packing always; the resident-weights backward packing when those kernels will run the backward pass and the
+    // streaming backward packing only when they will not; neither for an evaluation pass.
+    const bool infer = m->inference != 0;
+    const bool want_c = !infer && m->use_cluster && mode == MMDA_BF16;
+    const bool want_b = !infer && !(want_c && probe_resident(0, 1));
     int Hs[12]; const float* Wp[12]; void* Fp[12]; void* Bp[12]; void* Cp[12];
     int k = 0;
     for (int i = 0; i < 3; ++i)
       for (int l = 0; l < 2; ++l)
         for (int d = 0; d < 2; ++d, ++k) {
           Rnn& r = m->mod[i].rnn[l];
-          Hs[k] = r.H; Wp[k] = rW_hh(m, r, d); Fp[k] = WS(r.pack_f[d]); Bp[k] = WS(r.pack_b[d]); Cp[k] = WS(r.pack_c[d]);
+          Hs[k] = r.H; Wp[k] = rW_hh(m, r, d); Fp[k] = WS(r.pack_f[d]); Bp[k] = want_b ? WS(r.pack_b[d]) : nullptr; Cp[k] = WS(r.pack_c[d]);
         }
-    const bool want_c = m->use_cluster && mode == MMDA_BF16;
     void* ss = nullptr;
     x.rc = side_fork(m, stream, &ss);
     if (!x.rc) x.rc = mmda_lstm_pack_whh_multi(mode, 12, Hs, Wp, Fp, Bp, want_c ? Cp : nullptr, ss);
+    // the first recurrent kernel waits for the packing only, not for the transposes issued behind it
+    if (!x.rc && ss != stream && hipEventRecord(m->ev_pack, (hipStream_t)ss) != hipSuccess) x.rc = MMDA_ELAUNCH;
+    m->pack_b_valid = want_b ? 1 : 0;
     m->packed_c_valid = want_c ? 1 : 0;
     m->wT_valid = 0;
     if (!x.rc && B <= SKINNY_MAX_B && !m->inference) {
@@ -626,28 +651,15 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
   // GEMM epilogues) AND the resident-weights kernels will run, forward and backward.
   int gm = 0;
   static const int no_gm = getenv("MMDA_NO_GATE_MINOR") ? 1 : 0;     // ablation switch
-  if (bfg && (B % 8) == 0 && T > 0 && !no_gm) {
-    mmda_lstm_desc probe[3];
-    for (int i = 0; i < 3; ++i) {
-      Mod& md = m->mod[i]; Rnn& r = md.rnn[0];
-      probe[i] = mmda_lstm_desc{};
-      probe[i].H = r.H; probe[i].gates = WS(md.gates[0]); probe[i].cstash = WS(md.c[0]); probe[i].hseq = WS(md.hseq[0]);
-      probe[i].wpack[0] = WS(r.pack_f[0]); probe[i].wpack[1] = WS(r.pack_f[1]);
-      probe[i].wpack_c[0] = WS(r.pack_c[0]); probe[i].wpack_c[1] = WS(r.pack_c[1]); probe[i].utt = WS(md.utt);
-      probe[i].xchg = (m->use_cluster && md.xchg >= 0) ? (void*)WS(md.xchg) : nullptr; probe[i].gate_minor = 1;
-      probe[i].cell = c.rnncell;
-    }
-    gm = mmda_lstm_resident_applicable(mode, 3, probe, B, T, 0) && mmda_lstm_resident_applicable(mode, 3, probe, B, T, 1);
-  }
+  if (bfg && (B % 8) == 0 && T > 0 && !no_gm) gm = probe_resident(1, 0) && probe_resident(1, 1);
   m->gate_minor = gm;
   const bool inf = m->inference != 0;                   // no backward follows: transposed copies and stashes are not needed
   m->last_fwd_inference = inf;
   if (bfg) {
-    // layer 1's operands now; layer 2's W_ih on the side stream beside the layer-1 recurrence (see below)
     mmda_convert_job cj[9];
     int n = 0;
     for (int i = 0; i < 3; ++i) {
-      for (int l = 0; l < (m->use_side ? 1 : 2); ++l) {
+      for (int l = 0; l < 2; ++l) {
         Rnn& r = m->mod[i].rnn[l];
         cj[n++] = mmda_convert_job{rW_ih(m, r), r.D, 8 * r.H, r.D, nullptr, WS(r.wb), r.ldD, inf ? nullptr : WS(r.wbT), r.ldG, gm ? r.H : 0};
       }
@@ -686,23 +698,23 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
     if (bfg && !x.rc) x.rc = mmda_gemm_bf16_grouped(bg, 3, stream);
     m->epoch += (unsigned)T + 2u;
     group_end(x);
-    if (!x.rc && l == 0) x.rc = side_join(m, stream);       // packed W_hh ready
+    if (!x.rc && l == 0 && m->side_pending && m->use_side) {   // packed W_hh ready (the side stream carries on with its transposes)
+      if (hipStreamWaitEvent((hipStream_t)stream, m->ev_pack, 0) != hipSuccess) x.rc = MMDA_ELAUNCH;
+    }
     if (x.rc) return x.rc;
-    if (bfg && m->use_side) {
-      // Side stream, beside this layer's recurrent kernel (which leaves ~145 CUs idle): layer 1 -> W_ih of layer 2 (joined before
-      // its input GEMM below); layer 2 -> hseq^T of layer 1 for its dW_hh (joined at the end of forward()).
+    if (bfg && m->use_side && l == 1 && !inf) {
+      // side stream, beside the layer-2 recurrent kernel (which leaves ~145 CUs idle): hseq^T of layer 1 for its dW_hh (joined at
+      // the end of forward()).  A join costs the main stream ~10 us however early the side stream finished, so only work that an
+      // existing join covers is moved there.
       mmda_convert_job cj[3];
       for (int i = 0; i < 3; ++i) {
-        Mod& md = m->mod[i]; Rnn& r1 = md.rnn[1];
-        if (l == 0) cj[i] = mmda_convert_job{rW_ih(m, r1), r1.D, 8 * r1.H, r1.D, nullptr, WS(r1.wb), r1.ldD, inf ? nullptr : WS(r1.wbT), r1.ldG, gm ? r1.H : 0};
-        else cj[i] = mmda_convert_job{WS(md.hseq[0]), 2 * md.H, R, 2 * md.H, nullptr, nullptr, 0, WS(md.rnn[0].hbT), ldR};
+        Mod& md = m->mod[i];
+        cj[i] = mmda_convert_job{WS(md.hseq[0]), 2 * md.H, R, 2 * md.H, nullptr, nullptr, 0, WS(md.rnn[0].hbT), ldR};
       }
-      if (l == 0 || !inf) {
-        void* ss = nullptr;
-        x.rc = side_fork(m, stream, &ss);
-        if (!x.rc) x.rc = mmda_convert_bf16(cj, 3, ss);
-        if (x.rc) return x.rc;
-      }
+      void* ss = nullptr;
+      x.rc = side_fork(m, stream, &ss);
+      if (!x.rc) x.rc = mmda_convert_bf16(cj, 3, ss);
+      if (x.rc) return x.rc;
     }
     ev_rec(m, m->ev_fwd, l, 0, stream);
     x.rc = mmda_lstm_fwd(mode, 3, desc, B, T, lengths, stream);
@@ -726,7 +738,6 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
           cj[3 + i] = mmda_convert_job{WS(md.hseq[0]), 2 * md.H, R, 2 * md.H, nullptr, nullptr, 0, WS(r0.hbT), ldR};
         }
         x.rc = mmda_convert_bf16(cj, (inf || m->use_side) ? 3 : 6, stream);
-        if (!x.rc) x.rc = side_join(m, stream);             // layer 2's W_ih copies (side stream) are ready
       }
     } else if (!x.rc && ((bfg && !inf) || (m->zero_grad_pending && !m->eager_losses))) {
       // side stream, beside the fusion block: the gradient bucket is cleared (train_step) and hseq^T of layer 2 is made for its
@@ -1155,6 +1166,8 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
       desc[i].gate_minor = m->gate_minor; desc[i].cell = c.rnncell;
     }
     m->epoch += (unsigned)T + 2u;
+    // the forward pass skipped the streaming backward packing because the resident-weights kernels were going to run: they must
+    if (!m->pack_b_valid && !mmda_lstm_resident_applicable(mode, 3, desc, B, T, 1)) return MMDA_EINVAL;
     ev_rec(m, m->ev_bwd, l == 1 ? 2 : 3, 0, stream);
     x.rc = mmda_lstm_bwd(mode, 3, desc, B, T, lengths, stream);
     ev_rec(m, m->ev_bwd, l == 1 ? 2 : 3, 1, stream);
