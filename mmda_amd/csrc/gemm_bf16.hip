@@ -333,9 +333,10 @@ extern "C" int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, vo
     if (a.perm_n_H < 0 || a.perm_m_H < 0 || (a.perm_n_H && a.N % (4 * a.perm_n_H)) || (a.perm_m_H && a.M % (4 * a.perm_m_H))) return MMDA_EINVAL;
   }
   // 128 x 128 tiles when they alone fill the chip twice over; else 64 x 64 (4x the workgroups, 2x the residency)
+  static const int t128_min = getenv("MMDA_GEMM_T128_MIN") ? atoi(getenv("MMDA_GEMM_T128_MIN")) : 512;     // experiment switch
   auto tile_of = [](const mmda_gemm_bf16_args& a) {
     const int Ne = a.N + (a.bias_grad ? 1 : 0);
-    return ceil_div(Ne, 128) * ceil_div(a.M, 128) >= 512 ? 128 : 64;
+    return ceil_div(Ne, 128) * ceil_div(a.M, 128) >= t128_min ? 128 : 64;
   };
   for (int T = 64; T <= 128; T += 64) {
     Bf16Group G;

@@ -547,13 +547,21 @@ extern "C" int mmda_misa_cluster_status(const mmda_misa* m, int* aborted_host) {
 namespace {
 // side stream, right after x6 = [private x3, shared x3] exists: clear the loss sums and the loss-seeded activation gradients,
 // then DiffLoss and CMD with their gradients (they read x6 only), then the gradient bucket if train_step left that to forward()
-int eager_side_losses(mmda_misa* m, void* stream) {
+int eager_side_losses(mmda_misa* m, void* stream, bool hseq2_t) {
   if (!m->eager_losses) return MMDA_OK;
   const mmda_misa_config& c = m->cfg;
   const int B = m->B, hs = c.hidden;
   const int64_t BH = (int64_t)B * hs;
   void* ss = nullptr;
   int rc = side_fork(m, stream, &ss);
+  if (!rc && hseq2_t) {            // hseq^T of layer 2 for its dW_hh (every fork puts a marker packet on the main stream: one for both)
+    mmda_convert_job cj[3];
+    for (int i = 0; i < 3; ++i) {
+      Mod& md = m->mod[i];
+      cj[i] = mmda_convert_job{WS(md.hseq[1]), 2 * md.H, m->B * m->T, 2 * md.H, nullptr, nullptr, 0, WS(md.rnn[1].hbT), m->ldR};
+    }
+    rc = mmda_convert_bf16(cj, 3, ss);
+  }
   if (!rc) rc = mmda_misa_zero_act_grads(m, ss);
   float* L = WS(m->losses);
   if (!rc) rc = mmda_loss_diff(WS(m->x6), BH, B, hs, c.diff_weight, L + 1, WS(m->d_x6), WS(m->diff_work), ss);
@@ -655,19 +663,30 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
   m->gate_minor = gm;
   const bool inf = m->inference != 0;                   // no backward follows: transposed copies and stashes are not needed
   m->last_fwd_inference = inf;
-  if (bfg) {
+  // The transposed copies are read by the backward pass only: with a side stream they are made there, beside the recurrent
+  // kernels (`late_t`), and the main stream converts just what the forward GEMMs read.
+  // (measured: the fork's marker packet on the main stream and the L2 traffic beside the forward recurrences cost ~15 us more
+  // than the smaller main-stream conversions save, so this stays an ablation switch, off by default)
+  static const int late_t_on = getenv("MMDA_LATE_T") ? atoi(getenv("MMDA_LATE_T")) : 0;
+  const bool late_t = bfg && m->use_side && !inf && late_t_on;
+  auto first_converts = [&](bool plain, bool transposed, void* st) -> int {
     mmda_convert_job cj[9];
     int n = 0;
     for (int i = 0; i < 3; ++i) {
       for (int l = 0; l < 2; ++l) {
         Rnn& r = m->mod[i].rnn[l];
-        cj[n++] = mmda_convert_job{rW_ih(m, r), r.D, 8 * r.H, r.D, nullptr, WS(r.wb), r.ldD, inf ? nullptr : WS(r.wbT), r.ldG, gm ? r.H : 0};
+        cj[n++] = mmda_convert_job{rW_ih(m, r), r.D, 8 * r.H, r.D, nullptr, plain ? WS(r.wb) : nullptr, plain ? r.ldD : 0,
+                                   transposed ? WS(r.wbT) : nullptr, transposed ? r.ldG : 0, gm ? r.H : 0};
       }
       Rnn& r0 = m->mod[i].rnn[0];
-      if (i == 0) cj[n++] = mmda_convert_job{PP(m->embed), c.d_t, R, c.d_t, t_ids, WS(r0.xb), r0.ldD, inf ? nullptr : WS(r0.xbT), ldR};
-      else cj[n++] = mmda_convert_job{xin[i], r0.D, R, r0.D, nullptr, WS(r0.xb), r0.ldD, inf ? nullptr : WS(r0.xbT), ldR};
+      const float* src = i == 0 ? PP(m->embed) : xin[i];
+      cj[n++] = mmda_convert_job{src, r0.D, R, r0.D, i == 0 ? t_ids : nullptr, plain ? WS(r0.xb) : nullptr, plain ? r0.ldD : 0,
+                                 transposed ? WS(r0.xbT) : nullptr, transposed ? ldR : 0};
     }
-    x.rc = mmda_convert_bf16(cj, n, stream);
+    return mmda_convert_bf16(cj, n, st);
+  };
+  if (bfg) {
+    x.rc = first_converts(true, !inf && !late_t, stream);
   } else {
     // embedding rows (models.py:201)
     x.rc = mmda_embed_gather(PP(m->embed), t_ids, R, c.d_t, WS(m->mod[0].x), stream);
@@ -702,18 +721,24 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
       if (hipStreamWaitEvent((hipStream_t)stream, m->ev_pack, 0) != hipSuccess) x.rc = MMDA_ELAUNCH;
     }
     if (x.rc) return x.rc;
-    if (bfg && m->use_side && l == 1 && !inf) {
-      // side stream, beside the layer-2 recurrent kernel (which leaves ~145 CUs idle): hseq^T of layer 1 for its dW_hh (joined at
-      // the end of forward()).  A join costs the main stream ~10 us however early the side stream finished, so only work that an
-      // existing join covers is moved there.
-      mmda_convert_job cj[3];
-      for (int i = 0; i < 3; ++i) {
-        Mod& md = m->mod[i];
-        cj[i] = mmda_convert_job{WS(md.hseq[0]), 2 * md.H, R, 2 * md.H, nullptr, nullptr, 0, WS(md.rnn[0].hbT), ldR};
-      }
+    if (late_t) {
+      // Side stream, beside this layer's recurrent kernel (which leaves ~145 CUs idle), joined at the end of forward():
+      //   layer 1: W_ih^T of both layers (dX) and the layer-1 inputs transposed (dW_ih)
+      //   layer 2: its inputs transposed (dW_ih) and hseq^T of layer 1 (dW_hh)
+      // A join costs the main stream ~10 us however early the side stream finished, so only work that an existing join covers
+      // is moved there.
       void* ss = nullptr;
       x.rc = side_fork(m, stream, &ss);
-      if (!x.rc) x.rc = mmda_convert_bf16(cj, 3, ss);
+      if (!x.rc && l == 0) x.rc = first_converts(false, true, ss);
+      if (!x.rc && l == 1) {
+        mmda_convert_job cj[6];
+        for (int i = 0; i < 3; ++i) {
+          Mod& md = m->mod[i];
+          cj[i] = mmda_convert_job{WS(md.hseq[0]), 2 * md.H, R, 2 * md.H, nullptr, nullptr, 0, WS(md.rnn[0].hbT), ldR};
+          cj[3 + i] = mmda_convert_job{WS(md.normed), 2 * md.H, R, 2 * md.H, nullptr, nullptr, 0, WS(md.rnn[1].xbT), ldR};
+        }
+        x.rc = mmda_convert_bf16(cj, 6, ss);
+      }
       if (x.rc) return x.rc;
     }
     ev_rec(m, m->ev_fwd, l, 0, stream);
@@ -734,12 +759,13 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
         mmda_convert_job cj[6];
         for (int i = 0; i < 3; ++i) {
           Mod& md = m->mod[i]; Rnn& r1 = md.rnn[1]; Rnn& r0 = md.rnn[0];
-          cj[i] = mmda_convert_job{WS(md.normed), 2 * md.H, R, 2 * md.H, nullptr, WS(r1.xb), r1.ldD, inf ? nullptr : WS(r1.xbT), ldR};
+          const bool tr = !inf && !late_t;
+          cj[i] = mmda_convert_job{WS(md.normed), 2 * md.H, R, 2 * md.H, nullptr, WS(r1.xb), r1.ldD, tr ? WS(r1.xbT) : nullptr, tr ? ldR : 0};
           cj[3 + i] = mmda_convert_job{WS(md.hseq[0]), 2 * md.H, R, 2 * md.H, nullptr, nullptr, 0, WS(r0.hbT), ldR};
         }
-        x.rc = mmda_convert_bf16(cj, (inf || m->use_side) ? 3 : 6, stream);
+        x.rc = mmda_convert_bf16(cj, (inf || late_t) ? 3 : 6, stream);
       }
-    } else if (!x.rc && ((bfg && !inf) || (m->zero_grad_pending && !m->eager_losses))) {
+    } else if (!x.rc && !m->eager_losses && ((bfg && !inf) || m->zero_grad_pending)) {
       // side stream, beside the fusion block: the gradient bucket is cleared (train_step) and hseq^T of layer 2 is made for its
       // dW_hh.  Joined at the end of forward(), so everything the backward pass issues on either stream is ordered behind both.
       void* ss = nullptr;
@@ -778,7 +804,7 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
                    MMDA_ACT_SIGMOID);
     g[3] = sk_nt(3 * B, hs, hs, WS(m->orig), hs, PP(m->sh_w), PP(m->sh_b), WS(m->x6 + 3 * BH), hs, MMDA_ACT_SIGMOID);
     sk_launch(x, g, 4);
-    if (!x.rc) x.rc = eager_side_losses(m, stream);
+    if (!x.rc) x.rc = eager_side_losses(m, stream, bfg && !inf);
     // reconstruct from private + shared (models.py:254-262), the q/k/v projection of the six tokens (models.py:243) and the
     // discriminator's first layer all read x6 only
     int n = 0;
@@ -836,7 +862,7 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
          BH, (int64_t)hs * hs, BH, hs);
     gemm(x, fmode, 0, 1, 3 * B, hs, hs, WS(m->orig), hs, PP(m->sh_w), hs, WS(m->x6 + 3 * BH), hs, PP(m->sh_b), nullptr, 0,
          MMDA_ACT_SIGMOID);
-    if (!x.rc) x.rc = eager_side_losses(m, stream);
+    if (!x.rc) x.rc = eager_side_losses(m, stream, bfg && !inf);
     // reconstruct (models.py:254-262)
     if (!x.rc) x.rc = mmda_add(WS(m->x6), WS(m->x6 + 3 * BH), WS(m->rsum), 3 * BH, stream);
     gemm(x, fmode, 0, 1, B, hs, hs, WS(m->rsum), hs, PP(m->rec_w), hs, WS(m->recon), hs, PP(m->rec_b), nullptr, 0, 0, 3, BH,
