@@ -105,6 +105,7 @@ typedef struct mmda_convert_job {
   void* plain; int ldp;
   void* transposed; int ldt;
   int row_perm_H;                    /* H > 0: output row r reads source row orig(r) (gate interleave, see mmda_gemm_bf16_args) */
+  int src_bf16;                      /* 1: `src` points at bf16 elements (ld in elements): re-layout (transpose / pad) without conversion */
 } mmda_convert_job;
 int mmda_convert_bf16(const mmda_convert_job* jobs, int n, void* stream);
 
@@ -227,6 +228,13 @@ typedef struct mmda_lstm_desc {
                           after backward gates = d[pre_r, pre_z, pre_n, h W_hn^T + b_hn].  Runs on the streaming kernels and on the
                           wave-autonomous resident-weights kernels (H <= 320; gate_minor allowed there), not on the barrier-form
                           resident kernels; all descriptors of one launch share the cell. */
+  void* dg_bf16;       /* backward, optional: (T*B, 8H) bf16, the gate gradients rounded to bf16 in the column order of `gates` (the A
+                          operand of dX = dG W_ih on the bf16 GEMM; mmda_convert_bf16 with src_bf16 makes its transpose for the
+                          weight-gradient GEMMs).  Written only by the wave-autonomous resident kernel with gate_minor = 1; NULL
+                          otherwise / ignored by the other kernels, so a caller passes it only when
+                          mmda_lstm_resident_applicable() said those kernels will run. */
+  int dg_bf16_only;    /* with dg_bf16: 1 = the fp32 gate gradients are NOT written (`gates` is unspecified after the call): the
+                          per-step stores are what the backward kernel's memory pipeline is busy with */
 } mmda_lstm_desc;
 int64_t mmda_lstm_xchg_bytes(int H, int B);
 /* 1 if mmda_lstm_fwd/bwd would run these descriptors on the resident-weights kernels (so gate_minor = 1 may be used), else 0 */

@@ -40,7 +40,8 @@ class GemmBf16Args(C.Structure):
 
 class ConvertJob(C.Structure):
     _fields_ = [("src", C.c_void_p), ("ld", C.c_int), ("rows", C.c_int), ("cols", C.c_int), ("gather", C.c_void_p),
-                ("plain", C.c_void_p), ("ldp", C.c_int), ("transposed", C.c_void_p), ("ldt", C.c_int), ("row_perm_H", C.c_int)]
+                ("plain", C.c_void_p), ("ldp", C.c_int), ("transposed", C.c_void_p), ("ldt", C.c_int), ("row_perm_H", C.c_int),
+                ("src_bf16", C.c_int)]
 
 
 class SkinnyArgs(C.Structure):
@@ -78,7 +79,7 @@ class LstmDesc(C.Structure):
     _fields_ = [("H", C.c_int), ("gates", C.c_void_p), ("cstash", C.c_void_p), ("hseq", C.c_void_p),
                 ("wpack", C.c_void_p * 2), ("wpack_c", C.c_void_p * 2), ("utt", C.c_void_p), ("layer", C.c_int), ("d_hseq", C.c_void_p),
                 ("xchg", C.c_void_p), ("epoch_base", C.c_uint32), ("gate_minor", C.c_int), ("forward_only", C.c_int),
-                ("cell", C.c_int)]
+                ("cell", C.c_int), ("dg_bf16", C.c_void_p), ("dg_bf16_only", C.c_int)]
 
 
 class GruPadJob(C.Structure):

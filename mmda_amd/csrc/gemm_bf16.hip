@@ -301,14 +301,23 @@ __global__ __launch_bounds__(256) void convert_kernel(ConvLaunch L) {
     if (J.row_perm_H > 0) rc = gate_orig(rc, J.row_perm_H);
     srow[i] = J.gather ? J.gather[rc] : (int64_t)rc;
   }
-  float v[16];
+  unsigned short hv[16];
+  if (J.src_bf16) {                                     // block-uniform: the source already holds bf16 (re-layout only)
+    const unsigned short* s16 = reinterpret_cast<const unsigned short*>(J.src);
 #pragma unroll
-  for (int i = 0; i < 16; ++i) v[i] = J.src[srow[i] * J.ld + cc0];
+    for (int i = 0; i < 16; ++i) hv[i] = s16[srow[i] * J.ld + cc0];
+  } else {
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = J.src[srow[i] * J.ld + cc0];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) hv[i] = f2bf(v[i]);
+  }
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int rr = ty + 4 * i;
     const int r = r0 + rr, c = c0 + tx;
-    const unsigned short h = f2bf((r < J.rows && c < J.cols) ? v[i] : 0.f);
+    const unsigned short h = (r < J.rows && c < J.cols) ? hv[i] : (unsigned short)0;
     tile[rr][tx] = h;
     if (P && r < J.rows && c < J.ldp) P[(int64_t)r * J.ldp + c] = h;      // c in [cols, ldp) writes the zero padding
   }

@@ -39,6 +39,8 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 struct CDesc {
   int H, Hp, Kp, KS, KSB, nHT, TPW, NC;
   float* gates; float* cstash; float* hseq; const void* wpack[2]; const void* wpack_c[2]; float* utt; int layer;
+  void* dg16;                        // backward, optional: bf16 copy of the gate gradients (gate-minor wave kernel only)
+  int dg16_only;                     // ... and no fp32 store of them
   const float* d_hseq;
   unsigned char* xchg;
   int wg_begin;
@@ -1085,21 +1087,30 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
 #define STAMP(i) do { if (L.dbg && tid == 0) { unsigned long long now_ = __builtin_readcyclecounter(); ph[i] += now_ - last; last = now_; } } while (0)
   if (L.dbg && tid == 0) last = __builtin_readcyclecounter();
   bool alive = true;
+  typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
   float dgv[4][4];                                      // fp32 dG of the previous step, stored behind the next step's gather loads
+  const __amdgpu_buffer_rsrc_t rg16 = make_rsrc(D.dg16, D.dg16 ? (unsigned)T * B * 2u * G4 * 2u : 0u);
+  const bool has_dg16 = gm && D.dg16 != nullptr;       // workgroup-uniform
+  const bool f32_dg = !(has_dg16 && D.dg16_only);
   auto flush = [&](int ps) {
     const int t = dir ? ps : T - 1 - ps;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const unsigned o = inb[r] ? og[r] + (unsigned)t * sg : OOB;       // zero at padded positions too
       if (gm) {
-        stf4(rg, o, f32x4{dgv[r][0], dgv[r][1], dgv[r][2], dgv[r][3]});
+        if (f32_dg) stf4(rg, o, f32x4{dgv[r][0], dgv[r][1], dgv[r][2], dgv[r][3]});
+        if (has_dg16) {                                // the same four values rounded to bf16: 8 bytes at half the byte offset
+          u32x2 pk;
+          pk[0] = (unsigned)f2bf(dgv[r][0]) | ((unsigned)f2bf(dgv[r][1]) << 16);
+          pk[1] = (unsigned)f2bf(dgv[r][2]) | ((unsigned)f2bf(dgv[r][3]) << 16);
+          __builtin_amdgcn_raw_buffer_store_b64(pk, rg16, inb[r] ? (og[r] + (unsigned)t * sg) >> 1 : OOB, 0, 0);
+        }
       } else {
 #pragma unroll
         for (int g = 0; g < 4; ++g) stf(rg, inb[r] ? o + g * H * 4u : OOB, dgv[r][g]);
       }
     }
   };
-  typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
   auto do_step = [&](int step) {
     const unsigned epoch = L.epoch_base + (unsigned)step + 1u;
     float dh_rec[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1320,6 +1331,8 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
       c.gates = d.gates; c.cstash = d.cstash; c.hseq = d.hseq; c.wpack[0] = d.wpack[0]; c.wpack[1] = d.wpack[1];
       c.wpack_c[0] = d.wpack_c[0]; c.wpack_c[1] = d.wpack_c[1];
       c.utt = d.utt; c.layer = d.layer; c.d_hseq = d.d_hseq; c.xchg = (unsigned char*)d.xchg;
+      c.dg16 = (bwd && fwd_wave && d.gate_minor) ? d.dg_bf16 : nullptr;
+      c.dg16_only = (c.dg16 && d.dg_bf16_only) ? 1 : 0;
       c.wg_begin = wg;
       if (i < n) wg += 2 * L.ng * members[i];
     }

@@ -1190,7 +1190,12 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
       desc[i].utt = WS(md.d_utt); desc[i].layer = l; desc[i].d_hseq = l == 0 ? WS(md.d_hseq1) : nullptr;
       desc[i].xchg = (m->use_cluster && md.xchg >= 0) ? (void*)WS(md.xchg) : nullptr; desc[i].epoch_base = m->epoch;
       desc[i].gate_minor = m->gate_minor; desc[i].cell = c.rnncell;
+      // gate-minor => the wave-autonomous kernels run (forward() probed both passes): they also emit the bf16 copy of dG that
+      // the input-gradient GEMM reads (d(normed) for layer 2, d(embedding rows) for the text layer 1)
+      // -- and only that copy: every consumer of dG in this mode is a bf16 GEMM (the transposed operand is made from it)
+      if (m->gate_minor && mode == MMDA_BF16 && m->use_bf16_gemm) { desc[i].dg_bf16 = WS(r.dgb); desc[i].dg_bf16_only = 1; }
     }
+    const bool kdg = desc[0].dg_bf16 != nullptr;
     m->epoch += (unsigned)T + 2u;
     // the forward pass skipped the streaming backward packing because the resident-weights kernels were going to run: they must
     if (!m->pack_b_valid && !mmda_lstm_resident_applicable(mode, 3, desc, B, T, 1)) return MMDA_EINVAL;
@@ -1203,16 +1208,20 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
     const bool bfg = mode == MMDA_BF16 && m->use_bf16_gemm;
     const bool bf_hh = bfg && (B % 8) == 0;        // the time-shifted views of dG^T / hseq^T start B elements into a row
     std::vector<mmda_gemm_bf16_args> bmain;
-    if (bfg) {
-      // gate gradients -> bf16: transposed (A of every dW) and, where an input gradient is needed, plain (A of dX)
-      mmda_convert_job cj[3];
-      for (int i = 0; i < 3; ++i) {
-        Mod& md = m->mod[i]; Rnn& r = md.rnn[l];
-        const bool plain = l == 1 || i == 0;
-        cj[i] = mmda_convert_job{WS(md.gates[l]), 8 * r.H, R, 8 * r.H, nullptr, plain ? WS(r.dgb) : nullptr, plain ? r.ldG : 0, WS(r.dgbT),
-                                 m->ldR};
-      }
-      x.rc = mmda_convert_bf16(cj, 3, stream);
+    // gate gradients -> bf16: transposed (A of every dW) and, where an input gradient is needed and the recurrent kernel did not
+    // write it itself, plain (A of dX).  Layer 2 with the kernel-written plain copy: only the weight-gradient GEMMs (side stream)
+    // read the transposed one, so the conversion goes to the side stream with them.
+    mmda_convert_job dgj[3];
+    for (int i = 0; i < 3; ++i) {
+      Mod& md = m->mod[i]; Rnn& r = md.rnn[l];
+      const bool plain = (l == 1 || i == 0) && !kdg;
+      dgj[i] = mmda_convert_job{WS(md.gates[l]), 8 * r.H, R, 8 * r.H, nullptr, plain ? WS(r.dgb) : nullptr, plain ? r.ldG : 0, WS(r.dgbT),
+                                m->ldR};
+      if (kdg) { dgj[i].src = WS(r.dgb); dgj[i].ld = r.ldG; dgj[i].src_bf16 = 1; }
+    }
+    const bool dg_on_side = bfg && kdg && l == 1 && dw_overlap && m->use_side;
+    if (bfg && !dg_on_side) {
+      x.rc = mmda_convert_bf16(dgj, 3, stream);
       if (x.rc) return x.rc;
     }
     x.deferring = (l == 1);
@@ -1283,6 +1292,7 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
       x.rc = side_fork(m, stream, &ss);
       if (!x.rc) x.rc = mmda_layernorm_bwd_multi(lb, 3, stream);
       for (int i = 0; i < 3; ++i) { lb[i].dgamma = GG(m->mod[i].ln_w); lb[i].dbeta = GG(m->mod[i].ln_b); lb[i].d_x = nullptr; }
+      if (!x.rc && dg_on_side) x.rc = mmda_convert_bf16(dgj, 3, ss);
       if (!x.rc) x.rc = mmda_layernorm_param_grads(lb, 3, ss);
       if (!x.rc && !x.deferred.empty()) x.rc = mmda_gemm_grouped(x.deferred.data(), (int)x.deferred.size(), ss);
       if (!x.rc && !bside.empty() && dw_overlap) { x.rc = mmda_gemm_bf16_grouped(bside.data(), (int)bside.size(), ss); bside.clear(); }

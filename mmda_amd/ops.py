@@ -61,7 +61,7 @@ def gemm(A, B, *, mode="fp32", transA=False, transB=True, bias=None, bias2=None,
 
 
 def convert_bf16(jobs):
-    """jobs: list of (src[rows, cols] fp32, gather or None, want_plain, want_transposed) -> list of (plain, transposed) bf16 tensors.
+    """jobs: list of (src[rows, cols] fp32 or bf16, gather or None, want_plain, want_transposed) -> list of (plain, transposed) bf16 tensors.
 
     plain is [rows, round_up(cols, 8)], transposed is [cols, round_up(rows, 8)], both zero padded; one launch for all jobs."""
     lib = load()
@@ -74,7 +74,12 @@ def convert_bf16(jobs):
         # filled with NaN patterns so that a padding element the kernel forgot shows up in the tests
         P = torch.full((rows, ldp), float("nan"), device=src.device, dtype=torch.bfloat16) if want_p else None
         T = torch.full((cols, ldt), float("nan"), device=src.device, dtype=torch.bfloat16) if want_t else None
-        j.src = ptr(_f(src)); j.ld = src.shape[1]; j.rows = rows; j.cols = cols; j.gather = ptr(gather)
+        if src.dtype == torch.bfloat16:                 # re-layout of an existing bf16 matrix (row stride = its leading dimension)
+            assert src.is_cuda and src.stride(1) == 1
+            j.src = ptr(src); j.ld = src.stride(0); j.src_bf16 = 1
+        else:
+            j.src = ptr(_f(src)); j.ld = src.shape[1]
+        j.rows = rows; j.cols = cols; j.gather = ptr(gather)
         j.plain = ptr(P); j.ldp = ldp; j.transposed = ptr(T); j.ldt = ldt
         outs.append((P, T))
     check(lib.mmda_convert_bf16(arr, len(jobs), stream_ptr()), "mmda_convert_bf16")
@@ -338,7 +343,7 @@ def lstm_bidir_fwd(pre, whh_f, whh_r, lengths, *, mode="fp32", layer=0, utt=None
                 gate_minor=bool(gate_minor), H=H, cell=cell)
 
 
-def lstm_bidir_bwd(fw, d_utt, d_hseq, *, mode="fp32", layer=0):
+def lstm_bidir_bwd(fw, d_utt, d_hseq, *, mode="fp32", layer=0, dg_bf16_only=False):
     """Consumes the dict returned by lstm_bidir_fwd; returns dG (T,B,2,4H) (overwrites fw['gates'])."""
     lib = load()
     gates = fw["gates"]
@@ -349,6 +354,11 @@ def lstm_bidir_bwd(fw, d_utt, d_hseq, *, mode="fp32", layer=0):
     d = (_lib.LstmDesc * 1)(_desc(H, gates, fw["cstash"], fw["hseq"], pb0, pb1, d_utt, layer, d_hseq, fw.get("xchg"), T + 2, pc0, pc1))
     d[0].gate_minor = int(fw.get("gate_minor", False))
     d[0].cell = _lib.CELL[fw.get("cell", "lstm")]
+    if fw.get("gate_minor") and fw.get("xchg") is not None and MODE[mode] == BF16 and H <= 320:     # wave-autonomous form
+        # the resident gate-minor kernel also emits dG rounded to bf16 (kernel column order); NaN-filled to expose gaps
+        fw["dg_bf16"] = torch.full((T * B, 2 * G4), float("nan"), device=gates.device, dtype=torch.bfloat16)
+        d[0].dg_bf16 = ptr(fw["dg_bf16"])
+        d[0].dg_bf16_only = int(dg_bf16_only)
     check(lib.mmda_lstm_bwd(MODE[mode], 1, d, B, T, ptr(fw["len_dev"]), stream_ptr()), "lstm_bwd")
     return _from_gate_minor(gates, H) if fw.get("gate_minor") else gates
 

@@ -69,6 +69,11 @@ def test_convert_bf16_plain_transposed_gather_padding():
         if P is not None:
             assert torch.equal(P.cpu()[:, :c], ref) and bool((P.cpu()[:, c:] == 0).all())
         assert torch.equal(T.cpu()[:, :r], ref.t()) and bool((T.cpu()[:, r:] == 0).all())
+    # bf16 source (re-layout only): transpose of a bf16 matrix with a padded leading dimension
+    Sb = torch.randn(130, 40).to(torch.bfloat16).to(dev())
+    (Pb, Tb), = ops.convert_bf16([(Sb[:, :37], None, True, True)])
+    assert torch.equal(Pb.cpu()[:, :37], Sb.cpu()[:, :37]) and bool((Pb.cpu()[:, 37:] == 0).all())
+    assert torch.equal(Tb.cpu()[:, :130], Sb.cpu()[:, :37].t()) and bool((Tb.cpu()[:, 130:] == 0).all())
 
 
 @pytest.mark.parametrize("M,N,K", [(1600, 2400, 300), (1600, 1200, 300), (128, 128, 64), (33, 70, 35), (7, 12, 768), (1600, 140, 40),
@@ -456,6 +461,16 @@ def test_lstm_fwd_bwd_vs_nn_lstm(mode, T, B, H, ragged):
     assert not ops.lstm_aborted(fw), "cluster exchange timed out in backward"
     mask = (torch.arange(T)[:, None] < lengths[None, :]).reshape(T * B)
     assert float(dG.cpu()[~mask].abs().max() if (~mask).any() else 0.0) == 0.0, "dG must be zero at padded positions"
+    if "dg_bf16" in fw:
+        # the kernel's own bf16 copy of dG (kernel column order [dir][unit][gate]) == the fp32 dG rounded, zeros at padding
+        want = ops._to_gate_minor(dG.view(T, B, 2, 4 * H), H).reshape(T * B, 8 * H).to(torch.bfloat16)
+        assert torch.equal(fw["dg_bf16"].view(torch.int16), want.view(torch.int16)), "bf16 dG copy differs from round(dG)"
+        # production form: only the bf16 copy is written (the fp32 stores are what the kernel's memory pipeline is busy with)
+        fw2 = ops.lstm_bidir_fwd(pre, rnn.weight_hh_l0.detach().to(d), rnn.weight_hh_l0_reverse.detach().to(d), lengths, mode=mode,
+                                 layer=1, resident=resident, gate_minor=gate_minor)
+        ops.lstm_bidir_bwd(fw2, d_utt.view(B, 4 * H).to(d), d_out.to(d), mode=mode, layer=1, dg_bf16_only=True)
+        assert not ops.lstm_aborted(fw2)
+        assert torch.equal(fw2["dg_bf16"].view(torch.int16), fw["dg_bf16"].view(torch.int16))
     btol = tol * (3 if mode == "bf16" else 1)
     dx = ops.gemm(dG, wih.to(d), mode=mode, transB=False).view(T, B, D)
     assert relerr(dx, x.grad) < btol
