@@ -53,7 +53,7 @@ struct CLaunch {
   unsigned epoch_base;
   unsigned long long* dbg;           // diagnostics only: per-workgroup phase cycle sums (NULL in production)
   int gate_minor;                    // `gates` columns are [dir][unit][gate]: 16-byte accesses (see mmda_lstm_desc)
-  int xcd_local;                     // EXPERIMENT: publish with plain stores (valid only when a cluster shares one XCD)
+  int xcd_local;                     // the waves may keep the exchange inside one XCD's L2 after checking their placement (see xcc_announce)
   int wpb;                           // wave-autonomous forward: waves per block (1, 2 or 4)
   int no_stash;                      // forward only (evaluation): gates / cell states are not stashed
   short blk2role[256];               // blockIdx -> linear role (-1: no role, exit at once); roles of one cluster share blockIdx % 8
@@ -424,6 +424,23 @@ __device__ __forceinline__ bool poll_tiles(const unsigned char* poll_flag, const
   }
 }
 
+// XCD-local hand-off (wave-autonomous kernels).  A wave exchanges data only with the waves of its own m-tile (19 for text), and
+// the host places those on block ids that are equal mod 8, which the dispatcher has been observed -- not promised -- to deal
+// to one XCD.  When that holds the exchange can stay inside that XCD's L2: plain stores keep their lines there (sc1 stores write
+// through and drop them, so that even a same-XCD reader pays the cross-XCD latency) and the readers' sc1 loads are L2-served.
+// Because the placement is not a contract the waves CHECK it: each stores {launch epoch, XCC_ID} next to its flag before its first
+// (write-through) publish; at step 1, after the usual poll, every wave reads the ids of all tiles of its m-tile and switches to
+// the plain-store form only if they all equal its own.  All waves of the m-tile read the same words, so they agree.
+typedef unsigned long long gu64 __attribute__((address_space(1)));
+__device__ __forceinline__ unsigned my_xcc_id() { return __builtin_amdgcn_s_getreg(6164) & 15u; }           // HW_REG_XCC_ID[3:0]
+__device__ __forceinline__ void xcc_announce(unsigned char* my_flag, unsigned epoch_base, unsigned xcc) {
+  __hip_atomic_store((gu64*)(my_flag + 8), ((unsigned long long)xcc << 32) | epoch_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool xcc_all_local(const unsigned char* tile_flag, bool watching, unsigned epoch_base, unsigned xcc) {
+  const unsigned long long v = __hip_atomic_load((const gu64*)(tile_flag + 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __all(!watching || v == (((unsigned long long)xcc << 32) | epoch_base));
+}
+
 // ------------------------------------------------------------------------------------------------ forward, wave-autonomous form
 // Same cluster, same math, no workgroup barrier and no LDS staging.  Every wave owns one (16-sample m-tile, 16-unit hidden
 // tile) for the whole sequence and runs on its own:
@@ -563,6 +580,9 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wave_kernel(CLaunch L) {
     }
     load_pre(Pp, ps + 2);
   };
+  bool fast = false;                                    // XCD-local hand-off in force (wave-uniform, same in every wave of the m-tile)
+  const unsigned xcc = my_xcc_id();
+  if (L.xcd_local && lane == 0) xcc_announce(my_flag, L.epoch_base, xcc);
   // P: pre-activations of this step; Pp: the buffer the previous step used (refilled for step + 1 by flush)
   auto do_step = [&](int step, float (&P)[4][4], float (&Pp)[4][4]) {
     const int t = dir ? T - 1 - step : step;
@@ -575,6 +595,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wave_kernel(CLaunch L) {
       const unsigned need = epoch - 1u;
       alive = poll_tiles(poll_flag, abort_w, lane < nHT, need);
       if (!alive) { if (lane == 0) st_flag(abort_w, 1u); return; }
+      if (L.xcd_local && step == 1) fast = xcc_all_local(poll_flag, lane < nHT, L.epoch_base, xcc);
       STAMP(0);
       const unsigned par = (need & 1u) * slot_b;
       bf16x8 af[KSM];
@@ -620,10 +641,11 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wave_kernel(CLaunch L) {
       STAMP(3);
       const unsigned par = (epoch & 1u) * slot_b;
       const u32x4 v = *reinterpret_cast<const u32x4*>(&Tr[(lane & 31) * 8]);
-      st16_sc1(xr, pub_off == OOB ? OOB : par + pub_off, v);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's write-through stores have landed
+      if (fast) st16_plain(xr, pub_off == OOB ? OOB : par + pub_off, v);
+      else st16_sc1(xr, pub_off == OOB ? OOB : par + pub_off, v);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's stores have landed (in L2 / written through)
       STAMP(4);
-      if (lane == 0) st_flag(my_flag, epoch);
+      if (lane == 0) { if (fast) st_flag_plain(my_flag, epoch); else st_flag(my_flag, epoch); }
     }
   };
   {
@@ -1111,6 +1133,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
       }
     }
   };
+  bool fast = false;                                    // XCD-local hand-off in force (see xcc_announce)
+  const unsigned xcc = my_xcc_id();
+  if (L.xcd_local && lane == 0) xcc_announce(my_flag, L.epoch_base, xcc);
   auto do_step = [&](int step) {
     const unsigned epoch = L.epoch_base + (unsigned)step + 1u;
     float dh_rec[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1118,6 +1143,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
       const unsigned need = epoch - 1u;
       alive = poll_tiles(poll_flag, abort_w, lane < nHT, need);
       if (!alive) { if (lane == 0) st_flag(abort_w, 1u); return; }
+      if (L.xcd_local && step == 1) fast = xcc_all_local(poll_flag, lane < nHT, L.epoch_base, xcc);
       STAMP(0);
       const unsigned par = (need & 1u) * slot_b;
       u32x2 gv[NTM];
@@ -1178,13 +1204,14 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
           u32x2 pk;
           pk[0] = (unsigned)f2bf(acc[0]) | ((unsigned)f2bf(acc[1]) << 16);
           pk[1] = (unsigned)f2bf(acc[2]) | ((unsigned)f2bf(acc[3]) << 16);
-          __builtin_amdgcn_raw_buffer_store_b64(pk, xr, par + pub_base + (unsigned)nt * pub_stride, 0, 16);
+          if (fast) __builtin_amdgcn_raw_buffer_store_b64(pk, xr, par + pub_base + (unsigned)nt * pub_stride, 0, 0);
+          else __builtin_amdgcn_raw_buffer_store_b64(pk, xr, par + pub_base + (unsigned)nt * pub_stride, 0, 16);
         }
       }
       STAMP(4);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's write-through stores have landed
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's stores have landed (in L2 / written through)
       STAMP(5);
-      if (lane == 0) st_flag(my_flag, epoch);
+      if (lane == 0) { if (fast) st_flag_plain(my_flag, epoch); else st_flag(my_flag, epoch); }
       __builtin_amdgcn_sched_barrier(0);                             // keep the folding behind the hand-off
       derive(step + 1);
     }
@@ -1339,15 +1366,24 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
     // Placement (speed only): blocks b and b + 8 are dealt to the same XCD, so the members of one cluster get block ids that
     // are equal mod 8; clusters go to the XCD with the fewest members so far.
     static const int use_place = getenv("MMDA_NO_PLACEMENT") ? 0 : 1;
-    L.xcd_local = getenv("MMDA_XCD_LOCAL") ? 1 : 0;
+    static const int xcd_env = getenv("MMDA_XCD_LOCAL") ? atoi(getenv("MMDA_XCD_LOCAL")) : 1;      // 0: ablation (always write through)
+    L.xcd_local = xcd_env;
     for (int b = 0; b < 256; ++b) L.blk2role[b] = -1;
     int grid_blocks = wg;
     {
       int used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       bool fits = use_place && wg <= 256;
-      std::vector<std::pair<int, int>> clusters;     // (first role, members)
+      // (first role, members).  Wave form with one wave per block: a wave exchanges data only with the waves of its own m-tile
+      // (roles first + mt, first + mt + 2, ...), so each m-tile is a cluster of its own (19 blocks for text: fits an XCD's 32 CUs).
+      const bool by_mt = fwd_wave && wpb == 1;
+      const int stride = by_mt ? 2 : 1;
+      std::vector<std::pair<int, int>> clusters;
       for (int i = 0; i < n; ++i)
-        for (int c2 = 0; c2 < 2 * L.ng; ++c2) clusters.push_back({L.d[i].wg_begin + c2 * members[i], members[i]});
+        for (int c2 = 0; c2 < 2 * L.ng; ++c2) {
+          const int first = L.d[i].wg_begin + c2 * members[i];
+          if (by_mt) { clusters.push_back({first, members[i] / 2}); clusters.push_back({first + 1, members[i] / 2}); }
+          else clusters.push_back({first, members[i]});
+        }
       std::stable_sort(clusters.begin(), clusters.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.second > b.second; });
       short map[256];
       for (int b = 0; b < 256; ++b) map[b] = -1;
@@ -1356,12 +1392,15 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
         int x = 0;
         for (int k = 1; k < 8; ++k) if (used[k] < used[x]) x = k;
         if (used[x] + cl.second > 32) { fits = false; break; }
-        for (int j = 0; j < cl.second; ++j) map[(used[x] + j) * 8 + x] = (short)(cl.first + j);
+        for (int j = 0; j < cl.second; ++j) map[(used[x] + j) * 8 + x] = (short)(cl.first + j * stride);
         used[x] += cl.second;
         if (used[x] > max_slots) max_slots = used[x];
       }
       if (fits) { for (int b = 0; b < 256; ++b) L.blk2role[b] = map[b]; grid_blocks = 8 * max_slots; }
       else { for (int b = 0; b < wg && b < 256; ++b) L.blk2role[b] = (short)b; L.xcd_local = 0; }
+      // only the wave kernels with one wave per block verify the placement (per m-tile) before they rely on it; the barrier-form
+      // kernels' unchecked variant stays an experiment (MMDA_XCD_LOCAL=2)
+      if (!by_mt && xcd_env != 2) L.xcd_local = 0;
     }
     bool bwd_regs = true;                    // every descriptor's n-tiles fit the register-resident form (<= 10 per wave)
     for (int i = 0; i < n; ++i) bwd_regs = bwd_regs && L.d[i].nHT <= 20;
