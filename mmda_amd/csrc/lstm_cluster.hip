@@ -432,6 +432,13 @@ __device__ __forceinline__ bool poll_tiles(const unsigned char* poll_flag, const
 // (write-through) publish; at step 1, after the usual poll, every wave reads the ids of all tiles of its m-tile and switches to
 // the plain-store form only if they all equal its own.  All waves of the m-tile read the same words, so they agree.
 typedef unsigned long long gu64 __attribute__((address_space(1)));
+// two floats -> one dword of two bf16 (round to nearest even): ONE v_cvt_pk_bf16_f32 on gfx950
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
+}
+constexpr unsigned FAR = 0x40000000u;      // added to a valid offset it lands beyond any exchange buffer (and does not wrap)
 __device__ __forceinline__ unsigned my_xcc_id() { return __builtin_amdgcn_s_getreg(6164) & 15u; }           // HW_REG_XCC_ID[3:0]
 __device__ __forceinline__ void xcc_announce(unsigned char* my_flag, unsigned epoch_base, unsigned xcc) {
   __hip_atomic_store((gu64*)(my_flag + 8), ((unsigned long long)xcc << 32) | epoch_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1122,9 +1129,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
       if (gm) {
         if (f32_dg) stf4(rg, o, f32x4{dgv[r][0], dgv[r][1], dgv[r][2], dgv[r][3]});
         if (has_dg16) {                                // the same four values rounded to bf16: 8 bytes at half the byte offset
-          u32x2 pk;
-          pk[0] = (unsigned)f2bf(dgv[r][0]) | ((unsigned)f2bf(dgv[r][1]) << 16);
-          pk[1] = (unsigned)f2bf(dgv[r][2]) | ((unsigned)f2bf(dgv[r][3]) << 16);
+          const u32x2 pk = {pack_bf16x2(dgv[r][0], dgv[r][1]), pack_bf16x2(dgv[r][2], dgv[r][3])};
           __builtin_amdgcn_raw_buffer_store_b64(pk, rg16, inb[r] ? (og[r] + (unsigned)t * sg) >> 1 : OOB, 0, 0);
         }
       } else {
@@ -1149,7 +1154,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
       u32x2 gv[NTM];
 #pragma unroll
       for (int p = 0; p < NTM; ++p)
-        gv[p] = __builtin_amdgcn_raw_buffer_load_b64(xr, p < nHT ? par + gat_base + (unsigned)p * 512u : OOB, 0, 16);
+        gv[p] = __builtin_amdgcn_raw_buffer_load_b64(xr, gat_base + (p < nHT ? par + (unsigned)p * 512u : FAR), 0, 16);
       flush(step - 1);
       load_raw(step + 1);                                // consumed by derive() at the end of this step
       STAMP(1);
@@ -1205,14 +1210,21 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
 #pragma unroll
       for (int nt = 0; nt < NTM; ++nt) accs[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wreg[nt][1], accs[nt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+      // the tile-dependent part of the offset is wave-uniform (scalar select, one vector add); tiles past nHT go out of range
+      if (fast) {
 #pragma unroll
-      for (int nt = 0; nt < NTM; ++nt) {
-        u32x2 pk;
-        pk[0] = (unsigned)f2bf(accs[nt][0]) | ((unsigned)f2bf(accs[nt][1]) << 16);
-        pk[1] = (unsigned)f2bf(accs[nt][2]) | ((unsigned)f2bf(accs[nt][3]) << 16);
-        const unsigned off = nt < nHT ? par + pub_base + (unsigned)nt * pub_stride : OOB;
-        if (fast) __builtin_amdgcn_raw_buffer_store_b64(pk, xr, off, 0, 0);
-        else __builtin_amdgcn_raw_buffer_store_b64(pk, xr, off, 0, 16);
+        for (int nt = 0; nt < NTM; ++nt) {
+          const u32x2 pk = {pack_bf16x2(accs[nt][0], accs[nt][1]), pack_bf16x2(accs[nt][2], accs[nt][3])};
+          const unsigned so = nt < nHT ? par + (unsigned)nt * pub_stride : FAR;
+          __builtin_amdgcn_raw_buffer_store_b64(pk, xr, pub_base + so, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int nt = 0; nt < NTM; ++nt) {
+          const u32x2 pk = {pack_bf16x2(accs[nt][0], accs[nt][1]), pack_bf16x2(accs[nt][2], accs[nt][3])};
+          const unsigned so = nt < nHT ? par + (unsigned)nt * pub_stride : FAR;
+          __builtin_amdgcn_raw_buffer_store_b64(pk, xr, pub_base + so, 0, 16);
+        }
       }
       STAMP(4);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's stores have landed (in L2 / written through)
