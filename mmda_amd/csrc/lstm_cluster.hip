@@ -68,7 +68,8 @@ __host__ __device__ inline size_t xchg_x_off(int ngroups_total, int NC) { return
 // one exchange slot = one (direction, group, parity): forward uses GROUP x 4Hp bf16 of it, backward NC x GROUP x Hp
 __host__ __device__ inline size_t xchg_slot(int NC, int Hp) {
   const size_t barrier_form = (size_t)(NC > 4 ? NC : 4) * GROUP * Hp * 2;
-  const size_t wave_form = (size_t)(Hp / 16) * 2 * (Hp / 16) * 512;       // backward, wave-autonomous: [tile][m-tile][tile][64] x 8 B
+  // backward, wave-autonomous: [consumer tile][m-tile][producer tile (count rounded up to even)][64] x 8 B
+  const size_t wave_form = (size_t)(Hp / 16) * 2 * (((Hp / 16) + 1) & ~1) * 512;
   return barrier_form > wave_form ? barrier_form : wave_form;
 }
 __host__ __device__ inline size_t xchg_bytes(int ngroups_total, int NC, int Hp) {
@@ -1106,11 +1107,19 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
   load_raw(1);
   // exchange image per parity: [consumer tile nt][m-tile][producer tile][64 lanes] x 8 B
   const unsigned slot_b = (unsigned)xchg_slot(NC, Hp);
-  const unsigned img_b = (unsigned)(nHT * 2 * nHT) * 512u;
+  // One region of RS bytes per (consumer tile, m-tile).  Two arrangements of the producers' 512-byte partials inside it:
+  //   write-through form : [producer][lane] x 8 B          -- every 128-byte line is written whole by one wave's store
+  //   XCD-local form     : [producer pair][lane][2] x 8 B  -- the consumer fetches two producers per 16-byte load (half the load
+  //                        instructions of the gather; the 8-byte halves of a line come from two waves, which L2 merges)
+  const unsigned RS = (unsigned)((nHT + 1) & ~1) * 512u;
+  const unsigned img_b = (unsigned)(nHT * 2) * RS;
   const __amdgpu_buffer_rsrc_t xr = make_rsrc(Xb, slot_b + img_b);
-  const unsigned gat_base = (unsigned)((((ht * 2 + mt) * nHT) * 64 + lane) * 8);          // + producer * 512
-  const unsigned pub_base = (unsigned)(((mt * nHT + ht) * 64 + lane) * 8);                // + consumer tile nt * (2 * nHT * 512)
-  const unsigned pub_stride = (unsigned)(2 * nHT) * 512u;
+  const unsigned gat_base = (unsigned)(ht * 2 + mt) * RS + (unsigned)lane * 8u;          // + producer * 512
+  const unsigned pub_base = (unsigned)mt * RS + (unsigned)(ht * 64 + lane) * 8u;         // + consumer tile nt * pub_stride
+  const unsigned gat_base2 = (unsigned)(ht * 2 + mt) * RS + (unsigned)lane * 16u;        // + producer pair * 1024
+  const unsigned pub_base2 = (unsigned)mt * RS + (unsigned)(ht >> 1) * 1024u + (unsigned)lane * 16u + (unsigned)(ht & 1) * 8u;
+  const unsigned pub_stride = 2u * RS;
+  bool paired = false;                                  // arrangement of the image the NEXT gather reads (= what the last publish used)
 
   unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last = 0;
 #define STAMP(i) do { if (L.dbg && tid == 0) { unsigned long long now_ = __builtin_readcyclecounter(); ph[i] += now_ - last; last = now_; } } while (0)
@@ -1151,19 +1160,42 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
       if (L.xcd_local && step == 1) fast = xcc_all_local(poll_flag, lane < nHT, L.epoch_base, xcc);
       STAMP(0);
       const unsigned par = (need & 1u) * slot_b;
-      u32x2 gv[NTM];
+      if (paired) {                                      // wave-uniform
+        u32x4 gq[NTM / 2];
 #pragma unroll
-      for (int p = 0; p < NTM; ++p)
-        gv[p] = __builtin_amdgcn_raw_buffer_load_b64(xr, gat_base + (p < nHT ? par + (unsigned)p * 512u : FAR), 0, 16);
-      flush(step - 1);
-      load_raw(step + 1);                                // consumed by derive() at the end of this step
-      STAMP(1);
+        for (int q = 0; q < NTM / 2; ++q)
+          gq[q] = __builtin_amdgcn_raw_buffer_load_b128(xr, gat_base2 + (2 * q < nHT ? par + (unsigned)q * 1024u : FAR), 0, 16);
+        flush(step - 1);
+        load_raw(step + 1);                              // consumed by derive() at the end of this step
+        STAMP(1);
 #pragma unroll
-      for (int p = 0; p < NTM; ++p) {
-        dh_rec[0] += __builtin_bit_cast(float, gv[p][0] << 16);
-        dh_rec[1] += __builtin_bit_cast(float, gv[p][0] & 0xffff0000u);
-        dh_rec[2] += __builtin_bit_cast(float, gv[p][1] << 16);
-        dh_rec[3] += __builtin_bit_cast(float, gv[p][1] & 0xffff0000u);
+        for (int q = 0; q < NTM / 2; ++q) {              // same summation order as the unpaired form: producer 2q, then 2q + 1
+          const bool two = 2 * q + 1 < nHT;              // the upper half of an odd count's last pair was written by nobody
+          const unsigned b0 = two ? gq[q][2] : 0u, b1 = two ? gq[q][3] : 0u;
+          dh_rec[0] += __builtin_bit_cast(float, gq[q][0] << 16);
+          dh_rec[1] += __builtin_bit_cast(float, gq[q][0] & 0xffff0000u);
+          dh_rec[2] += __builtin_bit_cast(float, gq[q][1] << 16);
+          dh_rec[3] += __builtin_bit_cast(float, gq[q][1] & 0xffff0000u);
+          dh_rec[0] += __builtin_bit_cast(float, b0 << 16);
+          dh_rec[1] += __builtin_bit_cast(float, b0 & 0xffff0000u);
+          dh_rec[2] += __builtin_bit_cast(float, b1 << 16);
+          dh_rec[3] += __builtin_bit_cast(float, b1 & 0xffff0000u);
+        }
+      } else {
+        u32x2 gv[NTM];
+#pragma unroll
+        for (int p = 0; p < NTM; ++p)
+          gv[p] = __builtin_amdgcn_raw_buffer_load_b64(xr, gat_base + (p < nHT ? par + (unsigned)p * 512u : FAR), 0, 16);
+        flush(step - 1);
+        load_raw(step + 1);                              // consumed by derive() at the end of this step
+        STAMP(1);
+#pragma unroll
+        for (int p = 0; p < NTM; ++p) {
+          dh_rec[0] += __builtin_bit_cast(float, gv[p][0] << 16);
+          dh_rec[1] += __builtin_bit_cast(float, gv[p][0] & 0xffff0000u);
+          dh_rec[2] += __builtin_bit_cast(float, gv[p][1] << 16);
+          dh_rec[3] += __builtin_bit_cast(float, gv[p][1] & 0xffff0000u);
+        }
       }
     }
     if (L.dbg) { asm volatile("s_nop 0" :: "v"(dh_rec[0]), "v"(dh_rec[1]), "v"(dh_rec[2]), "v"(dh_rec[3])); STAMP(2); }
@@ -1216,7 +1248,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
         for (int nt = 0; nt < NTM; ++nt) {
           const u32x2 pk = {pack_bf16x2(accs[nt][0], accs[nt][1]), pack_bf16x2(accs[nt][2], accs[nt][3])};
           const unsigned so = nt < nHT ? par + (unsigned)nt * pub_stride : FAR;
-          __builtin_amdgcn_raw_buffer_store_b64(pk, xr, pub_base + so, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(pk, xr, pub_base2 + so, 0, 0);
         }
       } else {
 #pragma unroll
@@ -1230,6 +1262,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's stores have landed (in L2 / written through)
       STAMP(5);
       if (lane == 0) { if (fast) st_flag_plain(my_flag, epoch); else st_flag(my_flag, epoch); }
+      paired = fast;
       __builtin_amdgcn_sched_barrier(0);                             // keep the folding behind the hand-off
       derive(step + 1);
     }
