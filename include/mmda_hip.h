@@ -387,6 +387,13 @@ int mmda_misa_set_gemm_operands(mmda_misa* m, int bf16_copies);
  * bf16 copies that only the weight-gradient GEMMs read are not made.  Default 0.  mmda_misa_backward after a forward in this mode
  * returns MMDA_EINVAL. */
 int mmda_misa_set_inference(mmda_misa* m, int forward_only);
+/* Data parallel: the gradient bucket is laid out in the order the backward pass completes it (fusion block, LayerNorms,
+ * layer-2 recurrent layers, layer-1 recurrent layers, embedding).  After mmda_misa_backward / mmda_misa_train_step has been
+ * ISSUED, the first mmda_misa_early_grad_floats() floats of the bucket are final as soon as an event recorded inside that call
+ * fires -- beside the layer-1 backward recurrence, long before the call's last kernel; mmda_misa_wait_early_grads makes `stream`
+ * wait for that event, so a collective enqueued on it overlaps the rest of the backward pass.  0 floats = nothing is early. */
+int64_t mmda_misa_early_grad_floats(const mmda_misa* m);
+int mmda_misa_wait_early_grads(mmda_misa* m, void* stream);
 /* 1 (default) = weight-gradient GEMMs run on an internal side stream underneath the recurrent kernels (joined before
  * mmda_misa_backward returns control of `stream`); 0 = everything on `stream` */
 int mmda_misa_set_overlap(mmda_misa* m, int side_stream);

@@ -164,6 +164,8 @@ SIGNATURES = {
     "mmda_misa_set_overlap": (_I, [_P, _I]),
     "mmda_misa_set_recurrence": (_I, [_P, _I]),
     "mmda_misa_set_gemm_operands": (_I, [_P, _I]),
+    "mmda_misa_early_grad_floats": (_I64, [_P]),
+    "mmda_misa_wait_early_grads": (_I, [_P, _P]),
     "mmda_misa_set_inference": (_I, [_P, _I]),
     "mmda_misa_cluster_status": (_I, [_P, C.POINTER(_I)]),
     "mmda_misa_forward": (_I, [_P, _P, _P, _P, _P, _I, _U64, _P]),

@@ -45,6 +45,9 @@ struct mmda_misa {
   std::vector<ParamInfo> params;
   std::map<std::string, int> index;
   int64_t dense = 0, flat = 0;
+  int64_t rnn2_begin = 0, rnn1_begin = 0;    // bucket offsets where the layer-2 / layer-1 recurrent parameters start
+  hipEvent_t ev_early = nullptr;             // recorded by backward() when the gradients of the bucket prefix are final
+  int64_t early_floats = 0; int early_valid = 0;
   Mod mod[3];
   // fusion parameter offsets
   int64_t priv_w, priv_b, sh_w, sh_b, rec_w, rec_b, d1_w = -1, d1_b = -1, d2_w = -1, d2_b = -1, sp_w, sp_b;
@@ -100,24 +103,10 @@ void build_params(mmda_misa* m) {
   const int dims[3] = {c.d_t, c.d_v, c.d_a};
   const char* mn[3] = {"t", "v", "a"};
   const int hs = c.hidden;
-  for (int i = 0; i < 3; ++i) {
-    Mod& md = m->mod[i];
-    md.D = md.H = dims[i];
-    for (int l = 0; l < 2; ++l) {
-      Rnn& r = md.rnn[l];
-      r.H = md.H; r.D = l == 0 ? md.D : 2 * md.H;
-      const int ng = c.rnncell == MMDA_CELL_GRU ? 3 : 4;      // gate blocks per direction in the torch-layout parameters
-      std::string pre = std::string(mn[i]) + "rnn" + (l == 0 ? "1" : "2") + ".";
-      r.w_ih = add_param(m, pre + "weight_ih_l0", ng * r.H, r.D);
-      add_param(m, pre + "weight_ih_l0_reverse", ng * r.H, r.D);
-      r.w_hh[0] = add_param(m, pre + "weight_hh_l0", ng * r.H, r.H);
-      r.w_hh[1] = add_param(m, pre + "weight_hh_l0_reverse", ng * r.H, r.H);
-      r.b_ih = add_param(m, pre + "bias_ih_l0", ng * r.H, 0);
-      add_param(m, pre + "bias_ih_l0_reverse", ng * r.H, 0);
-      r.b_hh = add_param(m, pre + "bias_hh_l0", ng * r.H, 0);
-      add_param(m, pre + "bias_hh_l0_reverse", ng * r.H, 0);
-    }
-  }
+  // Order of the dense bucket = the order in which the backward pass completes the gradients (data-parallel ranks start
+  // reducing a prefix while the rest is still being computed, mmda_misa_early_grad_floats): fusion block and LayerNorms first,
+  // then the layer-2 recurrent layers, then layer 1; the embedding matrix closes the bucket.
+  for (int i = 0; i < 3; ++i) { Mod& md = m->mod[i]; md.D = md.H = dims[i]; }
   for (int i = 0; i < 3; ++i) {
     Mod& md = m->mod[i];
     std::string p = std::string("project_") + mn[i] + ".project_" + mn[i];
@@ -171,6 +160,25 @@ void build_params(mmda_misa* m) {
   m->n1_b = add_param(m, te + "norm1.bias", hs, 0);
   m->n2_w = add_param(m, te + "norm2.weight", hs, 0);
   m->n2_b = add_param(m, te + "norm2.bias", hs, 0);
+  for (int l = 1; l >= 0; --l) {
+    m->flat = (m->flat + 3) & ~(int64_t)3;
+    (l == 1 ? m->rnn2_begin : m->rnn1_begin) = m->flat;
+    for (int i = 0; i < 3; ++i) {
+      Mod& md = m->mod[i];
+      Rnn& r = md.rnn[l];
+      r.H = md.H; r.D = l == 0 ? md.D : 2 * md.H;
+      const int ng = c.rnncell == MMDA_CELL_GRU ? 3 : 4;      // gate blocks per direction in the torch-layout parameters
+      std::string pre = std::string(mn[i]) + "rnn" + (l == 0 ? "1" : "2") + ".";
+      r.w_ih = add_param(m, pre + "weight_ih_l0", ng * r.H, r.D);
+      add_param(m, pre + "weight_ih_l0_reverse", ng * r.H, r.D);
+      r.w_hh[0] = add_param(m, pre + "weight_hh_l0", ng * r.H, r.H);
+      r.w_hh[1] = add_param(m, pre + "weight_hh_l0_reverse", ng * r.H, r.H);
+      r.b_ih = add_param(m, pre + "bias_ih_l0", ng * r.H, 0);
+      add_param(m, pre + "bias_ih_l0_reverse", ng * r.H, 0);
+      r.b_hh = add_param(m, pre + "bias_hh_l0", ng * r.H, 0);
+      add_param(m, pre + "bias_hh_l0_reverse", ng * r.H, 0);
+    }
+  }
   m->flat = (m->flat + 3) & ~(int64_t)3;
   m->dense = m->flat;
   m->embed = add_param(m, "embed.weight", c.vocab, c.d_t);
@@ -461,6 +469,7 @@ extern "C" void mmda_misa_destroy(mmda_misa* m) {
   if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
   if (m->ev_join) (void)hipEventDestroy(m->ev_join);
   if (m->ev_pack) (void)hipEventDestroy(m->ev_pack);
+  if (m->ev_early) (void)hipEventDestroy(m->ev_early);
   if (m->side) (void)hipStreamDestroy(m->side);
   for (hipEvent_t e : m->ev) (void)hipEventDestroy(e);
   delete m;
@@ -523,6 +532,14 @@ extern "C" int mmda_misa_set_recurrence(mmda_misa* m, int resident_weights) {
 extern "C" int mmda_misa_set_gemm_operands(mmda_misa* m, int bf16_copies) {
   if (!m) return MMDA_EINVAL;
   m->use_bf16_gemm = bf16_copies ? 1 : 0;
+  return MMDA_OK;
+}
+extern "C" int64_t mmda_misa_early_grad_floats(const mmda_misa* m) {
+  return (m && m->early_valid) ? m->early_floats : 0;
+}
+extern "C" int mmda_misa_wait_early_grads(mmda_misa* m, void* stream) {
+  if (!m || !m->early_valid || !m->ev_early) return MMDA_EINVAL;
+  if (hipStreamWaitEvent((hipStream_t)stream, m->ev_early, 0) != hipSuccess) return MMDA_ELAUNCH;
   return MMDA_OK;
 }
 extern "C" int mmda_misa_set_inference(mmda_misa* m, int forward_only) {
@@ -961,6 +978,7 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
                                   void* stream) {
   if (check_ready(m) || !m->G || !t_ids || !v || !a || !lengths) return MMDA_EINVAL;
   if (m->last_fwd_inference) return MMDA_EINVAL;        // the last forward was an evaluation pass: nothing was stashed
+  m->early_valid = 0;
   const mmda_misa_config& c = m->cfg;
   const int B = m->B, T = m->T, hs = c.hidden, mode = c.mode, NC = 6 + c.ncls;
   const int fmode = MMDA_F32;       // fusion block: exact path (see mmda_misa_forward)
@@ -1295,8 +1313,18 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
       if (!x.rc && dg_on_side) x.rc = mmda_convert_bf16(dgj, 3, ss);
       if (!x.rc) x.rc = mmda_layernorm_param_grads(lb, 3, ss);
       if (!x.rc && !x.deferred.empty()) x.rc = mmda_gemm_grouped(x.deferred.data(), (int)x.deferred.size(), ss);
-      if (!x.rc && !bside.empty() && dw_overlap) { x.rc = mmda_gemm_bf16_grouped(bside.data(), (int)bside.size(), ss); bside.clear(); }
+      const bool l2_early = !bside.empty() && dw_overlap;
+      if (!x.rc && l2_early) { x.rc = mmda_gemm_bf16_grouped(bside.data(), (int)bside.size(), ss); bside.clear(); }
       x.deferred.clear();
+      // Everything issued so far on either stream is final for the fusion block, the LayerNorms and -- when its weight-gradient
+      // GEMMs just went out and no GRU re-layout follows -- layer 2: data-parallel ranks may start reducing that prefix now,
+      // beside the layer-1 recurrence (mmda_misa_wait_early_grads).
+      if (!x.rc) {
+        if (!m->ev_early && hipEventCreateWithFlags(&m->ev_early, hipEventDisableTiming) != hipSuccess) x.rc = MMDA_ELAUNCH;
+        if (!x.rc && hipEventRecord(m->ev_early, (hipStream_t)ss) != hipSuccess) x.rc = MMDA_ELAUNCH;
+        m->early_floats = (l2_early && !is_gru(m) && mode == MMDA_BF16 && m->use_bf16_gemm) ? m->rnn1_begin : m->rnn2_begin;
+        m->early_valid = 1;
+      }
     } else if (!x.rc) {
       // text: gradient w.r.t. the embedding rows, scattered densely into embed.weight.grad (sparse=False)
       x.rc = mmda_embed_scatter_add(GG(m->embed), t_ids, R, c.d_t, WS(m->mod[0].d_x), stream);

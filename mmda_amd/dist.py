@@ -6,6 +6,10 @@ rank runs the reference loop on its own minibatch shard and the ranks exchange O
 gradient, summed with a single all-reduce and averaged by passing grad_scale = 1/world to the fused clamp+Adam kernel, so
 the clip happens AFTER averaging exactly like the single-process order (solver.py:183-186).
 
+The bucket is ordered by completion time of the backward pass; with ``overlap=True`` (default) the prefix that is final beside
+the layer-1 backward recurrence (fusion block, LayerNorms, layer-2 recurrent layers) is reduced on its own stream behind an
+event the native step records, the rest after the step's last kernel (``sync``).
+
 Semantics = DDP: every rank is the reference at batch_size = B_local; the batch-statistic losses (DiffLoss, CMD, conf)
 are per-shard, gradients are averaged.  Works on CPU tensors with the gloo backend (tests) and on GPU with RCCL.
 """
@@ -16,7 +20,7 @@ import torch.distributed as dist
 
 
 class DataParallelSync:
-    def __init__(self, group=None, bucket_mb: float = 0.0, sparse_embedding: bool = False):
+    def __init__(self, group=None, bucket_mb: float = 0.0, sparse_embedding: bool = False, overlap: bool = True):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
@@ -27,6 +31,8 @@ class DataParallelSync:
         # against 24 MB at V = 20 000), but every rank then scatter-adds with float atomics in its own order, so replicas agree
         # only to rounding, not bit for bit as after an all-reduce.  Default: the dense, bit-identical exchange.
         self.sparse_embedding = bool(sparse_embedding)
+        self.overlap = bool(overlap)          # reduce the early-finished prefix of the bucket beside the rest of the backward pass
+        self._comm = None
 
     def broadcast_parameters(self, model):
         """Rank 0's weights everywhere (one broadcast of the flat bucket when the model has one)."""
@@ -50,6 +56,17 @@ class DataParallelSync:
             t.copy_(h)
             return None
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+
+    def _early_split(self, flat_grads: torch.Tensor, model) -> int:
+        """Floats of the bucket that may be reduced ahead of the rest (0: none / not applicable)."""
+        if not self.overlap or model is None or not flat_grads.is_cuda or not hasattr(model, "early_grad_floats"):
+            return 0
+        early = int(model.early_grad_floats())
+        if early <= 0 or early >= flat_grads.numel():
+            return 0
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(device=flat_grads.device)
+        return early
 
     def _all_gather(self, t: torch.Tensor) -> torch.Tensor:
         """(world, *t.shape) gathered from every rank (equal shapes; t has at least one dimension)."""
@@ -97,6 +114,19 @@ class DataParallelSync:
             self._sync_sparse_embedding(flat_grads, dense_floats, model)
             return 1.0 / self.world
         n = flat_grads.numel()
+        early = self._early_split(flat_grads, model)
+        if early:
+            # The bucket is laid out in the order the backward pass completes it; the native step recorded an event behind the
+            # last kernel that writes its first `early` floats (fusion block, LayerNorms, layer-2 recurrent layers).  That part
+            # is reduced on a stream of its own as soon as the event fires -- beside the layer-1 backward recurrence, which
+            # leaves more than half of the CUs idle -- and the rest (layer 1, embedding) after the step's last kernel.
+            cur = torch.cuda.current_stream(flat_grads.device)
+            with torch.cuda.stream(self._comm):
+                model.wait_early_grads(self._comm)
+                self._all_reduce(flat_grads[:early])
+            self._all_reduce(flat_grads[early:])
+            cur.wait_stream(self._comm)
+            return 1.0 / self.world
         if self.bucket_floats <= 0 or self.bucket_floats >= n:
             self._all_reduce(flat_grads)
         else:

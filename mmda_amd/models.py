@@ -381,6 +381,16 @@ class MISA(nn.Module):
                 scale = grad_sync(self._G, self._dense_floats)
             _lib.check(self._lib.mmda_misa_adam_step(self._h, lr, clip, float(scale), self._step, s), "adam_step")
 
+    # ------------------------------------------------------------------ early part of the gradient bucket (data parallel)
+    def early_grad_floats(self) -> int:
+        """Length of the gradient-bucket prefix (fusion block, LayerNorms, layer-2 recurrent layers) whose gradients are final
+        beside the layer-1 backward recurrence of the step that was just issued; 0 if nothing is early."""
+        return int(self._lib.mmda_misa_early_grad_floats(self._h))
+
+    def wait_early_grads(self, stream) -> None:
+        """Make ``stream`` (a torch.cuda.Stream) wait for the event after which that prefix may be read."""
+        _lib.check(self._lib.mmda_misa_wait_early_grads(self._h, stream.cuda_stream), "wait_early_grads")
+
     # ------------------------------------------------------------------ sparse view of the embedding gradient (data parallel)
     def embedding_grad_rows(self):
         """(ids (R,) int64, rows (R, d_t) fp32) of the last backward: embed.weight.grad == scatter_add(ids, rows).  The dense

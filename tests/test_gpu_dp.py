@@ -91,3 +91,81 @@ def test_two_rank_dp_step_matches_oracle_mean_gradient(sparse):
         d = np.abs(got - ref)
         assert d.max() <= 2 * lr + 1e-7, k                      # one Adam step moves an element by at most lr
         assert (d <= 0.02 * lr).mean() >= 0.99, (k, float((d <= 0.02 * lr).mean()))
+
+
+def _grad_worker(rank, world, port, q, precision):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import misa_oracle as orc
+        from mmda_amd import make_config, MISA
+        from mmda_amd.dist import DataParallelSync
+        cfg = orc.default_config(vocab_size=120)
+        m = MISA(make_config(precision=precision, device="cuda:0", **vars(cfg)))
+        m.load_state_dict(orc.synth_params(cfg, 21))
+        m.to("cuda:0")
+        dp = DataParallelSync(overlap=True)
+        # B = 8 so that the bf16 path takes its production form (gate-minor stash, resident-weights kernels, side-stream GEMMs)
+        batch = orc.synth_batch(cfg, 8, 9, 40 + rank, ragged=True)
+        d = {k: (v.to("cuda:0") if k != "l" else v) for k, v in batch.items()}
+        out = []
+        for it in range(2):                   # twice: the second pass reuses the event and the communication stream
+            m.train_step(d["t"], d["v"], d["a"], d["l"], d["emo"], lr=1e-3, clip=1.0, training=False, do_adam=False)
+            early = m.early_grad_floats()
+            scale = dp.sync(m._G, m._dense_floats, m)
+            torch.cuda.synchronize()
+            out.append((early, scale, m._G.detach().cpu().numpy().copy()))
+        layout = {k: (off, tuple(shape)) for k, (off, shape) in m._layout.items()}
+        q.put((rank, out, layout))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_two_rank_overlapped_reduction_gives_the_summed_gradients(precision):
+    """The prefix of the bucket that is reduced early (beside the layer-1 backward recurrence, on its own stream, behind the
+    event the native step records) must hold the SUM of the shards' final gradients: compared tensor by tensor with the oracle's
+    sum.  A reduction that started before a gradient was complete would agree between the ranks and still fail here."""
+    from oracle import misa_oracle as orc
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q, precision)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, out, layout = q.get(timeout=150)
+        res[rank] = out
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    cfg = orc.default_config(vocab_size=120)
+    P = orc.synth_params(cfg, 21)
+    grads = [orc.loss_and_grads(P, cfg, orc.synth_batch(cfg, 8, 9, 40 + r, ragged=True))[2] for r in range(world)]
+    for it in range(2):
+        early, scale, G0 = res[0][it]
+        _, _, G1 = res[1][it]
+        assert scale == 0.5
+        np.testing.assert_array_equal(G0, G1)                   # the exchanged bucket is identical on both ranks
+        off_l2 = layout["trnn2.weight_ih_l0"][0]; off_l1 = layout["trnn1.weight_ih_l0"][0]
+        assert off_l2 < off_l1 < layout["embed.weight"][0]      # bucket order = completion order of the backward pass
+        assert early == (off_l1 if precision == "bf16" else off_l2), (early, off_l2, off_l1)
+        for k, (off, shape) in layout.items():
+            if grads[0][k] is None:
+                continue
+            ref = (grads[0][k] + grads[1][k]).numpy().ravel().astype(np.float64)
+            got = G0[off:off + ref.size].astype(np.float64)
+            if k.endswith("self_attn.in_proj_bias"):
+                hs = cfg.hidden_size
+                keep = np.ones(3 * hs, bool); keep[hs:2 * hs] = False
+                ref, got = ref[keep], got[keep]
+            nr = np.linalg.norm(ref)
+            if nr == 0:
+                continue
+            err = np.linalg.norm(got - ref) / nr
+            assert err < (2e-4 if precision == "fp32" else 1.5e-1), (k, err, "early" if off < early else "late")
