@@ -239,6 +239,8 @@ typedef struct mmda_lstm_desc {
 int64_t mmda_lstm_xchg_bytes(int H, int B);
 /* 1 if mmda_lstm_fwd/bwd would run these descriptors on the resident-weights kernels (so gate_minor = 1 may be used), else 0 */
 int mmda_lstm_resident_applicable(int mode, int n, const mmda_lstm_desc* descs, int B, int T, int backward);
+/* 1 if mmda_lstm_bwd on these descriptors will write mmda_lstm_desc.dg_bf16 (wave-autonomous resident kernel, gate_minor = 1) */
+int mmda_lstm_bwd_emits_dg_bf16(int mode, int n, const mmda_lstm_desc* descs, int B, int T);
 /* diagnostics only: 8 x uint64 per workgroup, phase cycle sums of the resident-weights forward kernel (NULL disables) */
 int mmda_debug_set_lstm_stamps(void* device_buffer);
 /* up to 4 independent biLSTMs (modalities) in ONE launch; all share B, T and lengths (device int32, B entries) */

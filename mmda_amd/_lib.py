@@ -120,6 +120,7 @@ SIGNATURES = {
     "mmda_lstm_packed_bytes": (_I64, [_I, _I, _I]),
     "mmda_lstm_xchg_bytes": (_I64, [_I, _I]),
     "mmda_lstm_resident_applicable": (_I, [_I, _I, C.POINTER(LstmDesc), _I, _I, _I]),
+    "mmda_lstm_bwd_emits_dg_bf16": (_I, [_I, _I, C.POINTER(LstmDesc), _I, _I]),
     "mmda_debug_set_lstm_stamps": (_I, [_P]),
     "mmda_lstm_pack_whh": (_I, [_I, _I, _P, _P, _P, _P]),
     "mmda_lstm_pack_whh_multi": (_I, [_I, _I, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),

@@ -1372,6 +1372,18 @@ extern "C" int mmda_lstm_resident_applicable(int mode, int n, const mmda_lstm_de
   return cluster_applicable(n, descs, B, T, backward != 0, plans, &lds) ? 1 : 0;
 }
 
+extern "C" int mmda_lstm_bwd_emits_dg_bf16(int mode, int n, const mmda_lstm_desc* descs, int B, int T) {
+  // the wave-autonomous backward kernel with the gate-minor layout is the one that writes mmda_lstm_desc.dg_bf16
+  if (mode != MMDA_BF16 || !descs || n <= 0 || n > MAXD || B <= 0 || T <= 0) return 0;
+  Plan plans[MAXD];
+  size_t lds = 0;
+  if (!cluster_applicable(n, descs, B, T, true, plans, &lds)) return 0;
+  if (!wave_form_ok(n, descs, true, nullptr)) return 0;
+  for (int i = 0; i < n; ++i)
+    if (!descs[i].gate_minor) return 0;
+  return 1;
+}
+
 // returns MMDA_OK and sets *used = 1 when the cluster kernels ran; *used = 0 means "not applicable, use the streaming path"
 int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, const int32_t* lengths, void* stream, bool bwd,
                              int* used) {

@@ -1208,12 +1208,13 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
       desc[i].utt = WS(md.d_utt); desc[i].layer = l; desc[i].d_hseq = l == 0 ? WS(md.d_hseq1) : nullptr;
       desc[i].xchg = (m->use_cluster && md.xchg >= 0) ? (void*)WS(md.xchg) : nullptr; desc[i].epoch_base = m->epoch;
       desc[i].gate_minor = m->gate_minor; desc[i].cell = c.rnncell;
-      // gate-minor => the wave-autonomous kernels run (forward() probed both passes): they also emit the bf16 copy of dG that
-      // the input-gradient GEMM reads (d(normed) for layer 2, d(embedding rows) for the text layer 1)
-      // -- and only that copy: every consumer of dG in this mode is a bf16 GEMM (the transposed operand is made from it)
-      if (m->gate_minor && mode == MMDA_BF16 && m->use_bf16_gemm) { desc[i].dg_bf16 = WS(r.dgb); desc[i].dg_bf16_only = 1; }
     }
-    const bool kdg = desc[0].dg_bf16 != nullptr;
+    // The wave-autonomous gate-minor kernel emits the gate gradients as bf16 (the operand of the input-gradient GEMM) -- and only
+    // as bf16: every consumer of dG in this mode is a bf16 GEMM (the transposed operand is re-laid-out from it).  The other
+    // kernels (barrier form: H > 320, ablation switches) write fp32 `gates` as before.
+    const bool kdg = mode == MMDA_BF16 && m->use_bf16_gemm && mmda_lstm_bwd_emits_dg_bf16(mode, 3, desc, B, T) != 0;
+    if (kdg)
+      for (int i = 0; i < 3; ++i) { desc[i].dg_bf16 = WS(m->mod[i].rnn[l].dgb); desc[i].dg_bf16_only = 1; }
     m->epoch += (unsigned)T + 2u;
     // the forward pass skipped the streaming backward packing because the resident-weights kernels were going to run: they must
     if (!m->pack_b_valid && !mmda_lstm_resident_applicable(mode, 3, desc, B, T, 1)) return MMDA_EINVAL;

@@ -354,7 +354,7 @@ def lstm_bidir_bwd(fw, d_utt, d_hseq, *, mode="fp32", layer=0, dg_bf16_only=Fals
     d = (_lib.LstmDesc * 1)(_desc(H, gates, fw["cstash"], fw["hseq"], pb0, pb1, d_utt, layer, d_hseq, fw.get("xchg"), T + 2, pc0, pc1))
     d[0].gate_minor = int(fw.get("gate_minor", False))
     d[0].cell = _lib.CELL[fw.get("cell", "lstm")]
-    if fw.get("gate_minor") and fw.get("xchg") is not None and MODE[mode] == BF16 and H <= 320:     # wave-autonomous form
+    if MODE[mode] == BF16 and lib.mmda_lstm_bwd_emits_dg_bf16(BF16, 1, d, B, T):
         # the resident gate-minor kernel also emits dG rounded to bf16 (kernel column order); NaN-filled to expose gaps
         fw["dg_bf16"] = torch.full((T * B, 2 * G4), float("nan"), device=gates.device, dtype=torch.bfloat16)
         d[0].dg_bf16 = ptr(fw["dg_bf16"])
