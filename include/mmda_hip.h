@@ -202,7 +202,8 @@ int mmda_lstm_pack_whh_multi(int mode, int n, const int* H, const float* const* 
 typedef struct mmda_lstm_desc {
   int H;
   float* gates;        /* (T,B,2,4H)  in: x W_ih^T + b_ih + b_hh per direction; out: activated i,f,g,o (stash) */
-  float* cstash;       /* (T,B,2,H)   cell state after each step (stash) */
+  float* cstash;       /* (T,B,2,H)   cell state after each step (stash).  With gate_minor = 1 the resident kernels keep it
+                          batch-minor-by-4, (T, ceil(B/4), 2, H, 4): allocate T * round_up(B,4) * 2 * H floats */
   float* hseq;         /* (T,B,2H)    layer output [fwd H | rev H], zero at padded positions */
   const void* wpack[2];/* packed W_hh per direction (forward packing for fwd, backward packing for bwd) */
   const void* wpack_c[2]; /* backward only, optional: "cluster-backward" packing (mmda_lstm_packed_bytes(mode,H,2)) used by the

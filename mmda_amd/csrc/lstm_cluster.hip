@@ -199,7 +199,10 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_cluster_kernel(CLaunch L) {
     for (int i = tid; i < 2 * GROUP * ld; i += 256) hb[i] = 0;
   }
   const __amdgpu_buffer_rsrc_t rg = make_rsrc(D.gates, (unsigned)T * B * 2u * G4 * 4u);
-  const __amdgpu_buffer_rsrc_t rc = make_rsrc(D.cstash, (unsigned)T * B * 2u * H * 4u);
+  // cell-state stash: (T,B,2,H) fp32; with the gate-minor layout it is batch-minor-by-4, (T, ceil(B/4), 2, H, 4): the four samples a
+  // lane owns are 16 contiguous bytes (one access in the wave-autonomous kernels instead of four)
+  const __amdgpu_buffer_rsrc_t rc = make_rsrc(D.cstash, (unsigned)T * (GM ? (unsigned)((B + 3) & ~3) : (unsigned)B) * 2u * H * 4u);
+  const unsigned scc = GM ? (unsigned)((B + 3) >> 2) * 2u * H * 16u : (unsigned)B * 2u * H * 4u;      // its byte stride per time step
   const __amdgpu_buffer_rsrc_t rh = make_rsrc(D.hseq, (unsigned)T * B * 2u * H * 4u);
   const unsigned sg = (unsigned)B * 2u * G4 * 4u, sc = (unsigned)B * 2u * H * 4u;   // byte strides per time step (hseq: sc too)
   unsigned og[4], oc[4], oh[4];
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_cluster_kernel(CLaunch L) {
     const int lv = L.lengths[min(b, B - 1)];
     len_r[r] = inb[r] ? lv : 0;
     og[r] = (((unsigned)b * 2u + dir) * G4 + (gm ? col * 4 : col)) * 4u;
-    oc[r] = (((unsigned)b * 2u + dir) * H + col) * 4u;
+    oc[r] = GM ? ((((((unsigned)b >> 2) * 2u + dir) * H + col) << 2) + ((unsigned)b & 3u)) * 4u : (((unsigned)b * 2u + dir) * H + col) * 4u;
     oh[r] = ((unsigned)b * 2u * H + dir * H + col) * 4u;
   }
   float c_reg[4] = {0.f, 0.f, 0.f, 0.f}, h_reg[4] = {0.f, 0.f, 0.f, 0.f};
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_cluster_kernel(CLaunch L) {
         stf(rg, o, sv[r][0]); stf(rg, act ? o + H * 4u : OOB, sv[r][1]); stf(rg, act ? o + 2u * H * 4u : OOB, sv[r][2]);
         stf(rg, act ? o + 3u * H * 4u : OOB, sv[r][3]);
       }
-      stf(rc, act ? oc[r] + (unsigned)t * sc : OOB, sv[r][4]);
+      stf(rc, act ? oc[r] + (unsigned)t * scc : OOB, sv[r][4]);
       stf(rh, inb[r] ? oh[r] + (unsigned)t * sc : OOB, sv[r][5]);     // zero at padded positions (pad_packed_sequence)
     }
   };
@@ -515,7 +518,10 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wave_kernel(CLaunch L) {
         wreg[g][k2] = k2 < KS ? src[((size_t)(ht * 4 + g) * KS + k2) * 64 + lane] : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
   }
   const __amdgpu_buffer_rsrc_t rg = make_rsrc(D.gates, (unsigned)T * B * 2u * G4 * 4u);
-  const __amdgpu_buffer_rsrc_t rc = make_rsrc(D.cstash, (unsigned)T * B * 2u * H * 4u);
+  // cell-state stash: (T,B,2,H) fp32; with the gate-minor layout it is batch-minor-by-4, (T, ceil(B/4), 2, H, 4): the four samples a
+  // lane owns are 16 contiguous bytes (one access in the wave-autonomous kernels instead of four)
+  const __amdgpu_buffer_rsrc_t rc = make_rsrc(D.cstash, (unsigned)T * (GM ? (unsigned)((B + 3) & ~3) : (unsigned)B) * 2u * H * 4u);
+  const unsigned scc = GM ? (unsigned)((B + 3) >> 2) * 2u * H * 16u : (unsigned)B * 2u * H * 4u;      // its byte stride per time step
   const __amdgpu_buffer_rsrc_t rh = make_rsrc(D.hseq, (unsigned)T * B * 2u * H * 4u);
   const unsigned sg = (unsigned)B * 2u * G4 * 4u, sc = (unsigned)B * 2u * H * 4u;
   unsigned og[4], oc[4], oh[4];
@@ -528,7 +534,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wave_kernel(CLaunch L) {
     const int lv = L.lengths[min(b, B - 1)];
     len_r[r] = inb[r] ? lv : 0;
     og[r] = (((unsigned)b * 2u + dir) * G4 + (gm ? col * 4 : col)) * 4u;
-    oc[r] = (((unsigned)b * 2u + dir) * H + col) * 4u;
+    oc[r] = GM ? ((((((unsigned)b >> 2) * 2u + dir) * H + col) << 2) + ((unsigned)b & 3u)) * 4u : (((unsigned)b * 2u + dir) * H + col) * 4u;
     oh[r] = ((unsigned)b * 2u * H + dir * H + col) * 4u;
   }
   float c_reg[4] = {0.f, 0.f, 0.f, 0.f}, h_reg[4] = {0.f, 0.f, 0.f, 0.f};
@@ -582,10 +588,12 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wave_kernel(CLaunch L) {
           stf(rg, o, sv[r][0]); stf(rg, act ? o + H * 4u : OOB, sv[r][1]); stf(rg, act ? o + 2u * H * 4u : OOB, sv[r][2]);
           stf(rg, act ? o + 3u * H * 4u : OOB, sv[r][3]);
         }
-        stf(rc, act ? oc[r] + (unsigned)t * sc : OOB, sv[r][4]);
+        if (!gm) stf(rc, act ? oc[r] + (unsigned)t * scc : OOB, sv[r][4]);
       }
       stf(rh, inb[r] ? oh[r] + (unsigned)t * sc : OOB, sv[r][5]);     // zero at padded positions (pad_packed_sequence)
     }
+    // batch-minor stash: the lane's four samples in one 16-byte store (rows past their length carry the frozen state: never read)
+    if (gm && !L.no_stash) stf4(rc, inb[0] ? oc[0] + (unsigned)t * scc : OOB, f32x4{sv[0][4], sv[1][4], sv[2][4], sv[3][4]});
     load_pre(Pp, ps + 2);
   };
   bool fast = false;                                    // XCD-local hand-off in force (wave-uniform, same in every wave of the m-tile)
@@ -642,7 +650,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wave_kernel(CLaunch L) {
       c_reg[r] = act ? cn : c_reg[r];
       h_reg[r] = act ? hn : h_reg[r];
       Tr[(fq * 4 + r) * 16 + fr] = f2bf(h_reg[r]);
-      sv[r][0] = gi; sv[r][1] = gf; sv[r][2] = gg; sv[r][3] = go; sv[r][4] = cn; sv[r][5] = act ? hn : 0.f;
+      sv[r][0] = gi; sv[r][1] = gf; sv[r][2] = gg; sv[r][3] = go; sv[r][4] = c_reg[r]; sv[r][5] = act ? hn : 0.f;
     }
     if (step + 1 < T) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the tile is complete in the wave-private LDS block
@@ -733,7 +741,10 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(CLaunch L) {
     for (int i = tid; i < (NC > 1 ? NC - 1 : 1) * GROUP * OW; i += 256) Gb[i] = 0;
   }
   const __amdgpu_buffer_rsrc_t rg = make_rsrc(D.gates, (unsigned)T * B * 2u * G4 * 4u);
-  const __amdgpu_buffer_rsrc_t rc = make_rsrc(D.cstash, (unsigned)T * B * 2u * H * 4u);
+  // cell-state stash: (T,B,2,H) fp32; with the gate-minor layout it is batch-minor-by-4, (T, ceil(B/4), 2, H, 4): the four samples a
+  // lane owns are 16 contiguous bytes (one access in the wave-autonomous kernels instead of four)
+  const __amdgpu_buffer_rsrc_t rc = make_rsrc(D.cstash, (unsigned)T * (GM ? (unsigned)((B + 3) & ~3) : (unsigned)B) * 2u * H * 4u);
+  const unsigned scc = GM ? (unsigned)((B + 3) >> 2) * 2u * H * 16u : (unsigned)B * 2u * H * 4u;      // its byte stride per time step
   const __amdgpu_buffer_rsrc_t rd = make_rsrc(const_cast<float*>(D.d_hseq), D.d_hseq ? (unsigned)T * B * 2u * H * 4u : 0u);
   const __amdgpu_buffer_rsrc_t ru = make_rsrc(D.utt, (unsigned)B * 4u * H * 4u);
   const unsigned sg = (unsigned)B * 2u * G4 * 4u, sc = (unsigned)B * 2u * H * 4u;
@@ -748,7 +759,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(CLaunch L) {
     const int lv = L.lengths[min(b, B - 1)];
     len_r[r] = inb[r] ? lv : 0;
     og[r] = (((unsigned)b * 2u + dir) * G4 + (gm ? col * 4 : col)) * 4u;
-    oc[r] = (((unsigned)b * 2u + dir) * H + col) * 4u;
+    oc[r] = GM ? ((((((unsigned)b >> 2) * 2u + dir) * H + col) << 2) + ((unsigned)b & 3u)) * 4u : (((unsigned)b * 2u + dir) * H + col) * 4u;
     oh[r] = ((unsigned)b * 2u * H + dir * H + col) * 4u;
     d_fin[r] = ldf(ru, inb[r] ? ((unsigned)b * 4u * H + (dir * 2 + D.layer) * H + col) * 4u : OOB);
   }
@@ -788,8 +799,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(CLaunch L) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) S.g[g][r] = ldf(rg, act ? o + g * H * 4u : OOB);
       }
-      S.c[r] = ldf(rc, act ? oc[r] + (unsigned)t * sc : OOB);
-      S.cp[r] = ldf(rc, (act && tp >= 0 && tp < len_r[r]) ? oc[r] + (unsigned)tp * sc : OOB);
+      S.c[r] = ldf(rc, act ? oc[r] + (unsigned)t * scc : OOB);
+      S.cp[r] = ldf(rc, (act && tp >= 0 && tp < len_r[r]) ? oc[r] + (unsigned)tp * scc : OOB);
       S.dh[r] = ldf(rd, act ? oh[r] + (unsigned)t * sc : OOB);          // zero-record descriptor when d_hseq == NULL
     }
   };
@@ -1012,7 +1023,10 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
         wreg[nt][ks2] = nt < nHT ? src[((size_t)(ht * nHT + nt) * 2 + ks2) * 64 + lane] : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
   }
   const __amdgpu_buffer_rsrc_t rg = make_rsrc(D.gates, (unsigned)T * B * 2u * G4 * 4u);
-  const __amdgpu_buffer_rsrc_t rc = make_rsrc(D.cstash, (unsigned)T * B * 2u * H * 4u);
+  // cell-state stash: (T,B,2,H) fp32; with the gate-minor layout it is batch-minor-by-4, (T, ceil(B/4), 2, H, 4): the four samples a
+  // lane owns are 16 contiguous bytes (one access in the wave-autonomous kernels instead of four)
+  const __amdgpu_buffer_rsrc_t rc = make_rsrc(D.cstash, (unsigned)T * (GM ? (unsigned)((B + 3) & ~3) : (unsigned)B) * 2u * H * 4u);
+  const unsigned scc = GM ? (unsigned)((B + 3) >> 2) * 2u * H * 16u : (unsigned)B * 2u * H * 4u;      // its byte stride per time step
   const __amdgpu_buffer_rsrc_t rd = make_rsrc(const_cast<float*>(D.d_hseq), D.d_hseq ? (unsigned)T * B * 2u * H * 4u : 0u);
   const __amdgpu_buffer_rsrc_t ru = make_rsrc(D.utt, (unsigned)B * 4u * H * 4u);
   const unsigned sg = (unsigned)B * 2u * G4 * 4u, sc = (unsigned)B * 2u * H * 4u;
@@ -1027,7 +1041,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
     const int lv = L.lengths[min(b, B - 1)];
     len_r[r] = inb[r] ? lv : 0;
     og[r] = (((unsigned)b * 2u + dir) * G4 + (gm ? col * 4 : col)) * 4u;
-    oc[r] = (((unsigned)b * 2u + dir) * H + col) * 4u;
+    oc[r] = GM ? ((((((unsigned)b >> 2) * 2u + dir) * H + col) << 2) + ((unsigned)b & 3u)) * 4u : (((unsigned)b * 2u + dir) * H + col) * 4u;
     oh[r] = ((unsigned)b * 2u * H + dir * H + col) * 4u;
     d_fin[r] = ldf(ru, inb[r] ? ((unsigned)b * 4u * H + (dir * 2 + D.layer) * H + col) * 4u : OOB);
   }
@@ -1059,8 +1073,13 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
       }
       // the state of the step that follows in this walk (= the previous one in time); derive() hands it on as that step's own
       // state, so every state is read once
-      raw.cp[r] = ldf(rc, (step < T && tp >= 0 && tp < len_r[r]) ? oc[r] + (unsigned)tp * sc : OOB);
+      if (!gm) raw.cp[r] = ldf(rc, (step < T && tp >= 0 && tp < len_r[r]) ? oc[r] + (unsigned)tp * scc : OOB);
       raw.dh[r] = has_dh ? ldf(rd, act ? oh[r] + (unsigned)t * sc : OOB) : 0.f;      // has_dh is workgroup-uniform
+    }
+    if (gm) {            // batch-minor stash: the lane's four samples in one 16-byte load; derive() masks the rows past their length
+      const f32x4 v = ldf4(rc, (step < T && tp >= 0 && tp < T && inb[0]) ? oc[0] + (unsigned)tp * scc : OOB);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) raw.cp[r] = v[r];
     }
   };
   // raw (step `step`) + c_keep -> dv.  With dh the total gradient of h_t and dc the carried one:
@@ -1070,8 +1089,10 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
   // inactive steps of a sample come first in this walk (forward direction, carry still zero) or last (reverse direction).
   auto derive = [&](int step) {
     const int t = dir ? step : T - 1 - step;
+    const int tpd = dir ? t + 1 : t - 1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
+      if (gm) raw.cp[r] = (tpd >= 0 && tpd < len_r[r]) ? raw.cp[r] : 0.f;     // (the scalar form masked its load instead)
       const bool act = step < T && t < len_r[r];
       const bool fin = dir ? (t == 0) : (t == len_r[r] - 1);
       const float gi = raw.g[0][r], gf = raw.g[1][r], gg = raw.g[2][r], go = raw.g[3][r];
@@ -1099,7 +1120,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int t0 = dir ? 0 : T - 1;
-      c_keep[r] = ldf(rc, t0 < len_r[r] ? oc[r] + (unsigned)t0 * sc : OOB);
+      c_keep[r] = ldf(rc, t0 < len_r[r] ? oc[r] + (unsigned)t0 * scc : OOB);
     }
   }
   load_raw(0);

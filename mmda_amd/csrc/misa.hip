@@ -230,7 +230,7 @@ int64_t layout(mmda_misa* m, int B, int T, bool commit) {
     md.x = (i == 0) ? k.take(R * md.D) : -1;
     for (int l = 0; l < 2; ++l) {
       md.gates[l] = k.take(R * 8 * md.H);
-      md.c[l] = k.take(R * 2 * md.H);
+      md.c[l] = k.take((int64_t)T * round_up(B, 4) * 2 * md.H);     // batch-minor-by-4 under the gate-minor layout: rows rounded up
       md.hseq[l] = k.take(R * 2 * md.H);
     }
     md.normed = k.take(R * 2 * md.H);

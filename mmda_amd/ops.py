@@ -326,7 +326,8 @@ def lstm_bidir_fwd(pre, whh_f, whh_r, lengths, *, mode="fp32", layer=0, utt=None
     T, B, _, G4 = pre.shape
     H = G4 // 4
     gates = _to_gate_minor(pre, H) if gate_minor else pre.clone().contiguous()
-    cst = torch.zeros(T, B, 2, H, device=pre.device)
+    # torch layout (T,B,2,H); the gate-minor kernels keep it batch-minor-by-4, (T, ceil(B/4), 2, H, 4): rows rounded up
+    cst = torch.zeros(T, (B + 3) // 4, 2, H, 4, device=pre.device) if gate_minor else torch.zeros(T, B, 2, H, device=pre.device)
     hseq = torch.full((T, B, 2 * H), float("nan"), device=pre.device)
     if utt is None:
         utt = torch.zeros(B, 4 * H, device=pre.device)
