@@ -76,7 +76,8 @@ __global__ void pack_kernel(int H, const float* __restrict__ W, void* outF, void
 struct PackMulti { int H[16]; const float* W[16]; void* F[16]; void* Bk[16]; void* Ck[16]; int start[17]; int n; };
 template <int MODE>
 __global__ void pack_multi_kernel(PackMulti P) {
-  // blockIdx.x -> matrix through the prefix table; each matrix gets ceil(elements/256) blocks
+  // blockIdx.x -> matrix through the prefix table.  One thread per (fragment, lane): it gathers the lane's 8 bf16 (4 fp32) values
+  // and writes them with one 16-byte store; loads are unconditional from clamped addresses (values outside H are zeroed after).
   int i = 0;
 #pragma unroll
   for (int k = 1; k < 16; ++k)
@@ -84,46 +85,65 @@ __global__ void pack_multi_kernel(PackMulti P) {
   const int H = P.H[i];
   const float* __restrict__ W = P.W[i];
   const int Hp = pad16(H), nHT = Hp / 16;
-  const int per = (MODE == MMDA_BF16) ? 8 : 4;
+  constexpr int per = (MODE == MMDA_BF16) ? 8 : 4;
   const int kspan = (MODE == MMDA_BF16) ? 32 : 16;
   const int KS = (MODE == MMDA_BF16) ? pad32(H) / 32 : Hp / 16;
   const int KSB = 4 * Hp / kspan;
-  const int64_t nF = (int64_t)nHT * 4 * KS * 64 * per, nB = (int64_t)nHT * KSB * 64 * per;
-  const int64_t e0 = (int64_t)(blockIdx.x - P.start[i]) * blockDim.x + threadIdx.x;
-  const int64_t nC = (MODE == MMDA_BF16 && P.Ck[i]) ? (int64_t)nHT * nHT * 2 * 64 * 8 : 0;
-  if (e0 >= nF + nB + nC) return;
-  if (e0 >= nF + nB) {
+  const int64_t gF = (int64_t)nHT * 4 * KS * 64, gB = (int64_t)nHT * KSB * 64;        // (fragment, lane) pairs per packing
+  const int64_t gC = (MODE == MMDA_BF16 && P.Ck[i]) ? (int64_t)nHT * nHT * 2 * 64 : 0;
+  const int64_t q0 = (int64_t)(blockIdx.x - P.start[i]) * blockDim.x + threadIdx.x;
+  if (q0 >= gF + gB + gC) return;
+  float v[per];
+  void* dst;
+  int64_t q;
+  if (q0 >= gF + gB) {
     // cluster-backward packing [(ht*nHT + nt)*2 + ks2][lane][8]: k = gate rows of hidden tile ht, n = hidden tile nt
-    const int64_t e = e0 - nF - nB;
-    const int j = e % 8, lane = (e / 8) % 64;
-    const int64_t frag = e / 512;
-    const int ks2 = frag & 1, nt = (frag >> 1) % nHT, ht = (frag >> 1) / nHT;
-    const int kk = ks2 * 32 + 8 * (lane >> 4) + j;
-    const int g = kk >> 4, jl = kk & 15;
-    const int unit = ht * 16 + jl, n = nt * 16 + (lane & 15);
-    float v = (unit < H && n < H) ? W[(int64_t)(g * H + unit) * H + n] : 0.f;
-    reinterpret_cast<unsigned short*>(P.Ck[i])[e] = f2bf(v);
-    return;
-  }
-  const bool bwd = e0 >= nF;
-  void* dst = bwd ? P.Bk[i] : P.F[i];
-  if (!dst) return;                                    // this packing is not wanted
-  const int64_t e = bwd ? e0 - nF : e0;
-  const int j = e % per, lane = (e / per) % 64;
-  const int64_t frag = e / (per * 64);
-  const int koff = (MODE == MMDA_BF16) ? 8 * (lane >> 4) + j : 4 * j + (lane >> 4);
-  float v = 0.f;
-  if (!bwd) {
-    int ks = frag % KS, tg = frag / KS, g = tg & 3, ht = tg >> 2;
-    int n = ht * 16 + (lane & 15), k = ks * kspan + koff;
-    if (n < H && k < H) v = W[(int64_t)(g * H + n) * H + k];
+    q = q0 - gF - gB;
+    dst = P.Ck[i];
+    const int lane = (int)(q % 64);
+    const int64_t frag = q / 64;
+    const int ks2 = (int)(frag & 1), nt = (int)((frag >> 1) % nHT), ht = (int)((frag >> 1) / nHT);
+    const int n = nt * 16 + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < per; ++j) {
+      const int kk = ks2 * 32 + 8 * (lane >> 4) + j;
+      const int g = kk >> 4, unit = ht * 16 + (kk & 15);
+      const float w = W[(int64_t)(g * H + min(unit, H - 1)) * H + min(n, H - 1)];
+      v[j] = (unit < H && n < H) ? w : 0.f;
+    }
   } else {
-    int ks = frag % KSB, ht = frag / KSB, kk = ks * kspan + koff;
-    int g = kk / Hp, jj = kk % Hp, n = ht * 16 + (lane & 15);
-    if (jj < H && n < H) v = W[(int64_t)(g * H + jj) * H + n];
+    const bool bwd = q0 >= gF;
+    dst = bwd ? P.Bk[i] : P.F[i];
+    if (!dst) return;                                  // this packing is not wanted
+    q = bwd ? q0 - gF : q0;
+    const int lane = (int)(q % 64);
+    const int64_t frag = q / 64;
+    const int n16 = lane & 15;
+#pragma unroll
+    for (int j = 0; j < per; ++j) {
+      const int koff = (MODE == MMDA_BF16) ? 8 * (lane >> 4) + j : 4 * j + (lane >> 4);
+      if (!bwd) {
+        const int ks = (int)(frag % KS), tg = (int)(frag / KS), g = tg & 3, ht = tg >> 2;
+        const int n = ht * 16 + n16, k = ks * kspan + koff;
+        const float w = W[(int64_t)(g * H + min(n, H - 1)) * H + min(k, H - 1)];
+        v[j] = (n < H && k < H) ? w : 0.f;
+      } else {
+        const int ks = (int)(frag % KSB), ht = (int)(frag / KSB), kk = ks * kspan + koff;
+        const int g = kk / Hp, jj = kk % Hp, n = ht * 16 + n16;
+        const float w = W[(int64_t)(g * H + min(jj, H - 1)) * H + min(n, H - 1)];
+        v[j] = (jj < H && n < H) ? w : 0.f;
+      }
+    }
   }
-  if (MODE == MMDA_BF16) reinterpret_cast<unsigned short*>(dst)[e] = f2bf(v);
-  else reinterpret_cast<float*>(dst)[e] = v;
+  if (MODE == MMDA_BF16) {
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (unsigned)f2bf(v[2 * j]) | ((unsigned)f2bf(v[2 * j + 1]) << 16);
+    reinterpret_cast<u32x4_t*>(dst)[q] = o;
+  } else {
+    reinterpret_cast<float4*>(dst)[q] = float4{v[0], v[1], v[2], v[3]};
+  }
 }
 
 template <int MODE> __device__ __forceinline__ float sig_(float x) { return MODE == MMDA_BF16 ? sigmoid_fast(x) : sigmoidf_(x); }
@@ -528,8 +548,9 @@ extern "C" int mmda_lstm_pack_whh_multi(int mode, int n, const int* H, const flo
     P.H[i] = H[i]; P.W[i] = whh[i]; P.F[i] = packed_fwd[i]; P.Bk[i] = packed_bwd[i];
     P.Ck[i] = (packed_c && mode == MMDA_BF16) ? packed_c[i] : nullptr;
     P.start[i] = blocks;
-    int64_t total = (mmda_lstm_packed_bytes(mode, H[i], 0) + mmda_lstm_packed_bytes(mode, H[i], 1)) / (mode == MMDA_BF16 ? 2 : 4);
-    if (P.Ck[i]) total += mmda_lstm_packed_bytes(mode, H[i], 2) / 2;
+    // one thread per 16 bytes of packed output
+    int64_t total = (mmda_lstm_packed_bytes(mode, H[i], 0) + mmda_lstm_packed_bytes(mode, H[i], 1)) / 16;
+    if (P.Ck[i]) total += mmda_lstm_packed_bytes(mode, H[i], 2) / 16;
     blocks += (int)((total + 255) / 256);
   }
   for (int i = n; i < 16; ++i) { P.H[i] = P.H[0]; P.W[i] = P.W[0]; P.F[i] = P.F[0]; P.Bk[i] = P.Bk[0]; P.Ck[i] = P.Ck[0]; }
@@ -542,17 +563,16 @@ extern "C" int mmda_lstm_pack_whh_multi(int mode, int n, const int* H, const flo
 }
 
 extern "C" int mmda_lstm_pack_whh_cluster(int H, const float* whh, void* packed_c, void* stream) {
-  // single-matrix form on top of the multi kernel: forward/backward packings go to scratch-free dummies (not written)
+  // single-matrix form on top of the multi kernel: the forward / streaming-backward packings are not wanted (NULL: their threads
+  // exit at once), only the cluster segment is written
   if (!whh || !packed_c || H <= 0 || H > 512) return MMDA_EINVAL;
   PackMulti P;
   P.n = 1;
   for (int i = 0; i < 16; ++i) { P.H[i] = H; P.W[i] = whh; P.F[i] = nullptr; P.Bk[i] = nullptr; P.Ck[i] = packed_c; }
-  // only the cluster segment is launched: blocks cover [nF+nB, nF+nB+nC)
-  int64_t nFB = (mmda_lstm_packed_bytes(MMDA_BF16, H, 0) + mmda_lstm_packed_bytes(MMDA_BF16, H, 1)) / 2;
-  int64_t nC = mmda_lstm_packed_bytes(MMDA_BF16, H, 2) / 2;
-  if (nFB % 256) return MMDA_EINVAL;            // fragment counts are multiples of 512 elements
-  int first = (int)(nFB / 256), blocks = (int)((nC + 255) / 256);
-  P.start[0] = -first;                          // shift so that block 0 lands on the cluster segment
+  const int64_t total = (mmda_lstm_packed_bytes(MMDA_BF16, H, 0) + mmda_lstm_packed_bytes(MMDA_BF16, H, 1) +
+                         mmda_lstm_packed_bytes(MMDA_BF16, H, 2)) / 16;
+  const int blocks = (int)((total + 255) / 256);
+  P.start[0] = 0;
   for (int i = 1; i <= 16; ++i) P.start[i] = blocks;
   hipLaunchKernelGGL(pack_multi_kernel<MMDA_BF16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P);
   MMDA_CHECK_LAUNCH("mmda_lstm_pack_whh_cluster");
