@@ -597,7 +597,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wave_kernel(CLaunch L) {
     load_pre(Pp, ps + 2);
   };
   bool fast = false;                                    // XCD-local hand-off in force (wave-uniform, same in every wave of the m-tile)
-  const unsigned xcc = my_xcc_id();
+  const unsigned xcc = my_xcc_id() ^ ((L.xcd_local == 3 && (ht & 1)) ? 8u : 0u);   // (3: test hook, odd tiles announce a wrong id)
   if (L.xcd_local && lane == 0) xcc_announce(my_flag, L.epoch_base, xcc);
   // P: pre-activations of this step; Pp: the buffer the previous step used (refilled for step + 1 by flush)
   auto do_step = [&](int step, float (&P)[4][4], float (&Pp)[4][4]) {
@@ -1169,7 +1169,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
     }
   };
   bool fast = false;                                    // XCD-local hand-off in force (see xcc_announce)
-  const unsigned xcc = my_xcc_id();
+  const unsigned xcc = my_xcc_id() ^ ((L.xcd_local == 3 && (ht & 1)) ? 8u : 0u);   // (3: test hook, odd tiles announce a wrong id)
   if (L.xcd_local && lane == 0) xcc_announce(my_flag, L.epoch_base, xcc);
   auto do_step = [&](int step) {
     const unsigned epoch = L.epoch_base + (unsigned)step + 1u;

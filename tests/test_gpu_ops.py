@@ -1,12 +1,14 @@
 """Per-kernel parity on a real MI355X: every C-ABI operator against the same op computed by PyTorch on the CPU
 (fp32).  fp32 mode tolerance 1e-4 (north_star), bf16 mode 1e-2, both relative to the tensor's max magnitude."""
 import math
+import os
 
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from oracle import misa_oracle as orc
 
@@ -776,3 +778,45 @@ def test_transpose_f32_multi():
     outs = ops.transpose_f32([m.to(dev()) for m in mats])
     for m, o in zip(mats, outs):
         assert torch.equal(o.cpu(), m.t().contiguous())
+
+
+@pytest.mark.parametrize("xcd_local", ["0", "3"])
+def test_recurrence_hand_off_fallbacks_in_a_fresh_process(xcd_local):
+    """The XCD-local hand-off is taken only after the waves have verified that their cluster shares an XCD.  MMDA_XCD_LOCAL=0 never
+    tries (write-through form throughout); =3 is a test hook that makes the odd hidden tiles announce a wrong XCC id, so every
+    cluster's check fails at step 1 and the kernels must carry on in the write-through form.  Both must reproduce nn.LSTM.
+    (The switch is read once per process, hence the subprocess.)"""
+    import subprocess, sys
+    code = r'''
+import math, sys, torch
+sys.path.insert(0, %r)
+from mmda_amd import ops
+torch.manual_seed(5)
+T, B, H, D = 12, 32, 300, 40
+rnn = torch.nn.LSTM(D, H, bidirectional=True)
+x = torch.randn(T, B, D, requires_grad=True)
+lengths = torch.sort(torch.randint(1, T + 1, (B,)), descending=True).values; lengths[0] = T
+pk = torch.nn.utils.rnn.pack_padded_sequence(x, lengths, enforce_sorted=False)
+out, (hn, _) = rnn(pk)
+pad, _ = torch.nn.utils.rnn.pad_packed_sequence(out, total_length=T)
+d_out = torch.randn(T, B, 2 * H); d_hn = torch.randn(2, B, H)
+(pad * d_out).sum().add((hn * d_hn).sum()).backward()
+d = torch.device("cuda:0")
+wih = torch.cat((rnn.weight_ih_l0, rnn.weight_ih_l0_reverse), 0).detach().to(d)
+b1 = torch.cat((rnn.bias_ih_l0, rnn.bias_ih_l0_reverse), 0).detach().to(d); b2 = torch.cat((rnn.bias_hh_l0, rnn.bias_hh_l0_reverse), 0).detach().to(d)
+pre = ops.gemm(x.detach().reshape(T * B, D).to(d), wih, mode="bf16", bias=b1, bias2=b2).view(T, B, 2, 4 * H)
+fw = ops.lstm_bidir_fwd(pre, rnn.weight_hh_l0.detach().to(d), rnn.weight_hh_l0_reverse.detach().to(d), lengths, mode="bf16", layer=1,
+                        resident=True, gate_minor=True)
+assert not ops.lstm_aborted(fw)
+rel = lambda a, b: float((a.cpu() - b).abs().max() / b.abs().max())
+assert rel(fw["hseq"], pad.detach()) < 1e-2, rel(fw["hseq"], pad.detach())
+d_utt = torch.zeros(B, 4, H); d_utt[:, 1] = d_hn[0]; d_utt[:, 3] = d_hn[1]
+dG = ops.lstm_bidir_bwd(fw, d_utt.view(B, 4 * H).to(d), d_out.to(d), mode="bf16", layer=1).view(T * B, 8 * H)
+assert not ops.lstm_aborted(fw)
+dx = ops.gemm(dG, wih, mode="bf16", transB=False).view(T, B, D)
+assert rel(dx, x.grad) < 3e-2, rel(dx, x.grad)
+print("ok")
+''' % ROOT
+    env = dict(os.environ, MMDA_XCD_LOCAL=xcd_local)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
