@@ -48,12 +48,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    # rehearsal switches (not for measurements): MMDA_BENCH_BACKEND=gloo + MMDA_BENCH_ONE_DEVICE=1 run the N > 1 code path with
+    # every rank on cuda:0 (RCCL refuses two ranks on one device), gradients staged through the host
+    backend = os.environ.get("MMDA_BENCH_BACKEND", "nccl")
+    if os.environ.get("MMDA_BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from mmda_amd import make_config
     from mmda_amd.solver import Solver
@@ -96,7 +104,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
     losses = model.read_losses()
