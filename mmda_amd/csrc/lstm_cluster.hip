@@ -1492,7 +1492,11 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
     // LDS-using workgroup of a concurrent kernel (weight-gradient GEMMs and conversions on the side stream) off the ~110 CUs
     // that host a recurrent wave, and leaves them the other ~145.  (MMDA_LSTM_LDS_KB: ablation.)
     static const int lds_kb = getenv("MMDA_LSTM_LDS_KB") ? atoi(getenv("MMDA_LSTM_LDS_KB")) : 160;
-    const size_t lds_launch = fwd_wave ? (wpb == 1 ? (size_t)(lds_kb < 8 ? 8 : lds_kb > 160 ? 160 : lds_kb) * 1024 : (size_t)4 * 2048) : lds;
+    // Only while the launch leaves a good part of the chip free (<= 160 blocks): every block then needs a CU of its own, and the
+    // members of a cluster must all be resident at once -- a launch that wants most of the 256 CUs keeps the small allocation, so
+    // that its blocks can share CUs if something else (another process on the GPU) holds some.
+    const bool reserve = wpb == 1 && grid_blocks <= 160;
+    const size_t lds_launch = fwd_wave ? (reserve ? (size_t)(lds_kb < 8 ? 8 : lds_kb > 160 ? 160 : lds_kb) * 1024 : (size_t)4 * 2048) : lds;
     dim3 grid(grid_blocks), block(fwd_wave ? 64 * wpb : 256);
 #define LAUNCH_C()                                                                                               \
   do {                                                                                                           \
