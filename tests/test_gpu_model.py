@@ -392,3 +392,40 @@ def test_wide_text_encoder_takes_the_barrier_form_kernels():
         g = p.grad.cpu().double(); ref = G[k].double()
         l2 = float((g - ref).norm() / ref.norm().clamp_min(1e-30))
         assert l2 <= 1e-1, f"{k}: relative L2 error {l2:.3e}"
+
+
+@pytest.mark.parametrize("B,T,precision", [(1, 1, "fp32"), (3, 2, "fp32"), (1, 5, "bf16"), (8, 1, "bf16"), (17, 3, "bf16")])
+def test_degenerate_shapes_against_the_oracle(B, T, precision):
+    """Smallest shapes the reference accepts (one sample, one time step, odd batches that leave the MFMA tiles mostly empty and
+    keep the bf16 path off its gate-minor / resident fast forms): outputs, losses and gradients against the oracle."""
+    cfg = orc.default_config(vocab_size=40, use_confidNet=True)
+    model, c, P = make_model(cfg, 3, precision)
+    batch = orc.synth_batch(cfg, B, T, 11, ragged=True)
+    b = to_dev(batch)
+    model.train_step(b["t"], b["v"], b["a"], b["l"], b["emo"], lr=cfg.learning_rate, clip=cfg.clip, do_adam=False, training=False)
+    assert not model.cluster_aborted()
+    o, L, G = orc.loss_and_grads(P, cfg, batch)
+    tol = 1e-4 if precision == "fp32" else 1e-2
+    pub = model._public()
+    assert rel(pub["scores"], o.scores.detach()) < tol and rel(pub["tcp"], o.tcp.detach()) < tol
+    Lg = model.read_losses()
+    for k in ("cls", "diff", "sim", "recon", "conf", "total"):
+        ref = float(getattr(L, k).detach())
+        assert abs(Lg[k] - ref) <= tol * abs(ref) + 1e-6, (k, Lg[k], ref)
+    if B == 1:
+        # one sample: CMD's matchnorm is sqrt(0) for every moment and the reference's own gradients are NaN (69 of 99 tensors in the
+        # oracle = torch autograd): there is no gradient to agree with; the forward pass and the losses are what is defined
+        assert any(g is not None and not torch.isfinite(g).all() for g in G.values())
+        return
+    model._assign_grad_views()
+    for k, p in model.named_parameters():
+        if G[k] is None or k.endswith("self_attn.in_proj_bias"):
+            continue
+        g = p.grad.cpu().double(); ref = G[k].double()
+        if float(ref.norm()) < 1e-12:
+            assert float(g.norm()) < 1e-6, k
+            continue
+        l2 = float((g - ref).norm() / ref.norm())
+        # bf16: the quantisation floor of these tiny cases is higher than at full size (rounding only the LSTM weights and the
+        # inputs to bf16 inside the exact oracle moves vrnn1.weight_ih_l0 by 1.34e-1 at B=8,T=1: eight samples, nothing averages out)
+        assert l2 <= (2e-4 if precision == "fp32" else 2e-1), f"{k}: relative L2 error {l2:.3e}"
