@@ -103,12 +103,115 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------------------ head width 64, S = 6
+// The production shape (hidden 128, two heads, six tokens): the head width is the wave width, so lane d keeps column d of every
+// q, k and v row in registers (18 values), a score is one wave reduction, and after the reductions every lane holds the whole
+// 6 x 6 matrix -- softmax, dropout and the context product need no LDS and no barrier.  Same arithmetic order per element and
+// the same dropout indices as the generic kernels above.
+constexpr int S6K = 6;
+
+__global__ __launch_bounds__(64) void attn_fwd_hd64_kernel(const float* __restrict__ qkv, int B, float* ctx, float* probs, float p,
+                                                           uint64_t seed, int site, int nhead) {
+  constexpr int S = S6K, hd = 64;
+  const int E = hd * nhead;
+  const int b = blockIdx.x / nhead, h = blockIdx.x % nhead, d = threadIdx.x;
+  float q[S], k[S], v[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const float* row = qkv + ((int64_t)s * B + b) * 3 * E + h * hd + d;
+    q[s] = row[0]; k[s] = row[E]; v[s] = row[2 * E];
+  }
+  const float scale = 1.0f / sqrtf((float)hd);
+  float pr[S][S];
+#pragma unroll
+  for (int i = 0; i < S; ++i)
+#pragma unroll
+    for (int j = 0; j < S; ++j) pr[i][j] = wave_sum(q[i] * k[j]) * scale;
+#pragma unroll
+  for (int i = 0; i < S; ++i) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < S; ++j) m = fmaxf(m, pr[i][j]);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < S; ++j) { pr[i][j] = expf(pr[i][j] - m); sum += pr[i][j]; }
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      const float pv = pr[i][j] * inv;
+      const int64_t pi = ((int64_t)blockIdx.x * S + i) * S + j;
+      if (d == 0) probs[pi] = pv;                                   // every lane holds the same value
+      pr[i][j] = pv * drop_mul(p, seed, site, (uint64_t)pi);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < S; ++j) acc += pr[s][j] * v[j];
+    ctx[((int64_t)s * B + b) * E + h * hd + d] = acc;
+  }
+}
+
+__global__ __launch_bounds__(64) void attn_bwd_hd64_kernel(const float* __restrict__ qkv, const float* __restrict__ probs,
+                                                           const float* __restrict__ dctx, int B, float* dqkv, float p, uint64_t seed,
+                                                           int site, int nhead) {
+  constexpr int S = S6K, hd = 64;
+  const int E = hd * nhead;
+  const int b = blockIdx.x / nhead, h = blockIdx.x % nhead, d = threadIdx.x;
+  float q[S], k[S], v[S], dc[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const float* row = qkv + ((int64_t)s * B + b) * 3 * E + h * hd + d;
+    q[s] = row[0]; k[s] = row[E]; v[s] = row[2 * E];
+    dc[s] = dctx[((int64_t)s * B + b) * E + h * hd + d];
+  }
+  float P[S][S], Pd[S][S], dS[S][S];
+#pragma unroll
+  for (int i = 0; i < S; ++i)
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      const int64_t pi = (int64_t)blockIdx.x * S * S + i * S + j;
+      const float mul = drop_mul(p, seed, site, (uint64_t)pi);
+      P[i][j] = probs[pi];
+      Pd[i][j] = P[i][j] * mul;
+      dS[i][j] = wave_sum(dc[i] * v[j]) * mul;                      // dP
+    }
+#pragma unroll
+  for (int i = 0; i < S; ++i) {
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < S; ++j) dot += dS[i][j] * P[i][j];
+#pragma unroll
+    for (int j = 0; j < S; ++j) dS[i][j] = P[i][j] * (dS[i][j] - dot);
+  }
+  const float scale = 1.0f / sqrtf((float)hd);
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    float dq = 0.f, dk = 0.f, dv = 0.f;
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      dq += dS[s][j] * k[j];
+      dk += dS[j][s] * q[j];
+      dv += Pd[j][s] * dc[j];
+    }
+    float* row = dqkv + ((int64_t)s * B + b) * 3 * E + h * hd + d;
+    row[0] = dq * scale; row[E] = dk * scale; row[2 * E] = dv;
+  }
+}
+
 }  // namespace
 
 extern "C" int mmda_attn_fwd(const float* qkv, int S, int B, int E, int nhead, float* ctx, float* probs,
                              float drop_p, uint64_t seed, int site, void* stream) {
   if (!qkv || !ctx || !probs || S <= 0 || S > MAXS || B <= 0 || nhead <= 0 || E % nhead) return MMDA_EINVAL;
   int hd = E / nhead;
+  if (hd == 64 && S == S6K) {
+    hipLaunchKernelGGL(attn_fwd_hd64_kernel, dim3(B * nhead), dim3(64), 0, (hipStream_t)stream, qkv, B, ctx, probs, drop_p, seed, site,
+                       nhead);
+    MMDA_CHECK_LAUNCH("mmda_attn_fwd");
+    return MMDA_OK;
+  }
   size_t lds = sizeof(float) * (3 * S * hd + S * S);
   if (lds > 64 * 1024) return MMDA_EINVAL;
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * nhead), dim3(64), lds, (hipStream_t)stream, qkv, S, B, E, nhead, ctx, probs,
@@ -121,6 +224,12 @@ extern "C" int mmda_attn_bwd(const float* qkv, const float* probs, const float* 
                              float* dqkv, float drop_p, uint64_t seed, int site, void* stream) {
   if (!qkv || !probs || !dctx || !dqkv || S <= 0 || S > MAXS || B <= 0 || nhead <= 0 || E % nhead) return MMDA_EINVAL;
   int hd = E / nhead;
+  if (hd == 64 && S == S6K) {
+    hipLaunchKernelGGL(attn_bwd_hd64_kernel, dim3(B * nhead), dim3(64), 0, (hipStream_t)stream, qkv, probs, dctx, B, dqkv, drop_p, seed,
+                       site, nhead);
+    MMDA_CHECK_LAUNCH("mmda_attn_bwd");
+    return MMDA_OK;
+  }
   size_t lds = sizeof(float) * (4 * S * hd + 3 * S * S);
   if (lds > 64 * 1024) return MMDA_EINVAL;
   hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * nhead), dim3(64), lds, (hipStream_t)stream, qkv, probs, dctx, S, B, E, nhead,
