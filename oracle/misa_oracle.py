@@ -257,6 +257,15 @@ def forward(P: Params, cfg, t, v, a, lengths) -> SimpleNamespace:
     utt = {"t": encode_modality(emb, lengths, P, "t", dt, cell),
            "v": encode_modality(v, lengths, P, "v", dv, cell),
            "a": encode_modality(a, lengths, P, "a", da, cell)}
+    return fusion_from_utterances(P, cfg, utt)
+
+
+def fusion_from_utterances(P: Params, cfg, utt) -> SimpleNamespace:
+    """Everything of ``forward`` behind the encoders (models.py:216-249): projections, private/shared, discriminator,
+    reconstruction, the transformer fusion layer and the heads, from the three utterance vectors {"t","v","a"}."""
+    hs = cfg.hidden_size
+    act = _ACTS[cfg.activation]
+    o = SimpleNamespace()
     o.utterance_t, o.utterance_v, o.utterance_a = utt["t"], utt["v"], utt["a"]
     priv_names = {"t": "private_t.private_t_1", "v": "private_v.private_v_1", "a": "private_a.private_a_3"}
     for m in "tva":

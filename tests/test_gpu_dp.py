@@ -146,7 +146,13 @@ def test_two_rank_overlapped_reduction_gives_the_summed_gradients(precision):
         assert p.exitcode == 0
     cfg = orc.default_config(vocab_size=120)
     P = orc.synth_params(cfg, 21)
-    grads = [orc.loss_and_grads(P, cfg, orc.synth_batch(cfg, 8, 9, 40 + r, ragged=True))[2] for r in range(world)]
+    if precision == "bf16":
+        # the bf16-emulating oracle (same rounding points as the kernels, oracle/bf16_emul.py): north_star's 1e-2 on every gradient
+        from oracle import bf16_emul as emu
+        grads = [emu.loss_and_grads(P, cfg, orc.synth_batch(cfg, 8, 9, 40 + r, ragged=True), rounding=True, tile_partials=True)[2]
+                 for r in range(world)]
+    else:
+        grads = [orc.loss_and_grads(P, cfg, orc.synth_batch(cfg, 8, 9, 40 + r, ragged=True))[2] for r in range(world)]
     for it in range(2):
         early, scale, G0 = res[0][it]
         _, _, G1 = res[1][it]
@@ -168,4 +174,4 @@ def test_two_rank_overlapped_reduction_gives_the_summed_gradients(precision):
             if nr == 0:
                 continue
             err = np.linalg.norm(got - ref) / nr
-            assert err < (2e-4 if precision == "fp32" else 1.5e-1), (k, err, "early" if off < early else "late")
+            assert err < (2e-4 if precision == "fp32" else 1e-2), (k, err, "early" if off < early else "late")

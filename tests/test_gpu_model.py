@@ -164,22 +164,62 @@ def test_fp32_fused_step_matches_golden(name):
             assert np.abs(upd).max() == 0.0, k
 
 
-@pytest.mark.parametrize("name", ["real_b8_t12_ragged", "real_b32_t50_full", "real_b16_t20_adv_confid", "real_gru_b8_t12_ragged",
-                                  "real_gru_b16_t20_adv"])
+BF16_CASES = ["real_b8_t12_ragged", "real_b32_t50_full", "real_b16_t20_adv_confid", "real_gru_b8_t12_ragged", "real_gru_b16_t20_adv"]
+
+
+def _grad_rel_l2(model, G, cfg, none=()):
+    """{parameter: relative L2 error of its gradient against G[k]} (key-bias slice of in_proj_bias excluded: see DESIGN section 2)."""
+    out = {}
+    for k, p in model.named_parameters():
+        if k in none or G.get(k) is None:
+            assert float(p.grad.abs().max()) == 0.0, k
+            continue
+        g = p.grad.cpu().double(); ref = G[k].double()
+        if k.endswith("self_attn.in_proj_bias"):
+            hs = cfg.hidden_size
+            keep = torch.ones(3 * hs, dtype=torch.bool); keep[hs:2 * hs] = False
+            g, ref = g[keep], ref[keep]
+        out[k] = (float((g - ref).norm() / ref.norm().clamp_min(1e-30)),
+                  float((g.flatten() @ ref.flatten()) / (g.norm() * ref.norm()).clamp_min(1e-30)))
+    return out
+
+
+@pytest.mark.parametrize("name", BF16_CASES)
 def test_bf16_path_within_1e2(name):
-    """bf16 mode = bf16 MFMA operands (weights, inputs, h, dG rounded to bf16) with fp32 accumulate/state in the LSTM
-    GEMMs and recurrences; the fusion block stays on the exact path.  Against the fp32 oracle on identical inputs:
-      * every output the solver reads (scores, tcp, 12 side-channel tensors): within 1e-2 of the tensor's max magnitude
-      * the six losses: within 1e-2 relative
-      * every gradient: cosine >= 0.995 and relative L2 error <= 1e-1.
-    These gradient figures are the bf16 quantisation floor, not kernel error (the same kernels meet 1e-4 in fp32 mode):
-    tests/test_bf16_floor_cpu.py shows that rounding ONLY the LSTM weights to bf16 inside the exact fp32 oracle already
-    moves these gradients by up to 6e-2 in relative L2 (2x50 steps of BPTT amplify a 2^-9 weight perturbation), so
-    north_star's 1e-2 is reachable for outputs and losses but not for gradients with bf16 weights."""
+    """bf16 mode = bf16 MFMA operands (weights, inputs, h, dG and the per-tile partial dh rounded to bf16) with fp32
+    accumulate / state / stash in the LSTM GEMMs and recurrences; the fusion block stays on the exact path.
+
+    (1) Against the bf16-EMULATING oracle (oracle/bf16_emul.py: the reference's recurrences as explicit fp32 loops that round
+        at exactly the kernels' rounding points, pinned to misa_oracle / the golden gradients by tests/test_bf16_emul_cpu.py):
+        outputs within 1e-3 of the tensor's max magnitude, losses within 1e-4 relative, EVERY gradient within 1e-2 relative L2
+        (north_star's bf16 bound; measured 1.5e-3 .. 5e-3: bf16 rounding flips where the fp32 sums differ in the last bits).
+        Both recurrence implementations: resident weights (per-tile partial sums) and streaming (one fp32 sum).
+    (2) Against the exact fp32 oracle / golden fixture: outputs and losses within 1e-2; the gradient distance is the
+        quantisation floor of bf16 operands (tests/test_bf16_floor_cpu.py), stated here as a loose sanity bound only."""
+    from oracle import bf16_emul as emu
     z, meta, cfg = load_case(name)
     model, c, P = make_model(cfg, meta["seed"], "bf16")
     batch = batch_of(z)
     b = to_dev(batch)
+    none = set(meta["none_grads"])
+    for resident in (True, False):
+        model.set_recurrence(resident)
+        model.train_step(b["t"], b["v"], b["a"], b["l"], b["emo"], lr=cfg.learning_rate, clip=cfg.clip, do_adam=False, training=False)
+        assert not model.cluster_aborted()
+        oq, Lq, Gq = emu.loss_and_grads(P, cfg, batch, rounding=True, tile_partials=resident)
+        pub = model._public()
+        assert rel(pub["scores"], oq.scores) < 1e-3 and rel(pub["tcp"], oq.tcp) < 1e-3
+        for s in SIDE:
+            assert rel(pub[s], getattr(oq, s)) < 1e-3, s
+        L = model.read_losses()
+        for k in ("cls", "diff", "sim", "recon", "conf", "total"):
+            ref = float(getattr(Lq, k).detach())
+            assert abs(L[k] - ref) < 1e-4 * abs(ref) + 1e-7, (k, L[k], ref)
+        model._assign_grad_views()
+        for k, (l2, cos) in _grad_rel_l2(model, Gq, cfg, none).items():
+            assert l2 <= 1e-2, f"{k} (resident={resident}): relative L2 error vs the bf16-emulating oracle {l2:.3e}"
+    # (2) the fp32 oracle / golden fixture
+    model.set_recurrence(True)
     model.train_step(b["t"], b["v"], b["a"], b["l"], b["emo"], lr=cfg.learning_rate, clip=cfg.clip, do_adam=False, training=False)
     pub = model._public()
     assert rel(pub["scores"], z["out::scores"]) < 1e-2
@@ -187,33 +227,13 @@ def test_bf16_path_within_1e2(name):
     for s in SIDE:
         assert rel(pub[s], z["out::" + s]) < 1e-2, s
     L = model.read_losses()
-    assert not model.cluster_aborted()
     for k in ("cls", "diff", "sim", "recon", "conf", "total"):
         assert abs(L[k] - float(z["loss::" + k])) < 1e-2 * abs(float(z["loss::" + k])), k
-    model._assign_grad_views()
-    # the two bf16 recurrence implementations (LDS-resident cluster vs L2-streaming) agree to rounding
-    g_res = model.flat_buckets()[1].clone()
-    model.set_recurrence(False)
-    model.train_step(b["t"], b["v"], b["a"], b["l"], b["emo"], lr=cfg.learning_rate, clip=cfg.clip, do_adam=False, training=False)
-    g_str = model.flat_buckets()[1]
-    assert float((g_res - g_str).norm() / g_str.norm()) < 2e-2
-    model.set_recurrence(True)
-    model.train_step(b["t"], b["v"], b["a"], b["l"], b["emo"], lr=cfg.learning_rate, clip=cfg.clip, do_adam=False, training=False)
     _, _, G = orc.loss_and_grads(P, cfg, batch)
-    none = set(meta["none_grads"])
-    for k, p in model.named_parameters():
-        if k in none:
-            assert float(p.grad.abs().max()) == 0.0
-            continue
-        g = p.grad.cpu().double(); ref = G[k].double()
-        if k.endswith("self_attn.in_proj_bias"):
-            hs = cfg.hidden_size
-            keep = torch.ones(3 * hs, dtype=torch.bool); keep[hs:2 * hs] = False
-            g, ref = g[keep], ref[keep]
-        l2 = float((g - ref).norm() / ref.norm().clamp_min(1e-30))
-        cos = float((g.flatten() @ ref.flatten()) / (g.norm() * ref.norm()).clamp_min(1e-30))
-        # GRU fixtures: the weight-rounding floor itself is 1.0e-1 (tests/test_bf16_floor_cpu.py)
-        assert l2 <= (1.5e-1 if "gru" in name else 1e-1), f"{k}: relative L2 error {l2:.3e}"
+    model._assign_grad_views()
+    for k, (l2, cos) in _grad_rel_l2(model, G, cfg, none).items():
+        # quantisation floor (GRU fixtures: 1.0e-1, tests/test_bf16_floor_cpu.py)
+        assert l2 <= (1.5e-1 if "gru" in name else 1e-1), f"{k}: relative L2 error vs fp32 {l2:.3e}"
         assert cos >= (0.985 if "gru" in name else 0.995), f"{k}: cosine {cos:.6f}"
 
 
