@@ -342,6 +342,10 @@ int mmda_loss_domain(const float* dom, int B, float scale, float* loss, float* d
 int mmda_clamp_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                     float eps, float clip, float grad_scale, int step, void* stream);
 int mmda_clamp(float* g, int64_t n, float clip, void* stream);
+/* clip_grad_value_(clip) + torch.optim.RMSprop with torch's defaults besides lr (alpha 0.99, eps 1e-8, no momentum, not centered):
+ * the other entry of the reference's optimizer_dict (config.py:24).  grad_scale as in mmda_clamp_adam. */
+int mmda_clamp_rmsprop(float* p, const float* g, float* square_avg, int64_t n, float lr, float alpha, float eps, float clip,
+                       float grad_scale, void* stream);
 
 /* ============================================================================================== whole-model API
  * The reference's per-batch loop body (solver.py:139-186) as five calls.  `mmda_misa` is the native runtime object
@@ -373,9 +377,14 @@ int64_t mmda_misa_dense_floats(const mmda_misa* m);   /* non-embedding prefix */
 int mmda_misa_bind(mmda_misa* m, float* params, float* grads, float* adam_m, float* adam_v);
 int64_t mmda_misa_workspace_floats(const mmda_misa* m, int B, int T);
 int mmda_misa_set_workspace(mmda_misa* m, float* ws, int64_t floats, int B, int T);
+/* The same with the (rare) clears enqueued on `stream`.  The exchange buffers of the recurrences sit at the front of the workspace at
+ * offsets that depend on B alone and are cleared only when the buffer or B changes, so a new T per batch (the reference's collate pads
+ * to the batch maximum, data_loader.py:70-72) costs no device work; abort words found before a clear stay visible through
+ * mmda_misa_cluster_status.  Before handing over a NEW buffer read mmda_misa_cluster_status yourself: the old one is not touched. */
+int mmda_misa_set_workspace_async(mmda_misa* m, float* ws, int64_t floats, int B, int T, void* stream);
 /* offset (in floats, inside the workspace) of a named activation / activation-gradient, -1 if unknown. Names:
  *   scores labels tcp logits hfused x6 orig recon dom utt_t utt_v utt_a losses
- *   d_scores d_tcp d_x6 d_orig d_recon d_dom
+ *   d_scores d_tcp d_x6 d_orig d_recon d_dom   xchg_t xchg_v xchg_a (exchange buffers; word 0 of each = its sticky abort word)
  * x6 = [private_t, private_v, private_a, shared_t, shared_v, shared_a] each (B,hidden); orig/recon = (3,B,hidden);
  * losses = float[8]: cls, diff, sim, recon, conf, total */
 int64_t mmda_misa_tensor_offset(const mmda_misa* m, const char* name);

@@ -151,6 +151,7 @@ SIGNATURES = {
     "mmda_loss_domain": (_I, [_P, _I, _F, _P, _P, _P]),
     "mmda_clamp_adam": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _I, _P]),
     "mmda_clamp": (_I, [_P, _I64, _F, _P]),
+    "mmda_clamp_rmsprop": (_I, [_P, _P, _P, _I64, _F, _F, _F, _F, _F, _P]),
     "mmda_misa_create": (_I, [C.POINTER(MisaConfig), C.POINTER(C.c_void_p)]),
     "mmda_misa_destroy": (None, [_P]),
     "mmda_misa_num_params": (_I, [_P]),
@@ -160,6 +161,7 @@ SIGNATURES = {
     "mmda_misa_bind": (_I, [_P, _P, _P, _P, _P]),
     "mmda_misa_workspace_floats": (_I64, [_P, _I, _I]),
     "mmda_misa_set_workspace": (_I, [_P, _P, _I64, _I, _I]),
+    "mmda_misa_set_workspace_async": (_I, [_P, _P, _I64, _I, _I, _P]),
     "mmda_misa_tensor_offset": (_I64, [_P, C.c_char_p]),
     "mmda_misa_set_mode": (_I, [_P, _I]),
     "mmda_misa_set_overlap": (_I, [_P, _I]),

@@ -83,6 +83,10 @@ struct mmda_misa {
   // stream as soon as those exist, beside the transformer layer and the heads; mmda_misa_losses() then adds the rest
   int eager_losses = 0, eager_done = 0;
   int ldR = 0;
+  // cluster-exchange regions: at the front of the workspace, sized by B alone, so a change of T (every batch under the reference's
+  // collate) neither moves nor clears them -- flags are monotonic epochs.  Cleared (on the caller's stream) only when the buffer
+  // or B changes; the abort words found there before a clear are kept in `abort_sticky`.
+  float* xchg_ws = nullptr; int xchg_B = 0; int abort_sticky = 0;
   std::vector<hipEvent_t> ev;      // [step][slot][start/stop]
   int ev_steps = 0, ev_fwd = 0, ev_bwd = 0;
   int ev_stride = 1, ev_seen_f = 0, ev_seen_b = 0;   // record every ev_stride-th step (the event pairs cost ~35 us per step)
@@ -199,6 +203,11 @@ int64_t layout(mmda_misa* m, int B, int T, bool commit) {
   mmda_misa tmp_store;               // only used to keep the code path identical in dry runs
   mmda_misa* o = commit ? m : &tmp_store;
   if (!commit) { o->cfg = m->cfg; for (int i = 0; i < 3; ++i) o->mod[i] = m->mod[i]; }
+  for (int i = 0; i < 3; ++i) {       // exchange buffers of the recurrences first: their offsets depend on B only
+    Mod& md = o->mod[i];
+    md.xchg_floats = (mmda_lstm_xchg_bytes(md.H, B) + 3) / 4;
+    md.xchg = md.xchg_floats > 0 ? k.take(md.xchg_floats) : -1;
+  }
   for (int i = 0; i < 3; ++i) {
     Mod& md = o->mod[i];
     for (int l = 0; l < 2; ++l) {
@@ -225,8 +234,6 @@ int64_t layout(mmda_misa* m, int B, int T, bool commit) {
         r.pb_ih = k.take(8 * r.H); r.pb_hh = k.take(8 * r.H);
       }
     }
-    md.xchg_floats = (mmda_lstm_xchg_bytes(md.H, B) + 3) / 4;
-    md.xchg = md.xchg_floats > 0 ? k.take(md.xchg_floats) : -1;
     md.x = (i == 0) ? k.take(R * md.D) : -1;
     for (int l = 0; l < 2; ++l) {
       md.gates[l] = k.take(R * 8 * md.H);
@@ -291,6 +298,7 @@ int64_t layout(mmda_misa* m, int B, int T, bool commit) {
     t["pub_begin"] = pub_begin; t["pub_end"] = pub_end; t["zero_begin"] = m->zero_begin; t["zero_end"] = m->zero_end;
     t["hseq1_t"] = m->mod[0].hseq[0]; t["hseq1_v"] = m->mod[1].hseq[0]; t["hseq1_a"] = m->mod[2].hseq[0];
     t["d_x_t"] = m->mod[0].d_x;      // gradient w.r.t. the gathered embedding rows (T*B, d_t): the sparse form of embed.weight.grad
+    t["xchg_t"] = m->mod[0].xchg; t["xchg_v"] = m->mod[1].xchg; t["xchg_a"] = m->mod[2].xchg;   // word 0 of each = its abort word
   }
   return k.cur;
 }
@@ -496,18 +504,43 @@ extern "C" int64_t mmda_misa_workspace_floats(const mmda_misa* m, int B, int T) 
   if (!m || B <= 0 || T <= 0) return MMDA_EINVAL;
   return layout(const_cast<mmda_misa*>(m), B, T, false);
 }
-extern "C" int mmda_misa_set_workspace(mmda_misa* m, float* ws, int64_t floats, int B, int T) {
+namespace {
+// abort words of the CURRENT exchange regions -> abort_sticky (synchronous device->host copies)
+int harvest_abort(mmda_misa* m) {
+  if (!m->ws || !m->xchg_ws || m->xchg_ws != m->ws) return MMDA_OK;
+  for (int i = 0; i < 3; ++i) {
+    if (m->mod[i].xchg < 0) continue;
+    unsigned w = 0;
+    if (hipMemcpy(&w, m->ws + m->mod[i].xchg, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) return MMDA_ELAUNCH;
+    if (w) m->abort_sticky = 1;
+  }
+  return MMDA_OK;
+}
+}  // namespace
+
+extern "C" int mmda_misa_set_workspace_async(mmda_misa* m, float* ws, int64_t floats, int B, int T, void* stream) {
   if (!m || !ws || B <= 0 || T <= 0 || ((uintptr_t)ws & 15)) return MMDA_EINVAL;
   int64_t need = layout(m, B, T, false);
   if (floats < need) return MMDA_EINVAL;
+  // The exchange regions keep their place and their contents while the buffer and B stay the same (a new T only): nothing to clear,
+  // the flags there are monotonic epochs.  Otherwise they start from zero -- after the abort words of the old ones were looked at
+  // (same buffer, new B: one synchronous read per region, rare; a NEW buffer: the caller reads mmda_misa_cluster_status first).
+  const bool keep = m->xchg_ws == ws && m->xchg_B == B;
+  if (!keep && m->xchg_ws == ws) { int rc = harvest_abort(m); if (rc) return rc; }
   layout(m, B, T, true);
   m->ws = ws; m->ws_floats = floats; m->B = B; m->T = T; m->ldR = round_up(B * T, 8);
-  // cluster-exchange flags must start at zero (setup time, not on the step path)
-  for (int i = 0; i < 3; ++i)
-    if (m->mod[i].xchg >= 0 && hipMemset(ws + m->mod[i].xchg, 0, sizeof(float) * m->mod[i].xchg_floats) != hipSuccess) return MMDA_ELAUNCH;
-  if (m->gpad_end > m->gpad_begin && hipMemset(ws + m->gpad_begin, 0, sizeof(float) * (m->gpad_end - m->gpad_begin)) != hipSuccess)
+  hipStream_t s = (hipStream_t)stream;
+  if (!keep) {
+    for (int i = 0; i < 3; ++i)
+      if (m->mod[i].xchg >= 0 && hipMemsetAsync(ws + m->mod[i].xchg, 0, sizeof(float) * m->mod[i].xchg_floats, s) != hipSuccess) return MMDA_ELAUNCH;
+    m->xchg_ws = ws; m->xchg_B = B;
+  }
+  if (m->gpad_end > m->gpad_begin && hipMemsetAsync(ws + m->gpad_begin, 0, sizeof(float) * (m->gpad_end - m->gpad_begin), s) != hipSuccess)
     return MMDA_ELAUNCH;
   return MMDA_OK;
+}
+extern "C" int mmda_misa_set_workspace(mmda_misa* m, float* ws, int64_t floats, int B, int T) {
+  return mmda_misa_set_workspace_async(m, ws, floats, B, T, nullptr);       // the null stream: ordered against every blocking stream
 }
 extern "C" int64_t mmda_misa_tensor_offset(const mmda_misa* m, const char* name) {
   if (!m || !name) return -1;
@@ -550,7 +583,7 @@ extern "C" int mmda_misa_set_inference(mmda_misa* m, int forward_only) {
 extern "C" int mmda_misa_cluster_status(const mmda_misa* m, int* aborted_host) {
   // reads the sticky abort words of the three exchange buffers (device->host copy: call it off the step path)
   if (!m || !m->ws || !aborted_host) return MMDA_EINVAL;
-  *aborted_host = 0;
+  *aborted_host = m->abort_sticky;          // seen in an exchange region that has since been cleared (B changed)
   for (int i = 0; i < 3; ++i) {
     if (m->mod[i].xchg < 0) continue;
     unsigned w = 0;

@@ -37,6 +37,19 @@ __global__ __launch_bounds__(256) void clamp_adam_kernel(float* p, const float* 
     adam1(p[i], g[i], m[i], v[i], b1, b2, eps, clip, gscale, step_size, inv_bc2_sqrt);
 }
 
+// clip_grad_value_ + torch.optim.RMSprop (alpha, eps; no momentum, not centered, no weight decay: the reference constructs its
+// optimizer as config.optimizer(params, lr=...), solver.py:97-99, so every other argument is torch's default)
+__global__ __launch_bounds__(256) void clamp_rmsprop_kernel(float* p, const float* __restrict__ g, float* sq, int64_t n, float lr,
+                                                            float alpha, float eps, float clip, float gscale) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float gg = fminf(fmaxf(g[i] * gscale, -clip), clip);
+    const float s = alpha * sq[i] + (1.0f - alpha) * gg * gg;
+    sq[i] = s;
+    p[i] -= lr * gg / (sqrtf(s) + eps);
+  }
+}
+
 __global__ void clamp_kernel(float* g, int64_t n, float clip) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     g[i] = fminf(fmaxf(g[i], -clip), clip);
@@ -69,5 +82,17 @@ extern "C" int mmda_clamp(float* g, int64_t n, float clip, void* stream) {
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(clamp_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, g, n, clip);
   MMDA_CHECK_LAUNCH("mmda_clamp");
+  return MMDA_OK;
+}
+
+extern "C" int mmda_clamp_rmsprop(float* p, const float* g, float* square_avg, int64_t n, float lr, float alpha, float eps, float clip,
+                                  float grad_scale, void* stream) {
+  if (!p || !g || !square_avg || n < 0) return MMDA_EINVAL;
+  if (n == 0) return MMDA_OK;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(clamp_rmsprop_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, square_avg, n, lr, alpha, eps, clip,
+                     grad_scale);
+  MMDA_CHECK_LAUNCH("mmda_clamp_rmsprop");
   return MMDA_OK;
 }

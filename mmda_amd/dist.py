@@ -120,18 +120,16 @@ class DataParallelSync:
             # last kernel that writes its first `early` floats (fusion block, LayerNorms, layer-2 recurrent layers).  That part
             # is reduced on a stream of its own as soon as the event fires -- beside the layer-1 backward recurrence, which
             # leaves more than half of the CUs idle -- and the rest (layer 1, embedding) after the step's last kernel.
+            # `early` is a function of the model configuration and the build, identical on every rank; a failure of the event wait
+            # is raised, not handled: a rank that fell back to ONE all-reduce while its peers issue TWO would hang the job or,
+            # worse, sum mismatched ranges.
             cur = torch.cuda.current_stream(flat_grads.device)
-            try:
-                model.wait_early_grads(self._comm)          # before any collective is issued: a failure here is recoverable
-            except Exception:
-                self.overlap = False
-                early = 0
-            if early:
-                with torch.cuda.stream(self._comm):
-                    self._all_reduce(flat_grads[:early])
-                self._all_reduce(flat_grads[early:])
-                cur.wait_stream(self._comm)
-                return 1.0 / self.world
+            model.wait_early_grads(self._comm)
+            with torch.cuda.stream(self._comm):
+                self._all_reduce(flat_grads[:early])
+            self._all_reduce(flat_grads[early:])
+            cur.wait_stream(self._comm)
+            return 1.0 / self.world
         if self.bucket_floats <= 0 or self.bucket_floats >= n:
             self._all_reduce(flat_grads)
         else:

@@ -38,6 +38,23 @@ _PUB = ["scores", "tcp", "utt_t_orig", "utt_v_orig", "utt_a_orig", "utt_private_
         "domain_label_t", "domain_label_v", "domain_label_a"]
 
 
+_SIG_CACHE: Dict[int, bool] = {}
+
+
+def _takes_model(fn) -> bool:
+    """True if ``fn`` accepts a third positional argument (the model)."""
+    import inspect
+    key = id(getattr(fn, "__func__", fn))
+    if key not in _SIG_CACHE:
+        try:
+            ps = list(inspect.signature(fn).parameters.values())
+            npos = sum(p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD) for p in ps)
+            _SIG_CACHE[key] = npos >= 3 or any(p.kind == p.VAR_POSITIONAL for p in ps)
+        except (TypeError, ValueError):
+            _SIG_CACHE[key] = True
+    return _SIG_CACHE[key]
+
+
 class _Bag(nn.Module):
     """Parameter container; exists only to reproduce the reference's dotted state_dict names."""
 
@@ -113,6 +130,7 @@ class MISA(nn.Module):
         self._seed = 0x5EED
         self._anchor = None
         self._last = {}
+        self._abort_seen = False
 
     # ------------------------------------------------------------------ parameters
     def _register(self, dotted: str, shape):
@@ -229,8 +247,13 @@ class MISA(nn.Module):
         if self._ws_shape != (B, T):
             need = self._lib.mmda_misa_workspace_floats(self._h, B, T)
             if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+                if self._ws is not None and self._ws_shape is not None:
+                    # the old buffer's sticky abort words would be lost with it (the native side never touches a buffer it was
+                    # not handed): look at them first.  Buffers only grow, so this synchronous read happens a few times per run.
+                    self._abort_seen = self._abort_seen or self.cluster_aborted()
                 self._ws = torch.zeros(need, dtype=torch.float32, device=dev)
-            _lib.check(self._lib.mmda_misa_set_workspace(self._h, self._ws.data_ptr(), self._ws.numel(), B, T), "set_workspace")
+            _lib.check(self._lib.mmda_misa_set_workspace_async(self._h, self._ws.data_ptr(), self._ws.numel(), B, T, _lib.stream_ptr()),
+                       "set_workspace")
             self._ws_shape = (B, T)
         # lengths arrive on the CPU (reference: l = to_cpu(l), solver.py:149).  Convert on the host, stage through a pinned
         # buffer and copy asynchronously; an unchanged batch (benchmark loops) reuses the device copy.
@@ -355,29 +378,65 @@ class MISA(nn.Module):
     def utt_a(self):
         return self.utt_private_a + self.utt_shared_a
 
+    # sp_discriminator outputs (models.py:234-237): the reference computes them every forward and never reads them (no loss uses
+    # them), so the hot path skips the dead GEMMs; the attributes are materialised on demand on the HIP GEMM.
+    def _sp_disc(self, x):
+        from . import ops
+        w = self.sp_discriminator.sp_discriminator_layer_1.weight
+        b = self.sp_discriminator.sp_discriminator_layer_1.bias
+        return ops.gemm(x.detach().contiguous(), w.detach(), mode="fp32", bias=b.detach())
+
+    @property
+    def shared_or_private_p_t(self):
+        return self._sp_disc(self.utt_private_t)
+
+    @property
+    def shared_or_private_p_v(self):
+        return self._sp_disc(self.utt_private_v)
+
+    @property
+    def shared_or_private_p_a(self):
+        return self._sp_disc(self.utt_private_a)
+
+    @property
+    def shared_or_private_s(self):
+        return self._sp_disc((self.utt_shared_t + self.utt_shared_v + self.utt_shared_a) / 3.0)
+
     # ------------------------------------------------------------------ fused fast path (Solver.train_epoch)
     def train_step(self, sentences, video, acoustic, lengths, emo_label, lr: float, clip: float, do_adam: bool = True,
-                   training: bool = True, seed=None, grad_sync=None):
+                   training: bool = True, seed=None, grad_sync=None, optimizer=None):
         """One reference loop iteration (solver.py:139-186) in native code: zero_grad, forward, six losses, backward,
         clip + Adam.  ``grad_sync(flat_grad_bucket, dense_floats, model)`` is called between backward and Adam for the
         data-parallel all-reduce (mmda_amd/dist.py) and must return the gradient scale (1/world).
+        ``optimizer``: an mmda_amd.optim optimizer attached to this model.  Adam (or None) is stepped by the native fused
+        clamp+Adam with ``lr``; any other (RMSprop, config.py:24) by its own fused kernel after the gradient exchange.
         Losses stay on the device (read them with ``read_losses()``; one sync, not six)."""
+        from . import optim as _optim
         t, v, a, len_dev = self._prepare(sentences, video, acoustic, lengths)
         emo = emo_label.to(device=t.device, dtype=torch.float32).contiguous()
         if seed is None:
             seed = self._next_seed()
-        self._step += 1
+        custom = do_adam and optimizer is not None and not isinstance(optimizer, _optim.Adam)
+        if not custom:
+            self._step += 1                        # (a custom optimizer counts its own steps on the same counter)
         s = _lib.stream_ptr()
-        fused_adam = do_adam and grad_sync is None
+        fused_adam = do_adam and grad_sync is None and not custom
         _lib.check(self._lib.mmda_misa_train_step(self._h, t.data_ptr(), v.data_ptr(), a.data_ptr(), len_dev.data_ptr(),
-                                                  emo.data_ptr(), int(training), seed, int(fused_adam), lr, clip, self._step, s),
+                                                  emo.data_ptr(), int(training), seed, int(fused_adam), lr, clip, max(self._step, 1), s),
                    "mmda_misa_train_step")
         self._fwd_id += 1
         self._last = dict(t=t, v=v, a=a, len_dev=len_dev, emo=emo)
-        if do_adam and grad_sync is not None:
-            try:
+        if custom:
+            scale = 1.0
+            if grad_sync is not None:
+                scale = grad_sync(self._G, self._dense_floats, self) if _takes_model(grad_sync) else grad_sync(self._G, self._dense_floats)
+            optimizer.step(clip_value=clip, grad_scale=float(scale))
+        elif do_adam and grad_sync is not None:
+            # (bucket, dense_floats, model) or a plain (bucket, dense_floats) callable: decided from its signature, once -- never by
+            # retrying after a TypeError, which could come from inside the exchange after a collective was already issued
+            if _takes_model(grad_sync):
                 scale = grad_sync(self._G, self._dense_floats, self)
-            except TypeError:                       # a plain (bucket, dense_floats) callable
+            else:
                 scale = grad_sync(self._G, self._dense_floats)
             _lib.check(self._lib.mmda_misa_adam_step(self._h, lr, clip, float(scale), self._step, s), "adam_step")
 
@@ -425,11 +484,19 @@ class MISA(nn.Module):
         """True if a resident-weights recurrence ever timed out waiting for its cluster (results are invalid after that).
         Synchronous device->host read: call it off the step path."""
         import ctypes
-        if self._ws is None:
-            return False
+        if self._ws is None or self._ws_shape is None:
+            return self._abort_seen
         flag = ctypes.c_int(0)
         _lib.check(self._lib.mmda_misa_cluster_status(self._h, ctypes.byref(flag)), "cluster_status")
-        return bool(flag.value)
+        self._abort_seen = self._abort_seen or bool(flag.value)
+        return self._abort_seen
+
+    def check_cluster(self, where: str = ""):
+        """Raises MMDAError if a recurrence ever gave up waiting for its cluster (every result since then is invalid).
+        One synchronous device->host read: Solver calls it once per epoch / evaluation pass and before saving a checkpoint."""
+        if self.cluster_aborted():
+            raise _lib.MMDAError("a resident-weights recurrence timed out waiting for its workgroup cluster"
+                                 + (f" ({where})" if where else "") + ": results since then are invalid")
 
     def set_recurrence(self, resident_weights: bool):
         """bf16 recurrences: W_hh resident in LDS across a workgroup cluster (default) or streamed from L2 per step."""

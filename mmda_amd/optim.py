@@ -1,8 +1,11 @@
-"""Optimizers.  ``Adam`` keeps torch.optim.Adam's constructor (the reference builds it as
-``config.optimizer(params, lr=...)``, solver.py:97-99) but steps with the fused HIP clamp+Adam kernel.
+"""Optimizers.  ``Adam`` / ``RMSprop`` keep the torch.optim constructors (the reference builds its optimizer as
+``config.optimizer(params, lr=...)`` out of ``optimizer_dict = {'RMSprop', 'Adam'}``, config.py:24, solver.py:97-99) but step
+with the fused HIP clamp+update kernels.
 
 When every parameter is a view into one flat bucket whose gradient/moment buckets are laid out identically (that is
 how mmda_amd.models.MISA allocates them) the whole model is ONE kernel launch; otherwise one launch per tensor.
+``state_dict()`` / ``load_state_dict()`` of an attached optimizer carry the flat moment buckets and the step count, so a
+run can be resumed from ``checkpoints/optim_{name}.std`` (solver.py:220 saves it beside the model).
 """
 from __future__ import annotations
 
@@ -11,34 +14,91 @@ import torch
 from . import _lib
 
 
-class Adam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, clip_value=None):
-        if weight_decay != 0:
-            raise NotImplementedError("the reference never passes weight_decay (config.py:143 is a dead flag)")
-        defaults = dict(lr=lr, betas=betas, eps=eps, clip_value=clip_value)
+class _FlatOptimizer(torch.optim.Optimizer):
+    """Shared plumbing: binding to a MISA model's flat buckets, the step counter, (de)serialisation of the flat state."""
+
+    def __init__(self, params, defaults):
         super().__init__(params, defaults)
         self._model = None
         self._t = 0
 
     def attach(self, model):
-        """Bind to a MISA model so the step is one fused launch over its flat buckets."""
+        """Bind to a MISA model so the step is one fused launch over its flat buckets (and shares the model's step counter
+        with the native fused train step)."""
         self._model = model
         return self
+
+    def _flat(self):
+        m = self._model
+        if m is not None and m._P is not None and m._views_valid():
+            return m
+        return None
+
+    def _next_step(self) -> int:
+        m = self._model
+        if m is not None:
+            m._step += 1
+            self._t = m._step
+        else:
+            self._t += 1
+        return self._t
+
+    # ---- checkpointing (solver.py:220: torch.save(self.optimizer.state_dict(), 'checkpoints/optim_{name}.std'))
+    def _flat_state(self):
+        return {}
+
+    def _load_flat_state(self, st):
+        pass
+
+    def state_dict(self):
+        m = self._flat()
+        if m is None:
+            return super().state_dict()
+        groups = [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]
+        out = {"mmda_flat": True, "step": int(m._step), "param_groups": groups}
+        out.update({k: v.detach().cpu().clone() for k, v in self._flat_state().items()})
+        return out
+
+    def load_state_dict(self, sd):
+        if not (isinstance(sd, dict) and sd.get("mmda_flat")):
+            return super().load_state_dict(sd)
+        m = self._flat()
+        if m is None:
+            raise _lib.MMDAError("load_state_dict of a flat optimizer state needs the optimizer attached to a MISA model on the GPU")
+        for g, saved in zip(self.param_groups, sd["param_groups"]):
+            g.update(saved)
+        m._step = int(sd["step"]); self._t = m._step
+        self._load_flat_state(sd)
+
+
+class Adam(_FlatOptimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, clip_value=None):
+        if weight_decay != 0:
+            raise NotImplementedError("the reference never passes weight_decay (config.py:143 is a dead flag)")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, clip_value=clip_value))
+
+    def _flat_state(self):
+        _, _, M, V = self._model.flat_buckets()
+        return {"exp_avg": M, "exp_avg_sq": V}
+
+    def _load_flat_state(self, sd):
+        _, _, M, V = self._model.flat_buckets()
+        M.copy_(sd["exp_avg"].to(M.device)); V.copy_(sd["exp_avg_sq"].to(V.device))
 
     @torch.no_grad()
     def step(self, closure=None, clip_value=None, grad_scale=1.0):
         lib = _lib.load()
-        self._t += 1
+        t = self._next_step()
         s = _lib.stream_ptr()
         g0 = self.param_groups[0]
         clip = clip_value if clip_value is not None else g0["clip_value"]
         clip = float("inf") if clip is None else float(clip)
         b1, b2 = g0["betas"]
-        m = self._model
-        if m is not None and m._P is not None and m._views_valid():
+        m = self._flat()
+        if m is not None:
             P, G, M, V = m.flat_buckets()
             _lib.check(lib.mmda_clamp_adam(P.data_ptr(), G.data_ptr(), M.data_ptr(), V.data_ptr(), P.numel(), g0["lr"], b1, b2,
-                                           g0["eps"], clip, grad_scale, self._t, s), "mmda_clamp_adam")
+                                           g0["eps"], clip, grad_scale, t, s), "mmda_clamp_adam")
             return None
         for group in self.param_groups:
             for p in group["params"]:
@@ -55,7 +115,59 @@ class Adam(torch.optim.Optimizer):
                 if not ok:
                     raise _lib.MMDAError("parameter storage is not 16-byte aligned/contiguous")
                 _lib.check(lib.mmda_clamp_adam(p.data_ptr(), g.data_ptr(), st["m"].data_ptr(), st["v"].data_ptr(), p.numel(),
-                                               group["lr"], b1, b2, group["eps"], clip, grad_scale, self._t, s), "mmda_clamp_adam")
+                                               group["lr"], b1, b2, group["eps"], clip, grad_scale, t, s), "mmda_clamp_adam")
+        return None
+
+
+class RMSprop(_FlatOptimizer):
+    """torch.optim.RMSprop(params, lr) with torch's defaults (alpha 0.99, eps 1e-8, no momentum, not centered, no weight decay):
+    the form the reference can construct (config.py:24, solver.py:97-99)."""
+
+    def __init__(self, params, lr=1e-2, alpha=0.99, eps=1e-8, weight_decay=0, momentum=0, centered=False, clip_value=None):
+        if weight_decay != 0 or momentum != 0 or centered:
+            raise NotImplementedError("the reference passes lr only (solver.py:97-99)")
+        super().__init__(params, dict(lr=lr, alpha=alpha, eps=eps, clip_value=clip_value))
+        self._sq = None
+
+    def _square_avg(self, like):
+        if self._sq is None or self._sq.shape != like.shape or self._sq.device != like.device:
+            self._sq = torch.zeros_like(like)
+        return self._sq
+
+    def _flat_state(self):
+        return {"square_avg": self._square_avg(self._model.flat_buckets()[0])}
+
+    def _load_flat_state(self, sd):
+        sq = self._square_avg(self._model.flat_buckets()[0])
+        sq.copy_(sd["square_avg"].to(sq.device))
+
+    @torch.no_grad()
+    def step(self, closure=None, clip_value=None, grad_scale=1.0):
+        lib = _lib.load()
+        self._next_step()
+        s = _lib.stream_ptr()
+        g0 = self.param_groups[0]
+        clip = clip_value if clip_value is not None else g0["clip_value"]
+        clip = float("inf") if clip is None else float(clip)
+        m = self._flat()
+        if m is not None:
+            P, G, _, _ = m.flat_buckets()
+            sq = self._square_avg(P)
+            _lib.check(lib.mmda_clamp_rmsprop(P.data_ptr(), G.data_ptr(), sq.data_ptr(), P.numel(), g0["lr"], g0["alpha"], g0["eps"],
+                                              clip, grad_scale, s), "mmda_clamp_rmsprop")
+            return None
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if p.device.type != "cuda":
+                    raise _lib.MMDAError("mmda_amd.optim.RMSprop steps on the GPU only")
+                st = self.state[p]
+                if not st:
+                    st["square_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                g = p.grad.contiguous()
+                _lib.check(lib.mmda_clamp_rmsprop(p.data_ptr(), g.data_ptr(), st["square_avg"].data_ptr(), p.numel(), group["lr"],
+                                                  group["alpha"], group["eps"], clip, grad_scale, s), "mmda_clamp_rmsprop")
         return None
 
 
@@ -71,4 +183,4 @@ def clip_grad_value_(model_or_params, clip_value):
             _lib.check(lib.mmda_clamp(p.grad.data_ptr(), p.grad.numel(), float(clip_value), _lib.stream_ptr()), "mmda_clamp")
 
 
-optimizer_dict = {"Adam": Adam}
+optimizer_dict = {"RMSprop": RMSprop, "Adam": Adam}       # reference config.py:24

@@ -79,11 +79,14 @@ class Solver(object):
             t = to_gpu(t); v = to_gpu(v); a = to_gpu(a); emo_label = to_gpu(emo_label)
             l = to_cpu(l)
             self.model.train_step(t, v, a, l, emo_label, lr=cfg.learning_rate, clip=cfg.clip,
-                                  grad_sync=self.dp.sync if self.dp is not None else None)
+                                  grad_sync=self.dp.sync if self.dp is not None else None,
+                                  optimizer=getattr(self, "optimizer", None))
             L = self.model._ws_view("losses", (8,))
             sums = L.clone() if sums is None else sums + L       # stays on the device; one sync per epoch
             n += 1
         out = (sums / max(n, 1)).tolist() if sums is not None else [0.0] * 8
+        # the read-back above synchronised anyway: a recurrence that gave up on its cluster invalidates the whole epoch
+        self._check_cluster("train_epoch")
         return dict(cls=out[0], diff=out[1], sim=out[2], recon=out[3], conf=out[4], total=out[5])
 
     def train_epoch_unfused(self):
@@ -112,7 +115,12 @@ class Solver(object):
             _optim.clip_grad_value_(self.model, cfg.clip)
             self.optimizer.step()
             train_loss.append(loss.item())
+        self._check_cluster("train_epoch_unfused")
         return dict(total=float(np.mean(train_loss)) if train_loss else 0.0)
+
+    def _check_cluster(self, where):
+        if hasattr(self.model, "check_cluster"):
+            self.model.check_cluster(where)
 
     def train(self):
         cfg = self.train_config
@@ -130,10 +138,13 @@ class Solver(object):
             if valid_loss <= best_valid_loss:
                 best_valid_loss, best_epoch = valid_loss, e
                 print("Found new best model on dev set!")
-                if not os.path.exists("checkpoints"):
-                    os.makedirs("checkpoints")
                 if self.dp is None or self.dp.rank == 0:
+                    os.makedirs("checkpoints", exist_ok=True)
+                    self._check_cluster("before saving the checkpoint")        # never save weights a failed exchange produced
                     torch.save(self.model.state_dict(), f"checkpoints/model_{cfg.name}.std")
+                    torch.save(self.optimizer.state_dict(), f"checkpoints/optim_{cfg.name}.std")     # solver.py:220
+                if self.dp is not None:
+                    torch.distributed.barrier()           # nobody reads the checkpoint before rank 0 has written it
             history.append(dict(epoch=e, train=tr, valid_loss=valid_loss, valid_acc=valid_acc))
         test_loss, acc, _, _ = self.eval(mode="test", to_print=best_epoch >= 0)
         print("=" * 50)
@@ -172,6 +183,7 @@ class Solver(object):
                 y_true.append(emo_label.detach())
         y_true = torch.cat(y_true, 0).cpu().numpy().squeeze() if y_true else np.zeros((0,))
         y_pred = torch.cat(y_pred, 0).cpu().numpy().squeeze() if y_pred else np.zeros((0,))
+        self._check_cluster(f"eval({mode})")
         if acc_dev is not None:
             loss, acc, self.last_eval_metrics = acc_dev.result()
             return loss, acc, y_pred, y_true

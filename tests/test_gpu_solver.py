@@ -1,0 +1,201 @@
+"""GPU: the north_star call surface -- ``Solver(...).build().train_epoch()`` / ``train_epoch_unfused()`` / ``train()`` /
+``eval()`` (reference src/solver.py:60-370, the loop body :138-193 factored out as train_epoch) -- EXECUTED over loaders whose
+batches change shape from step to step, against the oracle's train_step loop on the same batches and weights.  Dropout is off
+on both sides (the oracle has none; CPU and GPU random streams cannot agree): config.dropout = 0 and the transformer layer's
+torch-default 0.1 patched to 0 for the test."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import misa_oracle as orc
+
+DEV = "cuda:0"
+SHAPES = [(6, 9), (4, 12), (6, 5)]          # (B, T) of consecutive batches: T and B both change (workspace re-layout, regrowth)
+
+
+class ListLoader:
+    def __init__(self, batches):
+        self.batches = batches
+        self.dataset = self
+
+    def __iter__(self):
+        return iter(self.batches)
+
+    def __len__(self):
+        return len(self.batches)
+
+
+def _tuple_of(b):
+    B = b["t"].shape[1]
+    z = torch.zeros(B, b["t"].shape[0] + 2, dtype=torch.int64)
+    return (b["t"], b["v"], b["a"], torch.zeros(B), b["emo"], b["l"], z, z, z, [f"s{i}" for i in range(B)])
+
+
+def _solver(monkeypatch, precision="fp32", shapes=SHAPES, seed=50, n_epoch=1, optimizer="Adam", lr=1e-3, name="t"):
+    from mmda_amd import make_config, models
+    from mmda_amd.solver import Solver
+    monkeypatch.setattr(models, "FUSION_DROPOUT", 0.0)
+    cfg = orc.default_config(vocab_size=80, dropout=0.0, learning_rate=lr)
+    c = make_config(precision=precision, device=DEV, n_epoch=n_epoch, optimizer=optimizer, name=name, **vars(cfg))
+    train = [orc.synth_batch(cfg, B, T, seed + i, ragged=True) for i, (B, T) in enumerate(shapes)]
+    dev = [orc.synth_batch(cfg, B, T, seed + 100 + i, ragged=True) for i, (B, T) in enumerate(shapes[:2])]
+    m = models.MISA(c)
+    m.load_state_dict(orc.synth_params(cfg, 9))
+    s = Solver(c, c, c, ListLoader([_tuple_of(b) for b in train]), ListLoader([_tuple_of(b) for b in dev]),
+               ListLoader([_tuple_of(b) for b in dev]), is_train=True, model=m).build()
+    # build() re-initialises weight_hh* with orthogonal_ (solver.py:78-79): the oracle starts from what the model now holds
+    P = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    return s, cfg, P, train, dev
+
+
+def _assert_params_match(model, P_ref, P0, cfg, steps, lr):
+    """Adam normalises every gradient element (the first updates are ~lr * sign), so an element whose gradient is rounding noise
+    may move differently: per tensor a hard bound, a bulk bound and the relative L2 error of the UPDATE (as test_gpu_model)."""
+    for k, p in model.state_dict().items():
+        got, ref, base = p.detach().cpu().numpy(), P_ref[k].numpy(), P0[k].numpy()
+        if k.endswith("self_attn.in_proj_bias"):
+            hs = cfg.hidden_size
+            keep = np.ones(3 * hs, bool); keep[hs:2 * hs] = False
+            got, ref, base = got[keep], ref[keep], base[keep]
+        d = np.abs(got - ref)
+        assert d.max() <= 2 * steps * lr + 1e-7, k
+        assert (d <= 0.01 * steps * lr).mean() >= 0.99, (k, float((d <= 0.01 * steps * lr).mean()))
+        upd_ref = (ref - base).astype(np.float64); upd = (got - base).astype(np.float64)
+        if np.linalg.norm(upd_ref) > 0:
+            assert np.linalg.norm(upd - upd_ref) <= 2e-2 * np.linalg.norm(upd_ref), (k, np.linalg.norm(upd - upd_ref) / np.linalg.norm(upd_ref))
+        else:
+            assert np.abs(upd).max() == 0.0, k
+
+
+@pytest.mark.parametrize("path", ["train_epoch", "train_epoch_unfused"])
+def test_train_epoch_matches_the_oracle_loop(monkeypatch, path):
+    s, cfg, P0, train, _ = _solver(monkeypatch)
+    out = getattr(s, path)()
+    P = {k: v.clone() for k, v in P0.items()}
+    opt = orc.AdamState(P, cfg.learning_rate)
+    losses = []
+    for b in train:
+        _, L, _ = orc.train_step(P, opt, cfg, b)
+        losses.append({k: float(getattr(L, k)) for k in ("cls", "diff", "sim", "recon", "conf", "total")})
+    for k in out:                                  # the fused path returns all six means, the unfused one the total
+        ref = float(np.mean([l[k] for l in losses]))
+        assert abs(out[k] - ref) <= 2e-4 * abs(ref) + 1e-7, (k, out[k], ref)
+    _assert_params_match(s.model, P, P0, cfg, len(train), cfg.learning_rate)
+    assert not s.model.cluster_aborted()
+
+
+def test_train_two_epochs_with_dev_eval_checkpoint_and_test_eval(monkeypatch, tmp_path):
+    """Solver.train() (solver.py:103-307): per epoch train_epoch + eval('dev'), best model + optimizer saved under checkpoints/,
+    final eval('test', to_print=True) reloads the best checkpoint.  The dev losses per epoch and the final weights against the
+    oracle loop; the saved optimizer state resumes to the same weights as the uninterrupted run."""
+    monkeypatch.chdir(tmp_path)
+    s, cfg, P0, train, dev = _solver(monkeypatch, n_epoch=2, name="ckpt")
+    hist = s.train()
+    assert len(hist) == 2
+    P = {k: v.clone() for k, v in P0.items()}
+    opt = orc.AdamState(P, cfg.learning_rate)
+    for e in range(2):
+        for b in train:
+            orc.train_step(P, opt, cfg, b)
+        ref = float(np.mean([float(orc.cls_loss(orc.forward(P, cfg, b["t"], b["v"], b["a"], b["l"]).scores, b["emo"])) for b in dev]))
+        assert abs(hist[e]["valid_loss"] - ref) <= 5e-4 * abs(ref), (e, hist[e]["valid_loss"], ref)
+    assert os.path.exists("checkpoints/model_ckpt.std") and os.path.exists("checkpoints/optim_ckpt.std")
+    # resume: a fresh solver loads model + optimizer state of the best epoch and takes one more epoch; equal to continuing
+    best, best_loss = -1, float("inf")
+    for e, h in enumerate(hist):                   # solver.py:212: `if valid_loss <= best_valid_loss`
+        if h["valid_loss"] <= best_loss:
+            best, best_loss = e, h["valid_loss"]
+    s2, _, _, _, _ = _solver(monkeypatch, n_epoch=1, name="ckpt")
+    s2.model.load_state_dict(torch.load("checkpoints/model_ckpt.std", weights_only=True))
+    s2.model.to(DEV)
+    b0 = train[0]
+    s2.model._prepare(b0["t"].to(DEV), b0["v"].to(DEV), b0["a"].to(DEV), b0["l"])     # materialise the flat buckets
+    s2.optimizer.load_state_dict(torch.load("checkpoints/optim_ckpt.std", weights_only=True))
+    assert s2.model._step == 3 * (best + 1)
+    s2.train_epoch()
+    Pr = {k: v.clone() for k, v in P0.items()}
+    optr = orc.AdamState(Pr, cfg.learning_rate)
+    for e in range(best + 2):
+        for b in train:
+            orc.train_step(Pr, optr, cfg, b)
+    _assert_params_match(s2.model, Pr, P0, cfg, 3 * (best + 2), cfg.learning_rate)
+
+
+def test_rmsprop_from_the_optimizer_dict(monkeypatch):
+    """config.optimizer = 'RMSprop' (reference config.py:24): the fused and the unfused epoch against torch.optim.RMSprop driven by
+    the oracle's gradients."""
+    for path in ("train_epoch", "train_epoch_unfused"):
+        s, cfg, P0, train, _ = _solver(monkeypatch, optimizer="RMSprop", lr=1e-3)
+        getattr(s, path)()
+        P = {k: torch.nn.Parameter(v.clone()) for k, v in P0.items()}
+        topt = torch.optim.RMSprop(list(P.values()), lr=cfg.learning_rate)
+        for b in train:
+            _, _, G = orc.loss_and_grads({k: v.detach() for k, v in P.items()}, cfg, b)
+            for k, p in P.items():
+                p.grad = None if G[k] is None else G[k].clamp(-cfg.clip, cfg.clip)
+            topt.step()
+        # RMSprop's first steps move every element by ~lr/sqrt(1-alpha) = 10 lr: same criteria with that bound
+        _assert_params_match(s.model, {k: v.detach() for k, v in P.items()}, P0, cfg, len(train), 10 * cfg.learning_rate)
+
+
+def test_planted_abort_word_makes_the_solver_raise(monkeypatch, tmp_path):
+    """A recurrence that gives up on its cluster sets a sticky word in the exchange buffer; training must stop, not go on with
+    garbage (and never save it).  The word is planted by hand; it has to survive a re-layout for a new T, a clear of the exchange
+    region for a new B and a regrown workspace."""
+    from mmda_amd import _lib
+    monkeypatch.chdir(tmp_path)
+    s, cfg, P0, train, dev = _solver(monkeypatch, precision="bf16", shapes=[(8, 6), (8, 9), (16, 9), (16, 30)])
+    m = s.model
+    b = train[0]
+    m.train_step(b["t"].to(DEV), b["v"].to(DEV), b["a"].to(DEV), b["l"], b["emo"].to(DEV), lr=1e-4, clip=1.0)
+    assert not m.cluster_aborted()
+    m._ws.view(torch.int32)[m._off("xchg_t")] = 1          # the abort word, as a recurrence would set it
+    with pytest.raises(_lib.MMDAError):
+        s.train_epoch()              # batches of new T, new B and a larger workspace follow: the word stays seen
+    with pytest.raises(_lib.MMDAError):
+        s.eval(mode="dev")
+    with pytest.raises(_lib.MMDAError):
+        s.train()
+    assert not os.path.exists("checkpoints/model_t.std")
+
+
+def test_shape_changes_keep_the_exchange_state(monkeypatch):
+    """bf16 resident-weights path over batches whose T changes every step and whose B changes once: no abort, and the result of
+    the last batch equals the same batch on a fresh model with the same weights (epochs carried across re-layouts are harmless)."""
+    s, cfg, P0, train, _ = _solver(monkeypatch, precision="bf16", shapes=[(8, 6), (8, 11), (8, 4), (16, 7), (8, 6)])
+    m = s.model
+    for b in train:
+        m.train_step(b["t"].to(DEV), b["v"].to(DEV), b["a"].to(DEV), b["l"], b["emo"].to(DEV), lr=0.0, clip=1.0, training=False)
+    assert not m.cluster_aborted()
+    got = m._public()["scores"].clone(); G1 = m.flat_buckets()[1].clone()
+    s2, _, _, _, _ = _solver(monkeypatch, precision="bf16", shapes=[(8, 6)])
+    s2.model.load_state_dict(P0); s2.model.to(DEV)
+    b = train[-1]
+    s2.model.train_step(b["t"].to(DEV), b["v"].to(DEV), b["a"].to(DEV), b["l"], b["emo"].to(DEV), lr=0.0, clip=1.0, training=False)
+    assert float((s2.model._public()["scores"] - got).abs().max()) < 1e-5
+    G2 = s2.model.flat_buckets()[1]
+    assert float((G1 - G2).norm() / G2.norm()) < 1e-3          # float-atomic split-K order only
+
+
+def test_written_but_unread_attributes_are_materialisable():
+    """models.py:234-237, 256-258: shared_or_private_{p_t,p_v,p_a,s} and utt_{t,v,a} exist after a forward (the reference writes
+    them and never reads them; here they are computed on demand) and equal the oracle's Linear(128 -> 4) on the same codes."""
+    from mmda_amd import make_config, MISA
+    cfg = orc.default_config(vocab_size=60)
+    P = orc.synth_params(cfg, 4)
+    m = MISA(make_config(precision="fp32", device=DEV, **vars(cfg))); m.load_state_dict(P); m.to(DEV); m.eval()
+    b = orc.synth_batch(cfg, 5, 7, 2, ragged=True)
+    with torch.no_grad():
+        m(b["t"].to(DEV), b["v"].to(DEV), b["a"].to(DEV), b["l"])
+    o = orc.forward(P, cfg, b["t"], b["v"], b["a"], b["l"])
+    W, bias = P["sp_discriminator.sp_discriminator_layer_1.weight"], P["sp_discriminator.sp_discriminator_layer_1.bias"]
+    for name, x in (("p_t", o.utt_private_t), ("p_v", o.utt_private_v), ("p_a", o.utt_private_a),
+                    ("s", (o.utt_shared_t + o.utt_shared_v + o.utt_shared_a) / 3.0)):
+        got = getattr(m, "shared_or_private_" + name).cpu()
+        assert got.shape == (5, 4)
+        assert float((got - (x @ W.t() + bias)).abs().max()) < 1e-5, name
+    assert float((m.utt_t.cpu() - (o.utt_private_t + o.utt_shared_t)).abs().max()) < 1e-5
