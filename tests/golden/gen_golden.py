@@ -107,7 +107,7 @@ SIDE = ["utt_t_orig", "utt_v_orig", "utt_a_orig", "utt_private_t", "utt_private_
         "utt_shared_t", "utt_shared_v", "utt_shared_a", "utt_t_recon", "utt_v_recon", "utt_a_recon"]
 
 
-def run_case(name, cfg, B, T, seed, ragged, full_tensors, steps=3):
+def run_case(name, cfg, B, T, seed, ragged, full_tensors, steps=3, store_inputs=True):
     if ONLY not in name:
         return
     params = orc.synth_params(cfg, seed)
@@ -116,7 +116,7 @@ def run_case(name, cfg, B, T, seed, ragged, full_tensors, steps=3):
     opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=cfg.learning_rate)
     rec = {}
     meta = dict(name=name, cfg={k: v for k, v in vars(cfg).items()}, B=B, T=T, seed=seed, ragged=ragged,
-                full_tensors=full_tensors, steps=steps, torch=torch.__version__)
+                full_tensors=full_tensors, steps=steps, torch=torch.__version__, store_inputs=store_inputs)
     for step in range(steps):
         batch = orc.synth_batch(cfg, B, T, seed + step, ragged)
         model.zero_grad()
@@ -124,8 +124,12 @@ def run_case(name, cfg, B, T, seed, ragged, full_tensors, steps=3):
         L = losses(model, scores, batch["emo"])
         L["total"].backward()
         if step == 0:
-            for k in ("t", "v", "a", "l", "emo"):
-                rec["in::" + k] = batch[k].numpy()
+            if store_inputs:          # large cases: the test rebuilds the batch from (cfg, B, T, seed) with oracle.synth_batch
+                for k in ("t", "v", "a", "l", "emo"):
+                    rec["in::" + k] = batch[k].numpy()
+            else:
+                rec["insum::v"] = np.float64(batch["v"].double().sum().item())      # guards the regeneration
+                rec["insum::t"] = np.int64(batch["t"].sum().item())
             rec["out::scores"] = scores.detach().numpy()
             rec["out::labels"] = labels.detach().numpy()
             rec["out::tcp"] = model.tcp.detach().numpy()
@@ -180,6 +184,11 @@ def main():
              full_tensors=False, steps=3)
     run_case("real_b16_t20_adv_confid", orc.default_config(use_cmd_sim=False, use_confidNet=True, **real),
              B=16, T=20, seed=6, ragged=True, full_tensors=False)
+    # BASELINE.json configs[3] (seq_len = 500) and the per-GPU batch of configs[2] (B = 256), one step each
+    run_case("real_b32_t500_ragged", orc.default_config(**real), B=32, T=500, seed=10, ragged=True, full_tensors=False, steps=1,
+             store_inputs=False)
+    run_case("real_b256_t6_full", orc.default_config(**real), B=256, T=6, seed=11, ragged=False, full_tensors=False, steps=1,
+             store_inputs=False)
     # config.rnncell != 'lstm' -> nn.GRU encoders (reference models.py:39)
     run_case("tiny_gru_ragged", orc.default_config(rnncell="gru", use_confidNet=True, **tiny), B=5, T=8, seed=7, ragged=True,
              full_tensors=True)

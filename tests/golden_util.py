@@ -33,4 +33,11 @@ def load_case(name):
 
 
 def batch_of(z):
-    return {k: torch.from_numpy(z["in::" + k]) for k in ("t", "v", "a", "l", "emo")}
+    if "in::t" in z.files:
+        return {k: torch.from_numpy(z["in::" + k]) for k in ("t", "v", "a", "l", "emo")}
+    # large cases store no inputs: they are rebuilt from (cfg, B, T, seed) exactly as the generator built them
+    from oracle import misa_oracle as orc
+    meta = json.loads(bytes(z["meta"]).decode())
+    b = orc.synth_batch(SimpleNamespace(**meta["cfg"]), meta["B"], meta["T"], meta["seed"], meta["ragged"])
+    assert float(b["v"].double().sum()) == float(z["insum::v"]) and int(b["t"].sum()) == int(z["insum::t"])
+    return b

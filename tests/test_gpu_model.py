@@ -261,6 +261,100 @@ def test_batch_and_padding_invariance_at_full_size():
     assert all(np.isfinite(v) for v in L.values())
 
 
+def _check_grads_vs_golden_samples(model, z, meta, cfg, tol_max, tol_norm):
+    """Large cases: no oracle run on the test box (its backward takes a minute at T = 500); the reference-produced gradient samples
+    and norms of the fixture are the comparison."""
+    none = set(meta["none_grads"])
+    for k, p in model.named_parameters():
+        g = p.grad
+        if k in none:
+            assert float(g.abs().max()) == 0.0, k
+            continue
+        if k.endswith("self_attn.in_proj_bias"):
+            continue
+        gold = torch.from_numpy(z["gsample::" + k])
+        got = g.cpu().reshape(-1)[torch.from_numpy(sample_idx(g.numel()))]
+        e = float((got - gold).abs().max() / gold.abs().max().clamp_min(1e-12))
+        assert e < tol_max, f"{k}: sampled gradient, max error relative to the sample's max {e:.3e}"
+        n = float(g.double().norm())
+        assert abs(n - float(z["gnorm::" + k])) <= tol_norm * float(z["gnorm::" + k]), (k, n, float(z["gnorm::" + k]))
+
+
+@pytest.mark.parametrize("name", ["real_b256_t6_full", "real_b32_t500_ragged"])
+def test_c3_c4_shapes_fp32_match_the_reference_fixture(name):
+    """BASELINE.json configs[2] (B = 256 per GPU) and configs[3] (T = 500) on reference-generated fixtures: outputs, losses and
+    gradients of the exact path.  T = 500: 1000 recurrent steps of fp32 rounding each way; the bound is 1e-3 there."""
+    z, meta, cfg = load_case(name)
+    model, c, P = make_model(cfg, meta["seed"], "fp32")
+    b = to_dev(batch_of(z))
+    model.train_step(b["t"], b["v"], b["a"], b["l"], b["emo"], lr=cfg.learning_rate, clip=cfg.clip, do_adam=False, training=False)
+    tol = 1e-4 if meta["T"] <= 50 else 1e-3
+    pub = model._public()
+    assert rel(pub["scores"], z["out::scores"]) < tol and rel(pub["tcp"], z["out::tcp"]) < tol
+    for s_ in SIDE:
+        assert rel(pub[s_], z["out::" + s_]) < tol, s_
+    L = model.read_losses()
+    for k in ("cls", "diff", "sim", "recon", "conf", "total"):
+        assert abs(L[k] - float(z["loss::" + k])) < tol * abs(float(z["loss::" + k])) + 1e-7, (k, L[k], float(z["loss::" + k]))
+    model._assign_grad_views()
+    _check_grads_vs_golden_samples(model, z, meta, cfg, tol_max=2 * tol, tol_norm=2 * tol)
+
+
+@pytest.mark.parametrize("name", ["real_b256_t6_full", "real_b32_t500_ragged"])
+def test_c3_c4_shapes_bf16_match_the_emulating_oracle(name):
+    """The same two shapes on the bf16 path (resident-weights recurrences: eight 32-sample groups at B = 256; 500-step chains at
+    T = 500): no cluster abort, outputs and losses within 1e-2 of the reference fixture, every gradient within 1e-2 relative L2 of
+    the bf16-emulating oracle."""
+    from oracle import bf16_emul as emu
+    z, meta, cfg = load_case(name)
+    model, c, P = make_model(cfg, meta["seed"], "bf16")
+    batch = batch_of(z)
+    b = to_dev(batch)
+    model.train_step(b["t"], b["v"], b["a"], b["l"], b["emo"], lr=cfg.learning_rate, clip=cfg.clip, do_adam=False, training=False)
+    assert not model.cluster_aborted()
+    pub = model._public()
+    assert rel(pub["scores"], z["out::scores"]) < 1e-2 and rel(pub["tcp"], z["out::tcp"]) < 1e-2
+    for s_ in SIDE:
+        assert rel(pub[s_], z["out::" + s_]) < 1e-2, s_
+    L = model.read_losses()
+    for k in ("cls", "diff", "sim", "recon", "conf", "total"):
+        assert abs(L[k] - float(z["loss::" + k])) < 1e-2 * abs(float(z["loss::" + k])), k
+    oq, Lq, Gq = emu.loss_and_grads(P, cfg, batch, rounding=True, tile_partials=True)
+    assert rel(pub["scores"], oq.scores) < 1e-3
+    model._assign_grad_views()
+    for k, (l2, cos) in _grad_rel_l2(model, Gq, cfg, set(meta["none_grads"])).items():
+        assert l2 <= 1e-2, f"{k}: relative L2 error vs the bf16-emulating oracle {l2:.3e}"
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_c3_full_size_b256_t50_properties(precision):
+    """configs[2]'s per-GPU step at full size (B = 256, T = 50, MOSEI widths): eight 32-sample groups per recurrent launch.  No
+    oracle at this size; size-independent properties instead: no cluster abort, finite losses and gradients, every sample's
+    scores equal to the scores the same sample gets inside a 32-sample batch (samples are independent in the forward pass),
+    and a second identical step reproduces the first (epochs advance, the exchange images are reused)."""
+    cfg = orc.default_config(vocab_size=2000)
+    model, c, P = make_model(cfg, 91, precision)
+    full = to_dev(orc.synth_batch(cfg, 256, 50, 6, ragged=True))
+    model.train_step(full["t"], full["v"], full["a"], full["l"], full["emo"], lr=0.0, clip=1.0, do_adam=False, training=False)
+    assert not model.cluster_aborted()
+    L1 = model.read_losses()
+    assert all(np.isfinite(v) for v in L1.values()), L1
+    G1 = model.flat_buckets()[1].clone()
+    assert bool(torch.isfinite(G1).all()) and float(G1.abs().max()) > 0
+    s_full = model._public()["scores"].clone()
+    model.train_step(full["t"], full["v"], full["a"], full["l"], full["emo"], lr=0.0, clip=1.0, do_adam=False, training=False)
+    assert rel(model._public()["scores"], s_full) < 1e-5
+    assert float((model.flat_buckets()[1] - G1).norm() / G1.norm()) < (1e-3 if precision == "bf16" else 1e-5)
+    tol = 2e-3 if precision == "bf16" else 1e-5
+    model.eval()
+    with torch.no_grad():
+        for lo in (0, 96, 224):
+            sl = slice(lo, lo + 32)
+            s_sub, _ = model(full["t"][:, sl].contiguous(), full["v"][:, sl].contiguous(), full["a"][:, sl].contiguous(), full["l"][sl])
+            assert rel(s_sub, s_full[sl]) < tol, lo
+    assert not model.cluster_aborted()
+
+
 def test_long_sequence_t500_finite_and_length_semantics():
     """config 4 (T=500): finite losses/gradients, and a sample with len=1 only sees its first step."""
     cfg = orc.default_config(vocab_size=500)
