@@ -1338,7 +1338,7 @@ namespace {
 // The wave-autonomous kernels run when every descriptor's W_hh k-steps fit their register-resident form.  Their blocks hold
 // 1, 2 or 4 waves (one (hidden tile, m-tile) each): the fewest waves per block that still fit one launch, because the waves
 // of a block share the CU's address unit and the per-step memory instructions are what they queue on.
-bool wave_form_ok(int n, const mmda_lstm_desc* descs, bool bwd, int* wpb_out) {
+bool wave_form_ok(int n, const mmda_lstm_desc* descs, bool bwd, int* wpb_out, int ngt = 1) {
   static const int no_wave = getenv("MMDA_LSTM_BARRIER_FWD") ? 1 : 0;        // ablation: the barrier-synchronised forward kernel
   static const int force_wpb = getenv("MMDA_LSTM_WPB") ? atoi(getenv("MMDA_LSTM_WPB")) : 0;
   static const int no_wave_b = getenv("MMDA_LSTM_BARRIER_BWD") ? 1 : 0;      // ablation: the barrier-synchronised backward kernel
@@ -1347,8 +1347,13 @@ bool wave_form_ok(int n, const mmda_lstm_desc* descs, bool bwd, int* wpb_out) {
   auto count_wgs = [&](int w) { int t = 0; for (int i = 0; i < n; ++i) t += 2 * ceil_div(2 * (round_up(descs[i].H, 16) / 16), w); return t; };
   int wpb = 4;
   if (ok) {
+    // ... of ALL ngt batch groups where possible (B = 256: eight groups, 864 waves = 240 four-wave blocks, one wave per SIMD): the
+    // groups are independent chains, and a second launch for the groups that did not fit costs a whole extra walk of the sequence,
+    // where more waves per CU cost a fraction of a step (they queue on the CU's address unit, not on each other's hand-offs).
+    static const int per_group = getenv("MMDA_LSTM_WPB_PER_GROUP") ? 1 : 0;      // ablation: round 1's choice (fit ONE group)
+    const int groups = per_group ? 1 : (ngt < 1 ? 1 : ngt);
     wpb = 1;
-    while (wpb < 4 && count_wgs(wpb) > MAX_WG_PER_LAUNCH) wpb *= 2;
+    while (wpb < 4 && count_wgs(wpb) * groups > MAX_WG_PER_LAUNCH) wpb *= 2;
     if (force_wpb == 1 || force_wpb == 2 || force_wpb == 4) wpb = force_wpb;
     if (count_wgs(wpb) > MAX_WG_PER_LAUNCH) ok = false;
   }
@@ -1414,7 +1419,7 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
   if (!cluster_applicable(n, descs, B, T, bwd, plans, &lds)) return MMDA_OK;
   const int ngt = ceil_div(B, GROUP);
   int wpb = 4;
-  const bool fwd_wave = wave_form_ok(n, descs, bwd, &wpb);   // (named for the forward kernel; selects the wave-autonomous form of either pass)
+  const bool fwd_wave = wave_form_ok(n, descs, bwd, &wpb, ngt);   // (named for the forward kernel; selects the wave-autonomous form of either pass)
   const bool gru = descs[0].cell == MMDA_CELL_GRU;            // cluster_applicable() admitted GRU only together with the wave form
   int members[MAXD];                       // workgroups per cluster
   int wg_per_group = 0;
@@ -1482,9 +1487,9 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
       }
       if (fits) { for (int b = 0; b < 256; ++b) L.blk2role[b] = map[b]; grid_blocks = 8 * max_slots; }
       else { for (int b = 0; b < wg && b < 256; ++b) L.blk2role[b] = (short)b; L.xcd_local = 0; }
-      // only the wave kernels with one wave per block verify the placement (per m-tile) before they rely on it; the barrier-form
-      // kernels' unchecked variant stays an experiment (MMDA_XCD_LOCAL=2)
-      if (!by_mt && xcd_env != 2) L.xcd_local = 0;
+      // only the wave kernels verify the placement (per m-tile: every wave reads the XCC ids of all hidden tiles of its m-tile)
+      // before they rely on it; the barrier-form kernels' unchecked variant stays an experiment (MMDA_XCD_LOCAL=2)
+      if (!fwd_wave && xcd_env != 2) L.xcd_local = 0;
     }
     bool bwd_regs = true;                    // every descriptor's n-tiles fit the register-resident form (<= 10 per wave)
     for (int i = 0; i < n; ++i) bwd_regs = bwd_regs && L.d[i].nHT <= 20;

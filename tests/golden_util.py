@@ -14,10 +14,15 @@ SIDE = ["utt_t_orig", "utt_v_orig", "utt_a_orig", "utt_private_t", "utt_private_
         "utt_shared_t", "utt_shared_v", "utt_shared_a", "utt_t_recon", "utt_v_recon", "utt_a_recon"]
 
 
-def case_names():
-    # the model fixtures of gen_golden.py (eval_metrics.npz belongs to gen_golden_eval.py and has its own tests)
-    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                  if os.path.basename(p) != "eval_metrics.npz")
+LARGE = ("real_b32_t500_ragged", "real_b256_t6_full")     # BASELINE configs[3] / configs[2] shapes: tests of their own
+
+
+def case_names(large=False):
+    # the model fixtures of gen_golden.py (eval_metrics.npz belongs to gen_golden_eval.py and has its own tests); the large cases
+    # (no stored inputs, a CPU oracle backward of a minute at T = 500) only on request
+    names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
+                   if os.path.basename(p) != "eval_metrics.npz")
+    return [n for n in names if large or n not in LARGE]
 
 
 def sample_idx(n):

@@ -10,7 +10,7 @@ from golden_util import SIDE, batch_of, case_names, load_case, sample_idx
 RTOL, ATOL = 2e-5, 2e-6     # fp32 torch-vs-torch; same kernels for LSTM, closed forms elsewhere
 
 
-@pytest.mark.parametrize("name", case_names())
+@pytest.mark.parametrize("name", case_names(large=True))
 def test_oracle_forward_losses_grads(name):
     z, meta, cfg = load_case(name)
     P = orc.synth_params(cfg, meta["seed"])
