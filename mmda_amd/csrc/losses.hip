@@ -572,6 +572,117 @@ __global__ __launch_bounds__(1024) void cmd_fast_kernel(const float* __restrict_
     }
 }
 
+// cmd_fast_kernel for any row count (B = 256 per GPU is BASELINE's data-parallel shape): same 128 columns x 8 row groups and the
+// same reductions, but the elements are re-read in each of the three passes (the inputs are <= 400 KB and sit in L2) instead of
+// being kept in registers.  The serial cmd_kernel took 320 us of the B = 256 step.
+__global__ __launch_bounds__(1024) void cmd_stream_kernel(const float* __restrict__ x, int64_t stride, int B, int D, float scale,
+                                                          float vscale, float* loss, float* dx, PairList pl, int nmom) {
+  extern __shared__ float sm[];
+  float* P1 = sm;                                // [8][3][128]
+  float* P2 = sm + 8 * 3 * 128;                  // [8][3][4][128]
+  float* N2 = P2 + 8 * 3 * 4 * 128;              // [2][16] per-wave partial squared norms
+  const int tid = threadIdx.x, c = tid & 127, rg = tid >> 7;
+  const int cc = min(c, D - 1);
+  const bool c_ok = c < D;
+  const float invB = 1.f / B;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    float s = 0.f;
+    if (t < pl.nt && c_ok)
+      for (int r = rg; r < B; r += 8) s += x[(int64_t)t * stride + (int64_t)r * D + cc];
+    P1[(rg * 3 + t) * 128 + c] = s;
+  }
+  __syncthreads();
+  float mom[3][5];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) s += P1[(g * 3 + t) * 128 + c];
+    mom[t][0] = s * invB;
+  }
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    float q2 = 0.f, q3 = 0.f, q4 = 0.f, q5 = 0.f;
+    if (t < pl.nt && c_ok)
+      for (int r = rg; r < B; r += 8) {
+        const float d = x[(int64_t)t * stride + (int64_t)r * D + cc] - mom[t][0];
+        const float d2 = d * d;
+        q2 += d2; q3 += d2 * d; q4 += d2 * d2; q5 += d2 * d2 * d;
+      }
+    P2[((rg * 3 + t) * 4 + 0) * 128 + c] = q2; P2[((rg * 3 + t) * 4 + 1) * 128 + c] = q3;
+    P2[((rg * 3 + t) * 4 + 2) * 128 + c] = q4; P2[((rg * 3 + t) * 4 + 3) * 128 + c] = q5;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float s = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) s += P2[((g * 3 + t) * 4 + k) * 128 + c];
+      mom[t][k + 1] = s * invB;
+    }
+  float dk[3][5];
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) { a = (pl.a[p] == t) ? mom[t][k] : a; b = (pl.b[p] == t) ? mom[t][k] : b; }
+      dk[p][k] = (p < pl.np && k < nmom && c_ok) ? a - b : 0.f;
+    }
+  if (rg == 0) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const float s = wave_sum(dk[p][k] * dk[p][k]);
+        if ((tid & 63) == 0) N2[(tid >> 6) * 16 + p * 5 + k] = s;
+      }
+  }
+  __syncthreads();
+  float nrm[3][5], total = 0.f;
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      nrm[p][k] = sqrtf(N2[p * 5 + k] + N2[16 + p * 5 + k]);
+      if (p < pl.np && k < nmom) total += nrm[p][k];
+    }
+  if (tid == 0 && loss) atomicAdd(loss, total * vscale);
+  if (!dx) return;
+  float U[3][5];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int k = 0; k < 5; ++k) U[t][k] = 0.f;
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      if (p < pl.np && k < nmom) {                       // uniform
+        const float u = dk[p][k] / nrm[p][k];            // 0/0 -> NaN exactly like sqrt'(0) in the reference
+#pragma unroll
+        for (int t = 0; t < 3; ++t) U[t][k] += (pl.a[p] == t ? u : 0.f) - (pl.b[p] == t ? u : 0.f);
+      }
+    }
+  const float gs = scale * vscale / B;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    if (!(t < pl.nt && c_ok)) continue;
+    for (int r = rg; r < B; r += 8) {
+      const int64_t o = (int64_t)t * stride + (int64_t)r * D + c;
+      const float d = x[o] - mom[t][0];
+      const float d2 = d * d;
+      const float g = U[t][0] + U[t][1] * 2.f * d + U[t][2] * 3.f * (d2 - mom[t][1]) + U[t][3] * 4.f * (d2 * d - mom[t][2]) +
+                      U[t][4] * 5.f * (d2 * d2 - mom[t][3]);
+      dx[o] += gs * g;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ recon (MSE)
 __global__ __launch_bounds__(256) void recon_kernel(const float* __restrict__ rec, const float* __restrict__ orig, int64_t n,
                                                     float inv_n, float scale, float* loss, float* drec, float* dorig) {
@@ -720,10 +831,12 @@ extern "C" int mmda_loss_diff_pairs(const float* x, int64_t stride, int nt, int 
   float* mean = invn + 6 * B;                       // 6*D
   float* K = mean + 6 * D;                          // 6*B*B
   float* Ksum = K + (int64_t)6 * B * B;             // 6*B*B
-  const bool fast = D <= 128 && B <= 64;
+  const bool fast = D <= 128 && B <= 256;            // rows per thread 4 / 8 / 16 / 32 (B <= 32 / 64 / 128 / 256)
   if (fast) {
     if (B <= 32) hipLaunchKernelGGL(diff_prep_fast_kernel<4>, dim3(nt), dim3(1024), 0, s, x, stride, B, D, Ahat, invn, mean);
-    else hipLaunchKernelGGL(diff_prep_fast_kernel<8>, dim3(nt), dim3(1024), 0, s, x, stride, B, D, Ahat, invn, mean);
+    else if (B <= 64) hipLaunchKernelGGL(diff_prep_fast_kernel<8>, dim3(nt), dim3(1024), 0, s, x, stride, B, D, Ahat, invn, mean);
+    else if (B <= 128) hipLaunchKernelGGL(diff_prep_fast_kernel<16>, dim3(nt), dim3(1024), 0, s, x, stride, B, D, Ahat, invn, mean);
+    else hipLaunchKernelGGL(diff_prep_fast_kernel<32>, dim3(nt), dim3(1024), 0, s, x, stride, B, D, Ahat, invn, mean);
   } else {
     hipLaunchKernelGGL(diff_prep_kernel, dim3(nt), dim3(256), 0, s, x, stride, B, D, Ahat, invn, mean);
   }
@@ -771,7 +884,9 @@ extern "C" int mmda_loss_diff_pairs(const float* x, int64_t stride, int nt, int 
   if (rc) return rc;
   if (fast) {
     if (B <= 32) hipLaunchKernelGGL(diff_finish_fast_kernel<4>, dim3(nt), dim3(1024), 0, s, dA, invn, B, D, stride, dx);
-    else hipLaunchKernelGGL(diff_finish_fast_kernel<8>, dim3(nt), dim3(1024), 0, s, dA, invn, B, D, stride, dx);
+    else if (B <= 64) hipLaunchKernelGGL(diff_finish_fast_kernel<8>, dim3(nt), dim3(1024), 0, s, dA, invn, B, D, stride, dx);
+    else if (B <= 128) hipLaunchKernelGGL(diff_finish_fast_kernel<16>, dim3(nt), dim3(1024), 0, s, dA, invn, B, D, stride, dx);
+    else hipLaunchKernelGGL(diff_finish_fast_kernel<32>, dim3(nt), dim3(1024), 0, s, dA, invn, B, D, stride, dx);
   } else {
     hipLaunchKernelGGL(diff_finish_kernel, dim3(nt), dim3(256), 0, s, dA, invn, B, D, stride, dx);
   }
@@ -798,6 +913,13 @@ extern "C" int mmda_loss_cmd_pairs(const float* x, int64_t stride, int nt, int n
     else
       hipLaunchKernelGGL(cmd_fast_kernel<8>, dim3(1), dim3(1024), lds_fast, (hipStream_t)stream, x, stride, B, D, scale, value_scale,
                          loss, dx, pl, n_moments);
+    MMDA_CHECK_LAUNCH("mmda_loss_cmd");
+    return MMDA_OK;
+  }
+  if (nt <= 3 && D <= 128) {
+    const size_t lds_fast = sizeof(float) * (8 * 3 * 128 + 8 * 3 * 4 * 128 + 32);
+    hipLaunchKernelGGL(cmd_stream_kernel, dim3(1), dim3(1024), lds_fast, (hipStream_t)stream, x, stride, B, D, scale, value_scale, loss,
+                       dx, pl, n_moments);
     MMDA_CHECK_LAUNCH("mmda_loss_cmd");
     return MMDA_OK;
   }

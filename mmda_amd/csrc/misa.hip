@@ -353,7 +353,7 @@ void lin_dw(Ctx& c, int mode, int M, int N, int K, const float* dy, const float*
 }
 
 // ---- row-skinny forms (fusion block at B <= SKINNY_MAX_B): see gemm_skinny.hip
-constexpr int SKINNY_MAX_B = 64;
+static const int SKINNY_MAX_B = getenv("MMDA_SKINNY_MAX_B") ? atoi(getenv("MMDA_SKINNY_MAX_B")) : 256;   // (env: tile-shape experiments)
 // y(M,N) = act(x(M,K) W(N,K)^T + b)
 mmda_skinny_args sk_nt(int M, int N, int K, const float* x, int ldx, const float* W, const float* b, float* y, int ldy, int act = 0) {
   mmda_skinny_args g = {};

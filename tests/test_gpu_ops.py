@@ -78,6 +78,31 @@ def test_convert_bf16_plain_transposed_gather_padding():
     assert torch.equal(Tb.cpu()[:, :130], Sb.cpu()[:, :37].t()) and bool((Tb.cpu()[:, 130:] == 0).all())
 
 
+@pytest.mark.parametrize("rows,cols", [(130, 300), (77, 148), (1601, 600), (50, 12), (3, 4), (257, 2400), (64, 64)])
+def test_convert_bf16_16_byte_form(rows, cols):
+    """Shapes that take the 16-byte form of the conversion (16-byte-aligned rows, columns a multiple of 4 / 8): plain, transposed,
+    gathered and bf16-source jobs in one launch, odd row counts, the 4-element padding of a 300-wide plain copy."""
+    from mmda_amd import ops
+    torch.manual_seed(rows * 7 + cols)
+    X = torch.randn(rows, cols)
+    E = torch.randn(40, cols); ids = torch.randint(0, 40, (rows,))
+    c8 = cols // 8 * 8
+    Sb = torch.randn(rows, cols + 8).to(torch.bfloat16).to(dev())          # bf16 source inside a wider (16-byte-aligned) buffer
+    jobs = [(X.to(dev()), None, True, True), (X.to(dev()), None, False, True), (X.to(dev()), None, True, False),
+            (E.to(dev()), ids.to(dev()), True, True)]
+    if c8 >= 8:
+        jobs.append((Sb[:, :c8], None, True, True))
+    outs = ops.convert_bf16(jobs)
+    refs = [X, X, X, E[ids]] + ([Sb.cpu()[:, :c8].float()] if c8 >= 8 else [])
+    for (P, T), src in zip(outs, refs):
+        ref = src.to(torch.bfloat16)
+        r, c = src.shape
+        if P is not None:
+            assert torch.equal(P.cpu()[:, :c], ref) and bool((P.cpu()[:, c:] == 0).all())
+        if T is not None:
+            assert torch.equal(T.cpu()[:, :r], ref.t()) and bool((T.cpu()[:, r:] == 0).all())
+
+
 @pytest.mark.parametrize("M,N,K", [(1600, 2400, 300), (1600, 1200, 300), (128, 128, 64), (33, 70, 35), (7, 12, 768), (1600, 140, 40),
                                    (300, 128, 1600)])
 def test_gemm_bf16_operands_nt_bias(M, N, K):
@@ -668,7 +693,7 @@ def _side(B, D, seed):
     return [torch.sigmoid(torch.randn(B, D)).requires_grad_(True) for _ in range(6)]
 
 
-@pytest.mark.parametrize("B,D", [(32, 128), (5, 16), (70, 128), (41, 100), (64, 128)])
+@pytest.mark.parametrize("B,D", [(32, 128), (5, 16), (70, 128), (41, 100), (64, 128), (130, 128), (256, 128), (300, 128)])
 def test_diff_cmd_recon_losses_and_grads(B, D):
     from types import SimpleNamespace
     from mmda_amd.utils import functions as F
