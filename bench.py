@@ -138,19 +138,35 @@ def main():
     achieved = flops_per_launch / (ms[k] * 1e-3) / 1e12 if ms[k] > 0 else 0.0
     # HBM bytes per launch of that kernel from the PMC counters (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes, see
     # profiles/): only valid for the configuration the profile was taken on, otherwise null
-    traffic = None
+    # (PMC counters cannot be read from inside the process: they come from the committed rocprofv3 passes of THIS command,
+    # tools/prof_pmc.sh -> profiles/pmc_traffic.json; FETCH_SIZE doubled as the MI355X guide prescribes for gfx950)
+    traffic = mfma_busy = None
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tfile):
         try:
             tj = json.load(open(tfile))
             if (tj.get("batch"), tj.get("seq_len"), tj.get("precision")) == (args.batch, args.seq_len, args.precision) and not args.ragged:
-                traffic = tj["bytes_per_launch"].get(names[k].split("(")[0])
+                kn = names[k].split("(")[0]
+                traffic = tj["bytes_per_launch"].get(kn)
+                mfma_busy = {"chip_percent": tj.get("mfma_util_chip_percent", {}).get(kn),
+                             "share_of_wave_cycles_percent": tj.get("mfma_busy_share_of_wave_cycles_percent", {}).get(kn),
+                             "source": tj.get("source")}
         except Exception:
-            traffic = None
+            traffic = mfma_busy = None
     roofline = {"bound": "mfma", "kernel": names[k], "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 6), "traffic": traffic, "launch_ms": round(ms[k], 4),
                 "all_launch_ms": {n: round(m, 4) for n, m in zip(names, ms)},
-                "recurrent_share_of_step": round(sum(ms) / (elapsed / args.steps * 1e3), 3), "timed_steps": nst.value}
+                "recurrent_share_of_step": round(sum(ms) / (elapsed / args.steps * 1e3), 3), "timed_steps": nst.value,
+                "mfma_busy": mfma_busy}
+    # What actually bounds that kernel: neither MFMA nor HBM but the chain of T dependent cross-CU hand-offs (h_t needs every hidden
+    # tile of h_{t-1}).  Its floor is the guide's handoff-1to1 price (0.8 - 1.0 us per hop on an idle chip, MI355X_MICROARCH.md
+    # price list); frac = T x floor / launch time.
+    hop_floor_us = 0.9
+    chain_steps = int(lengths.max().item())
+    roofline_chain = {"bound": "serial_chain", "kernel": names[k], "steps": chain_steps, "floor_us_per_step": hop_floor_us,
+                      "achieved_us_per_step": round(ms[k] * 1e3 / max(chain_steps, 1), 3),
+                      "frac": round(chain_steps * hop_floor_us / (ms[k] * 1e3), 4) if ms[k] > 0 else 0.0,
+                      "all_us_per_step": {n: round(m * 1e3 / max(chain_steps, 1), 3) for n, m in zip(names, ms)}}
 
     total_samples = args.batch * world * args.steps
     value = total_samples / elapsed
@@ -166,6 +182,7 @@ def main():
                    "rnncell": args.rnncell},
         "gflop_per_sample": 1.184 if args.seq_len == 50 else round(3 * (7736080 * args.seq_len + 7832576) / 1e9, 3),
         "roofline": roofline,
+        "roofline_serial_chain": roofline_chain,
         "losses": {k_: round(v_, 5) for k_, v_ in losses.items()},
     }
 
