@@ -15,6 +15,7 @@
  */
 #ifndef MMDA_HIP_H
 #define MMDA_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -145,6 +146,18 @@ int mmda_colsum(const float* X, int ld, int M, int N, float* out, float* out2, v
  * models.py:47,201 nn.Embedding forward; backward = dense scatter-add (sparse=False). */
 int mmda_embed_gather(const float* W, const int64_t* ids, int rows, int dim, float* out, void* stream);
 int mmda_embed_scatter_add(float* dW, const int64_t* ids, int rows, int dim, const float* dX, void* stream);
+/* Deterministic form of the scatter-add for data-parallel ranks (and any caller that needs run-to-run identical sums):
+ *   dW[id] = sum over the list positions p with ids[p] == id of rows[p], added in LIST ORDER (fixed two-level order: runs of <= 64
+ * sorted positions, then the runs of a segment); rows of dW whose id occurs are OVERWRITTEN, all others are left alone; ids < 0 are
+ * skipped.  ids (n) int64 and rows (n, D) fp32 on the device.  `work`: mmda_embed_segment_sum_work_bytes(n, D) bytes, 256-B aligned.
+ * Ranks all-gather (ids, rows) and each runs this on the identical gathered list: replicas stay bit-identical, which the atomic
+ * scatter-add cannot give (<= T*B rows per rank on the wire instead of V rows). */
+int64_t mmda_embed_segment_sum_work_bytes(int n, int D);
+int mmda_embed_segment_sum(float* dW, const int64_t* ids, int n, int D, const float* rows, void* work, int64_t work_bytes, void* stream);
+/* In-place sum all-reduce of n_floats fp32 values on an RCCL communicator (ncclComm_t passed as void*) -- the data-parallel exchange
+ * the reference never had (its only trace: the commented nn.DataParallel, solver.py:88-91) for hosts that own a communicator.
+ * ncclAllReduce is resolved at run time (process symbols first, then librccl.so): no link-time dependency. */
+int mmda_allreduce(void* buf, size_t n_floats, void* nccl_comm, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- LayerNorm
  * y = LN(act(x) + res * dropmask) * gamma + beta over the last dim n (eps 1e-5).   models.py:155-157,172 and the

@@ -112,6 +112,9 @@ SIGNATURES = {
     "mmda_colsum": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "mmda_embed_gather": (_I, [_P, _P, _I, _I, _P, _P]),
     "mmda_embed_scatter_add": (_I, [_P, _P, _I, _I, _P, _P]),
+    "mmda_embed_segment_sum_work_bytes": (_I64, [_I, _I]),
+    "mmda_embed_segment_sum": (_I, [_P, _P, _I, _I, _P, _P, _I64, _P]),
+    "mmda_allreduce": (_I, [_P, C.c_size_t, _P, _P]),
     "mmda_layernorm_fwd": (_I, [C.POINTER(LnArgs), _P]),
     "mmda_layernorm_bwd": (_I, [C.POINTER(LnBwdArgs), _P]),
     "mmda_layernorm_fwd_multi": (_I, [C.POINTER(LnArgs), _I, _P]),

@@ -2,9 +2,10 @@
 
 The reference is single-device (its only multi-GPU trace is a commented-out nn.DataParallel, solver.py:88-91).  Here each
 rank runs the reference loop on its own minibatch shard and the ranks exchange ONE flat fp32 gradient bucket per step
-(SURVEY.md 8e): the dense prefix (all non-embedding parameters, 19.25 MB at MOSEI sizes) plus the dense embedding
-gradient, summed with a single all-reduce and averaged by passing grad_scale = 1/world to the fused clamp+Adam kernel, so
-the clip happens AFTER averaging exactly like the single-process order (solver.py:183-186).
+(SURVEY.md 8e): the dense prefix (all non-embedding parameters, 19.25 MB at MOSEI sizes) is all-reduced; the embedding gradient
+travels as all-gathered (ids, rows) and is summed by every rank with the native deterministic segment sum (or, on request, dense
+inside the same all-reduce); the average is taken by passing grad_scale = 1/world to the fused clamp+Adam kernel, so the clip
+happens AFTER averaging exactly like the single-process order (solver.py:183-186).
 
 The bucket is ordered by completion time of the backward pass; with ``overlap=True`` (default) the prefix that is final beside
 the layer-1 backward recurrence (fusion block, LayerNorms, layer-2 recurrent layers) is reduced on its own stream behind an
@@ -20,18 +21,22 @@ import torch.distributed as dist
 
 
 class DataParallelSync:
-    def __init__(self, group=None, bucket_mb: float = 0.0, sparse_embedding: bool = False, overlap: bool = True):
+    def __init__(self, group=None, bucket_mb: float = 0.0, sparse_embedding=None, overlap: bool = True, equal_shapes: bool = False):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.bucket_floats = int(bucket_mb * (1 << 20) / 4) if bucket_mb > 0 else 0
-        # Opt-in: exchange the embedding gradient as (ids, rows) instead of all-reducing V x d_t.  Less traffic (1.9 MB per rank
-        # against 24 MB at V = 20 000), but every rank then scatter-adds with float atomics in its own order, so replicas agree
-        # only to rounding, not bit for bit as after an all-reduce.  Default: the dense, bit-identical exchange.
-        self.sparse_embedding = bool(sparse_embedding)
+        # The embedding gradient travels as all-gathered (ids, rows) -- 2 * T*B*d_t*4 bytes per rank instead of an all-reduce of
+        # V*d_t*4 (1.9 MB against 24 MB at MOSEI sizes, V = 20 000) -- and every rank then sums the SAME gathered list in the SAME
+        # order with the native deterministic segment sum (mmda_embed_segment_sum), so replicas stay bit-identical exactly as after an
+        # all-reduce.  None (default): on whenever the model exposes the sparse view and its gradients live on a GPU; False: the
+        # dense all-reduce of the whole bucket.
+        self.sparse_embedding = sparse_embedding
         self.overlap = bool(overlap)          # reduce the early-finished prefix of the bucket beside the rest of the backward pass
+        # every rank holds a batch of the same (B, T) on every step (benchmarks): the row counts need not be exchanged first
+        self.equal_shapes = bool(equal_shapes)
         self._comm = None
 
     def broadcast_parameters(self, model):
@@ -57,6 +62,20 @@ class DataParallelSync:
             return None
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
+    def _all_reduce_chunked(self, t: torch.Tensor):
+        """With bucket_floats > 0 the range is cut into chunks so the first all-reduce can start while later chunks are still
+        being enqueued (xGMI rings are per-link bound; >= 8 MB chunks keep them at bandwidth)."""
+        n = t.numel()
+        if n == 0:
+            return
+        if self.bucket_floats <= 0 or self.bucket_floats >= n:
+            self._all_reduce(t)
+            return
+        works = [self._all_reduce(t[s:s + self.bucket_floats], async_op=True) for s in range(0, n, self.bucket_floats)]
+        for w in works:
+            if w is not None:
+                w.wait()
+
     def _early_split(self, flat_grads: torch.Tensor, model) -> int:
         """Floats of the bucket that may be reduced ahead of the rest (0: none / not applicable)."""
         if not self.overlap or model is None or not flat_grads.is_cuda or not hasattr(model, "early_grad_floats"):
@@ -64,8 +83,6 @@ class DataParallelSync:
         early = int(model.early_grad_floats())
         if early <= 0 or early >= flat_grads.numel():
             return 0
-        if self._comm is None:
-            self._comm = torch.cuda.Stream(device=flat_grads.device)
         return early
 
     def _all_gather(self, t: torch.Tensor) -> torch.Tensor:
@@ -80,63 +97,62 @@ class DataParallelSync:
             dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
         return out.view((self.world,) + tuple(t.shape))
 
-    def _sync_sparse_embedding(self, flat_grads: torch.Tensor, dense_floats: int, model) -> None:
-        """Dense prefix: one all-reduce.  Embedding gradient: every rank's (ids, rows) are all-gathered and the other ranks'
-        rows scatter-added into the local dense gradient (which already holds the local rows) -- 2 * T*B*d_t*4 bytes per
-        rank on the wire instead of an all-reduce of V*d_t*4 (1.9 MB against 24 MB at MOSEI sizes, V = 20 000)."""
-        self._all_reduce(flat_grads[:dense_floats])
+    def _use_sparse(self, flat_grads, dense_floats, model) -> bool:
+        if self.sparse_embedding is False or model is None or dense_floats >= flat_grads.numel():
+            return False
+        hooks = hasattr(model, "embedding_grad_rows") and hasattr(model, "set_embedding_grad_rows")
+        return hooks and (flat_grads.is_cuda or self.sparse_embedding is True)
+
+    def _exchange_embedding_rows(self, model) -> None:
+        """Every rank's (ids, rows) all-gathered (rank-major list), then the deterministic segment sum of that list into the dense
+        embedding gradient -- the same list, the same order, the same sums on every rank."""
         ids, rows = model.embedding_grad_rows()
-        # ranks may hold batches of different length: agree on the row count, pad with (id 0, zero row)
-        n = torch.tensor([ids.numel()], dtype=torch.int64, device=ids.device)
-        counts = self._all_gather(n).view(-1).tolist()
-        cap = max(counts)
-        if ids.numel() < cap:
-            pad = cap - ids.numel()
-            ids = torch.cat([ids, ids.new_zeros(pad)])
-            rows = torch.cat([rows, rows.new_zeros(pad, rows.shape[1])])
+        if not self.equal_shapes:
+            # ranks may hold batches of different length (the reference's collate pads to the batch maximum): agree on the row
+            # count, pad with (id -1, zero row) -- skipped by the segment sum.  One 8-byte collective and one host read per step.
+            n = torch.tensor([ids.numel()], dtype=torch.int64, device=ids.device)
+            cap = max(self._all_gather(n).view(-1).tolist())
+            if ids.numel() < cap:
+                pad = cap - ids.numel()
+                ids = torch.cat([ids, ids.new_full((pad,), -1)])
+                rows = torch.cat([rows, rows.new_zeros(pad, rows.shape[1])])
         all_ids = self._all_gather(ids)               # (world, cap)
         all_rows = self._all_gather(rows)             # (world, cap, d_t)
-        if self.rank > 0:
-            model.scatter_embedding_rows(all_ids[:self.rank].reshape(-1), all_rows[:self.rank].reshape(-1, rows.shape[1]))
-        if self.rank + 1 < self.world:
-            model.scatter_embedding_rows(all_ids[self.rank + 1:].reshape(-1), all_rows[self.rank + 1:].reshape(-1, rows.shape[1]))
+        model.set_embedding_grad_rows(all_ids.reshape(-1), all_rows.reshape(-1, rows.shape[1]))
 
     def sync(self, flat_grads: torch.Tensor, dense_floats: int, model=None) -> float:
-        """All-reduce(sum) the gradient bucket in place; returns the scale (1/world) the optimizer applies.
-        With ``sparse_embedding=True`` and a model that exposes ``embedding_grad_rows`` the embedding gradient travels in its
-        sparse form (see __init__).
-        With bucket_floats > 0 the bucket is cut into chunks so the first all-reduce can start while later chunks are
-        still being enqueued (xGMI rings are per-link bound; >=8 MB chunks keep them at bandwidth)."""
+        """Exchange the gradient bucket in place (sum over ranks); returns the scale (1/world) the optimizer applies.
+
+        The bucket is laid out in the order the backward pass completes it.  On a GPU the whole exchange runs on a communication
+        stream of its own: the prefix that is final beside the layer-1 backward recurrence (fusion block, LayerNorms, layer-2
+        recurrent layers; the native step records an event behind it) is all-reduced as soon as that event fires -- the recurrence
+        leaves more than half of the CUs idle -- and the remainder (layer 1; the embedding gradient in its dense or its (ids, rows)
+        form) behind the step's last kernel.  The calling stream waits for the communication stream before the optimizer runs."""
         if self.world == 1:
             return 1.0
-        if model is not None and self.sparse_embedding and hasattr(model, "embedding_grad_rows") \
-                and dense_floats < flat_grads.numel():
-            self._sync_sparse_embedding(flat_grads, dense_floats, model)
-            return 1.0 / self.world
         n = flat_grads.numel()
-        early = self._early_split(flat_grads, model)
+        sparse = self._use_sparse(flat_grads, dense_floats, model)
+        end = dense_floats if sparse else n           # floats that travel by all-reduce
+        if not flat_grads.is_cuda:
+            self._all_reduce_chunked(flat_grads[:end])
+            if sparse:
+                self._exchange_embedding_rows(model)
+            return 1.0 / self.world
+        early = min(self._early_split(flat_grads, model), end)
+        cur = torch.cuda.current_stream(flat_grads.device)
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(device=flat_grads.device)
         if early:
-            # The bucket is laid out in the order the backward pass completes it; the native step recorded an event behind the
-            # last kernel that writes its first `early` floats (fusion block, LayerNorms, layer-2 recurrent layers).  That part
-            # is reduced on a stream of its own as soon as the event fires -- beside the layer-1 backward recurrence, which
-            # leaves more than half of the CUs idle -- and the rest (layer 1, embedding) after the step's last kernel.
             # `early` is a function of the model configuration and the build, identical on every rank; a failure of the event wait
             # is raised, not handled: a rank that fell back to ONE all-reduce while its peers issue TWO would hang the job or,
             # worse, sum mismatched ranges.
-            cur = torch.cuda.current_stream(flat_grads.device)
             model.wait_early_grads(self._comm)
             with torch.cuda.stream(self._comm):
                 self._all_reduce(flat_grads[:early])
-            self._all_reduce(flat_grads[early:])
-            cur.wait_stream(self._comm)
-            return 1.0 / self.world
-        if self.bucket_floats <= 0 or self.bucket_floats >= n:
-            self._all_reduce(flat_grads)
-        else:
-            works = []
-            for s in range(0, n, self.bucket_floats):
-                works.append(self._all_reduce(flat_grads[s:s + self.bucket_floats], async_op=True))
-            for w in works:
-                if w is not None:
-                    w.wait()
+        self._comm.wait_stream(cur)                   # the rest is final once everything issued so far is through
+        with torch.cuda.stream(self._comm):
+            self._all_reduce_chunked(flat_grads[early:end])
+            if sparse:
+                self._exchange_embedding_rows(model)
+        cur.wait_stream(self._comm)
         return 1.0 / self.world

@@ -131,6 +131,7 @@ class MISA(nn.Module):
         self._anchor = None
         self._last = {}
         self._abort_seen = False
+        self._seg_work = None
 
     # ------------------------------------------------------------------ parameters
     def _register(self, dotted: str, shape):
@@ -452,20 +453,40 @@ class MISA(nn.Module):
 
     # ------------------------------------------------------------------ sparse view of the embedding gradient (data parallel)
     def embedding_grad_rows(self):
-        """(ids (R,) int64, rows (R, d_t) fp32) of the last backward: embed.weight.grad == scatter_add(ids, rows).  The dense
-        gradient is non-zero in at most R = T*B of its V rows, so data-parallel ranks exchange these instead of V x d_t."""
+        """(ids (R,) int64, rows (R, d_t) fp32) of the last backward: embed.weight.grad == sum over the list of rows[p] into row
+        ids[p].  The dense gradient is non-zero in at most R = T*B of its V rows, so data-parallel ranks exchange these instead of
+        V x d_t.  Positions past a sample's length carry id -1 (their rows are exactly zero: no gradient flows through padding)."""
         t = self._last["t"]
-        R = t.numel()
-        return t.reshape(R), self._ws_view("d_x_t", (R, self._layout["embed.weight"][1][1]))
+        T, B = t.shape
+        R = T * B
+        pad = torch.arange(T, device=t.device, dtype=torch.int32).unsqueeze(1) >= self._last["len_dev"].unsqueeze(0)
+        ids = torch.where(pad, torch.full_like(t, -1), t)
+        return ids.reshape(R), self._ws_view("d_x_t", (R, self._layout["embed.weight"][1][1]))
 
     def scatter_embedding_rows(self, ids: torch.Tensor, rows: torch.Tensor):
-        """embed.weight.grad[ids] += rows (other ranks' contributions), with the native dense scatter-add."""
+        """embed.weight.grad[ids] += rows with the native atomic scatter-add (summation order not fixed; ids < 0 not allowed)."""
         if ids.numel() == 0:
             return
         off, (V, D) = self._layout["embed.weight"]
         g = self._G[off:off + V * D]
         _lib.check(self._lib.mmda_embed_scatter_add(g.data_ptr(), ids.contiguous().data_ptr(), ids.numel(), D,
                                                     rows.contiguous().data_ptr(), _lib.stream_ptr()), "embed_scatter_add")
+
+    def set_embedding_grad_rows(self, ids: torch.Tensor, rows: torch.Tensor):
+        """embed.weight.grad[id] = sum of rows[p] over the positions with ids[p] == id, added in list order by the native
+        deterministic segment sum (rows of ids that occur are overwritten, ids < 0 skipped): what every data-parallel rank runs on
+        the same all-gathered list, so that replicas stay bit-identical."""
+        n = ids.numel()
+        if n == 0:
+            return
+        off, (V, D) = self._layout["embed.weight"]
+        g = self._G[off:off + V * D]
+        need = int(self._lib.mmda_embed_segment_sum_work_bytes(n, D))
+        if self._seg_work is None or self._seg_work.numel() < need or self._seg_work.device != g.device:
+            self._seg_work = torch.empty(need, dtype=torch.uint8, device=g.device)
+        _lib.check(self._lib.mmda_embed_segment_sum(g.data_ptr(), ids.contiguous().data_ptr(), n, D, rows.contiguous().data_ptr(),
+                                                    self._seg_work.data_ptr(), self._seg_work.numel(), _lib.stream_ptr()),
+                   "embed_segment_sum")
 
     def read_losses(self) -> Dict[str, float]:
         """cls, diff, sim, recon, conf, total of the last losses pass (one device->host sync)."""

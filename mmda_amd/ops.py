@@ -182,6 +182,16 @@ def embed_scatter_add(dW, ids, dX):
     return dW
 
 
+def embed_segment_sum(dW, ids, rows):
+    """dW[id] = list-order sum of rows[p] over ids[p] == id (overwrites those rows; ids < 0 skipped): mmda_embed_segment_sum."""
+    lib = load()
+    n, D = rows.shape
+    need = int(lib.mmda_embed_segment_sum_work_bytes(n, D))
+    work = torch.empty(max(need, 256), dtype=torch.uint8, device=dW.device)
+    check(lib.mmda_embed_segment_sum(ptr(_f(dW)), ptr(ids), n, D, ptr(_f(rows)), ptr(work), work.numel(), stream_ptr()), "mmda_embed_segment_sum")
+    return dW
+
+
 def layernorm_fwd(x, gamma, beta, *, res=None, act="none", drop_p=0.0, seed=0, site=0, permute=None, eps=1e-5):
     lib = load()
     n = x.shape[-1]

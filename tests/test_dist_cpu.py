@@ -87,8 +87,14 @@ def _sparse_worker(rank, world, port, q):
             def __init__(self):
                 self.G = torch.cat([dense, torch.zeros(V * D).index_add_(0, (ids[:, None] * D + torch.arange(D)).reshape(-1), rows.reshape(-1))])
             def embedding_grad_rows(self): return ids, rows
-            def scatter_embedding_rows(self, i, r):
-                self.G[n_dense:].index_add_(0, (i[:, None] * D + torch.arange(D)).reshape(-1), r.reshape(-1))
+            def set_embedding_grad_rows(self, i, r):          # rows of the ids that occur are overwritten by the list-order sums; ids < 0 skipped
+                E = self.G[n_dense:].view(V, D)
+                for v in sorted(set(int(x) for x in i.tolist() if x >= 0)):
+                    acc = torch.zeros(D)
+                    for p in range(i.numel()):
+                        if int(i[p]) == v:
+                            acc = acc + r[p]
+                    E[v] = acc
         m = FakeModel()
         scale = dp.sync(m.G, n_dense, m)
         # oracle: sum over ranks of the DENSE gradients
@@ -105,8 +111,8 @@ def _sparse_worker(rank, world, port, q):
 
 
 def test_sparse_embedding_exchange_world2_ragged_shards():
-    """opt-in sparse form: dense prefix all-reduced, embedding gradient as all-gathered (ids, rows) with padding to the longest
-    shard -- the result must equal the all-reduce of the dense gradients."""
+    """sparse form (the default on GPUs): dense prefix all-reduced, embedding gradient as all-gathered (ids, rows) with padding to the
+    longest shard (id -1), summed in list order on every rank -- the result must equal the all-reduce of the dense gradients."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -884,3 +884,93 @@ print("ok")
     env = dict(os.environ, MMDA_XCD_LOCAL=xcd_local)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
+
+
+# ------------------------------------------------------------------------------------------------ data-parallel pieces
+def _segment_sum_reference(ids, rows, V):
+    """The documented order in numpy fp32: stable sort by id; runs = segments cut at multiples of 64 sorted positions; a run is summed
+    sequentially, then a segment's runs sequentially."""
+    ids = ids.numpy(); rows = rows.numpy()
+    order = np.argsort(np.where(ids < 0, 1 << 40, ids), kind="stable")
+    sid = ids[order]
+    out = {}
+    p = 0
+    n = len(sid)
+    while p < n and sid[p] >= 0:
+        e = p
+        while e < n and sid[e] == sid[p]:
+            e += 1
+        acc = np.zeros(rows.shape[1], np.float32)
+        q = p
+        while q < e:
+            lim = min(e, (q // 64 + 1) * 64)
+            part = np.zeros(rows.shape[1], np.float32)
+            for r in range(q, lim):
+                part = (part + rows[order[r]]).astype(np.float32)
+            acc = (acc + part).astype(np.float32)
+            q = lim
+        out[int(sid[p])] = acc
+        p = e
+    return out
+
+
+@pytest.mark.parametrize("n,V,D", [(1600, 500, 300), (4000, 37, 300), (300, 64, 12), (5, 3, 7)])
+def test_embed_segment_sum_is_exact_and_deterministic(n, V, D):
+    """mmda_embed_segment_sum: the dense rows equal the list-order sums BIT FOR BIT (fixed two-level order, no atomics), untouched rows
+    stay as they were, ids < 0 are skipped, and a second run gives identical bits (what keeps data-parallel replicas identical)."""
+    from mmda_amd import ops
+    torch.manual_seed(n + D)
+    ids = torch.randint(0, V, (n,))
+    if n >= 1000:
+        ids[torch.randperm(n)[: n // 3]] = 1           # one long segment (a frequent word)
+        ids[torch.randperm(n)[: n // 10]] = -1         # padded positions
+    rows = torch.randn(n, D)
+    base = torch.randn(V, D)
+    ref = _segment_sum_reference(ids, rows, V)
+    outs = []
+    for _ in range(2):
+        dW = base.clone().to(dev())
+        ops.embed_segment_sum(dW, ids.to(dev()), rows.to(dev()))
+        outs.append(dW.cpu())
+    assert torch.equal(outs[0], outs[1])
+    for v in range(V):
+        if v in ref:
+            assert np.array_equal(outs[0][v].numpy(), ref[v]), v
+        else:
+            assert torch.equal(outs[0][v], base[v]), v
+
+
+def test_allreduce_entry_on_a_single_rank_rccl_communicator():
+    """mmda_allreduce (the C-ABI data-parallel exchange for hosts that own an RCCL communicator): exercised with a one-rank
+    communicator created through the same librccl the entry resolves ncclAllReduce from; a sum over one rank leaves the buffer as it
+    is, and the call has to go through RCCL's stream-ordered path to say so."""
+    import ctypes as C
+    from mmda_amd import _lib
+    lib = _lib.load()
+    rccl = None
+    for name in ("librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"):
+        try:
+            rccl = C.CDLL(name, mode=C.RTLD_GLOBAL)
+            break
+        except OSError:
+            continue
+    if rccl is None:
+        pytest.skip("librccl.so not found on this box")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        x = torch.randn(100003, device=dev())
+        want = x.clone()
+        _lib.check(lib.mmda_allreduce(x.data_ptr(), x.numel(), comm, _lib.stream_ptr()), "mmda_allreduce")
+        torch.cuda.synchronize()
+        assert torch.equal(x, want)
+        assert lib.mmda_allreduce(None, 4, comm, None) == -1 and lib.mmda_allreduce(x.data_ptr(), 4, None, None) == -1
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
