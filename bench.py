@@ -77,6 +77,8 @@ def main():
     if args.streaming_recurrence:
         model.set_recurrence(False)
     t, v, a, y, emo, lengths, *_ = synth_batch(cfg, args.batch, args.seq_len, seed=rank, ragged=bool(args.ragged), device=dev)
+    if solver.dp is not None:
+        solver.dp.equal_shapes = True            # every rank steps the same (B, T): no row-count exchange in front of the all-gathers
     sync = solver.dp.sync if solver.dp is not None else None
 
     def step():
