@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--ragged", type=int, default=0)
     ap.add_argument("--confidnet", type=int, default=0)
     ap.add_argument("--rnncell", default="lstm", choices=["lstm", "gru"], help="config.rnncell (the headline config is lstm)")
+    ap.add_argument("--fp8-fusion", type=int, default=0, help="BASELINE configs[4]: the fusion layer's feed-forward products on block-scaled fp8 (forward)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streaming-recurrence", action="store_true", help="bf16: stream W_hh from L2 per step instead of LDS-resident")
     ap.add_argument("--cpu-steps", type=int, default=0, help="0 = pick a count that takes ~10-30 s")
@@ -70,7 +71,8 @@ def main():
 
     torch.manual_seed(0)
     cfg = make_config(vocab_size=args.vocab, precision=args.precision, device=str(dev), batch_size=args.batch,
-                      seq_len=args.seq_len, use_confidNet=bool(args.confidnet), rnncell=args.rnncell, pretrained_emb=torch.randn(args.vocab, 300))
+                      seq_len=args.seq_len, use_confidNet=bool(args.confidnet), rnncell=args.rnncell, pretrained_emb=torch.randn(args.vocab, 300),
+                      fusion_fp8=bool(args.fp8_fusion))
     solver = Solver(cfg, cfg, cfg, None, None, None, is_train=True).build()
     model = solver.model
     model.train()
@@ -177,7 +179,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "config": {"workload": f"MISA train step, MOSEI shapes B={args.batch}/GPU T={args.seq_len} (d_t,d_v,d_a)=(300,35,74) "
-                               f"hidden=128 V={args.vocab}, {args.precision} MFMA operands fp32 accumulate, dropout on, "
+                               f"hidden=128 V={args.vocab}, {args.precision} MFMA operands fp32 accumulate"
+                               f"{', fusion FFN products on block-scaled fp8' if args.fp8_fusion else ''}, dropout on, "
                                f"{'ragged' if args.ragged else 'full'} lengths",
                    "global_batch": args.batch * world, "seq_len": args.seq_len,
                    "parallelism": f"dp{world}" if world > 1 else "single", "use_confidNet": bool(args.confidnet),

@@ -110,6 +110,30 @@ typedef struct mmda_convert_job {
 } mmda_convert_job;
 int mmda_convert_bf16(const mmda_convert_job* jobs, int n, void* stream);
 
+/* ---------------------------------------------------------------------------------------------- block-scaled fp8 GEMM (MX)
+ * The two feed-forward products of the fusion transformer layer (linear1 128 -> 2048, linear2 2048 -> 128; reference
+ * models.py:160-161) on v_mfma_scale_f32_16x16x128_f8f6f4: OCP MX operands -- e4m3 elements, one E8M0 scale per 32 consecutive k
+ * (shared exponent floor(log2 amax) - 8, elements clamped to +-448, round to nearest even) -- fp32 accumulate.  BASELINE.json
+ * configs[4] ("mixed fp8 fusion GEMMs"); off by default (mmda_misa_set_fusion_fp8).
+ * mmda_mx8_quant: fp32 (rows, K) row-major, K a multiple of 128 (16-byte loads when the rows are 16-byte aligned) -> q: rows * K element bytes in the MFMA's
+ * operand order ([row][k-step of 128][lane group 0..3][32 bytes]) and s: rows * K / 32 scale bytes ([row][block]).  <= 8 jobs / launch.
+ * mmda_gemm_mx8: C (M, N) = act(A (M, K) . B (N, K)^T + bias) * dropout, both operands quantised as above; N a multiple of 16. */
+typedef struct mmda_mx8_quant_job {
+  const float* src; int ld; int rows, K;
+  unsigned char* q; unsigned char* s;
+} mmda_mx8_quant_job;
+typedef struct mmda_mx8_args {
+  int M, N, K;
+  const unsigned char* Aq; const unsigned char* As;
+  const unsigned char* Bq; const unsigned char* Bs;
+  float* C; int ldc;
+  const float* bias; int act;
+  float drop_p; uint64_t drop_seed; int drop_site;     /* element index m * N + n, as in the f32 path */
+} mmda_mx8_args;
+int64_t mmda_mx8_quant_bytes(int rows, int K);
+int mmda_mx8_quant(const mmda_mx8_quant_job* jobs, int n, void* stream);
+int mmda_gemm_mx8(const mmda_mx8_args* args, void* stream);
+
 /* ---------------------------------------------------------------------------------------------- row-skinny f32 GEMM
  * The fusion block's GEMMs have M = B or 6B rows (models.py:63-153,243-249 and their input gradients): one workgroup per
  * 32 x 16 output tile whose eight waves split K, exact f32 MFMA, operands straight from global memory, fixed-order reduction
@@ -412,6 +436,9 @@ int mmda_misa_set_gemm_operands(mmda_misa* m, int bf16_copies);
  * bf16 copies that only the weight-gradient GEMMs read are not made.  Default 0.  mmda_misa_backward after a forward in this mode
  * returns MMDA_EINVAL. */
 int mmda_misa_set_inference(mmda_misa* m, int forward_only);
+/* 1 = the forward feed-forward products of the fusion transformer layer (linear1 / linear2) run on block-scaled fp8 operands
+ * (mmda_gemm_mx8); their backward stays on the exact f32 path with the stored activations (straight-through).  Default 0. */
+int mmda_misa_set_fusion_fp8(mmda_misa* m, int on);
 /* Data parallel: the gradient bucket is laid out in the order the backward pass completes it (fusion block, LayerNorms,
  * layer-2 recurrent layers, layer-1 recurrent layers, embedding).  After mmda_misa_backward / mmda_misa_train_step has been
  * ISSUED, the first mmda_misa_early_grad_floats() floats of the bucket are final as soon as an event recorded inside that call

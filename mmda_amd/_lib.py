@@ -96,6 +96,16 @@ class MisaConfig(C.Structure):
                 ("mode", C.c_int), ("rnncell", C.c_int)]
 
 
+class Mx8QuantJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("ld", C.c_int), ("rows", C.c_int), ("K", C.c_int), ("q", C.c_void_p), ("s", C.c_void_p)]
+
+
+class Mx8Args(C.Structure):
+    _fields_ = [("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("Aq", C.c_void_p), ("As", C.c_void_p), ("Bq", C.c_void_p),
+                ("Bs", C.c_void_p), ("C", C.c_void_p), ("ldc", C.c_int), ("bias", C.c_void_p), ("act", C.c_int),
+                ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_site", C.c_int)]
+
+
 CELL = {"lstm": 0, "gru": 1}
 
 # name -> (restype, argtypes).  Every symbol include/mmda_hip.h declares appears here (tests/test_abi.py checks it).
@@ -108,6 +118,9 @@ SIGNATURES = {
     "mmda_gemm_bf16_grouped": (_I, [C.POINTER(GemmBf16Args), _I, _P]),
     "mmda_convert_bf16": (_I, [C.POINTER(ConvertJob), _I, _P]),
     "mmda_gemm_skinny": (_I, [C.POINTER(SkinnyArgs), _I, _P]),
+    "mmda_mx8_quant_bytes": (_I64, [_I, _I]),
+    "mmda_mx8_quant": (_I, [C.POINTER(Mx8QuantJob), _I, _P]),
+    "mmda_gemm_mx8": (_I, [C.POINTER(Mx8Args), _P]),
     "mmda_transpose_f32": (_I, [C.POINTER(TransposeJob), _I, _P]),
     "mmda_colsum": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "mmda_embed_gather": (_I, [_P, _P, _I, _I, _P, _P]),
@@ -173,6 +186,7 @@ SIGNATURES = {
     "mmda_misa_early_grad_floats": (_I64, [_P]),
     "mmda_misa_wait_early_grads": (_I, [_P, _P]),
     "mmda_misa_set_inference": (_I, [_P, _I]),
+    "mmda_misa_set_fusion_fp8": (_I, [_P, _I]),
     "mmda_misa_cluster_status": (_I, [_P, C.POINTER(_I)]),
     "mmda_misa_forward": (_I, [_P, _P, _P, _P, _P, _I, _U64, _P]),
     "mmda_misa_losses": (_I, [_P, _P, _I, _P]),

@@ -66,6 +66,9 @@ struct mmda_misa {
   int wT_valid = 0;
   int64_t d_scores, d_tcp, d_x6, d_orig, d_recon, d_dom, d_logits, d_hfused, d_x1, d_f2, d_f1, d_attn_out, d_ctx, d_qkv, d_z,
       d_dom_h, d_dom_z;
+  // block-scaled fp8 operands of the feed-forward products (fusion_fp8): element bytes and scale bytes, as float offsets
+  int fusion_fp8 = 0;
+  int64_t x1q, x1s, w1q, w1s, f1q, f1s, w2q, w2s;
   // state of the last forward (dropout replay in backward)
   int training = 0; uint64_t seed = 0;
   // optional per-launch timing of the four recurrent kernels (bench.py roofline leg)
@@ -261,6 +264,9 @@ int64_t layout(mmda_misa* m, int B, int T, bool commit) {
   o->attn_out = k.take(6 * BH); o->ln1_mean = k.take(6 * B); o->ln1_rstd = k.take(6 * B); o->x1 = k.take(6 * BH);
   o->f1 = k.take((int64_t)6 * B * FFN); o->f2 = k.take(6 * BH); o->ln2_mean = k.take(6 * B); o->ln2_rstd = k.take(6 * B);
   o->hfused = k.take(6 * BH); o->logits = k.take((int64_t)B * NC);
+  o->x1q = k.take(6 * BH / 4); o->x1s = k.take(6 * BH / 128 + 4); o->w1q = k.take((int64_t)FFN * hs / 4); o->w1s = k.take((int64_t)FFN * hs / 128 + 4);
+  o->f1q = k.take((int64_t)6 * B * FFN / 4); o->f1s = k.take((int64_t)6 * B * FFN / 128 + 4);
+  o->w2q = k.take((int64_t)hs * FFN / 4); o->w2s = k.take((int64_t)hs * FFN / 128 + 4);
   o->diff_work = k.take(mmda_loss_diff_work_floats(B, hs));
   o->head_wT = k.take((int64_t)6 * hs * NC); o->l2_wT = k.take((int64_t)FFN * hs); o->l1_wT = k.take((int64_t)hs * FFN);
   o->out_wT = k.take((int64_t)hs * hs); o->in_wT = k.take((int64_t)hs * 3 * hs); o->rec_wT = k.take((int64_t)3 * hs * hs);
@@ -622,6 +628,43 @@ int eager_side_losses(mmda_misa* m, void* stream, bool hseq2_t) {
 }
 }  // namespace
 
+namespace {
+// feed-forward of the fusion transformer layer on block-scaled fp8 operands (models.py:160-161; torch's linear1 -> relu -> dropout ->
+// linear2): x1 (6B, hs) -> f1 (6B, FFN) -> f2 (6B, hs).  Four launches: quantise {x1, W1, W2}, product 1 (+bias, relu, dropout),
+// quantise f1, product 2 (+bias).  The f32 tensors f1 / f2 the backward pass reads are written as on the exact path.
+int ffn_fp8(mmda_misa* m, float p_tf, uint64_t seed, void* stream) {
+  const mmda_misa_config& c = m->cfg;
+  const int hs = c.hidden, R6 = 6 * m->B;
+  if ((hs % 128) != 0) return MMDA_EINVAL;               // K of product 1 must be whole 128-deep MFMA steps
+  auto U8 = [&](int64_t off) { return reinterpret_cast<unsigned char*>(m->ws + off); };
+  mmda_mx8_quant_job q[3] = {
+      {m->ws + m->x1, hs, R6, hs, U8(m->x1q), U8(m->x1s)},
+      {m->P + m->l1_w, hs, FFN, hs, U8(m->w1q), U8(m->w1s)},
+      {m->P + m->l2_w, FFN, hs, FFN, U8(m->w2q), U8(m->w2s)}};
+  int rc = mmda_mx8_quant(q, 3, stream);
+  if (rc) return rc;
+  mmda_mx8_args g = {};
+  g.M = R6; g.N = FFN; g.K = hs; g.Aq = U8(m->x1q); g.As = U8(m->x1s); g.Bq = U8(m->w1q); g.Bs = U8(m->w1s);
+  g.C = m->ws + m->f1; g.ldc = FFN; g.bias = m->P + m->l1_b; g.act = MMDA_ACT_RELU; g.drop_p = p_tf; g.drop_seed = seed; g.drop_site = SITE_FFN;
+  rc = mmda_gemm_mx8(&g, stream);
+  if (rc) return rc;
+  mmda_mx8_quant_job qf = {m->ws + m->f1, FFN, R6, FFN, U8(m->f1q), U8(m->f1s)};
+  rc = mmda_mx8_quant(&qf, 1, stream);
+  if (rc) return rc;
+  mmda_mx8_args h = {};
+  h.M = R6; h.N = hs; h.K = FFN; h.Aq = U8(m->f1q); h.As = U8(m->f1s); h.Bq = U8(m->w2q); h.Bs = U8(m->w2s);
+  h.C = m->ws + m->f2; h.ldc = hs; h.bias = m->P + m->l2_b;
+  return mmda_gemm_mx8(&h, stream);
+}
+}  // namespace
+
+extern "C" int mmda_misa_set_fusion_fp8(mmda_misa* m, int on) {
+  if (!m) return MMDA_EINVAL;
+  if (on && (m->cfg.hidden % 128) != 0) return MMDA_EINVAL;
+  m->fusion_fp8 = on ? 1 : 0;
+  return MMDA_OK;
+}
+
 extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float* v, const float* a, const int32_t* lengths,
                                  int training, uint64_t seed, void* stream) {
   if (check_ready(m) || !t_ids || !v || !a || !lengths) return MMDA_EINVAL;
@@ -879,11 +922,15 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
       l1.drop_site = SITE_DROP1; l1.eps = 1e-5f;
       x.rc = mmda_layernorm_fwd(&l1, stream);
     }
-    g[0] = sk_nt(6 * B, FFN, hs, WS(m->x1), hs, PP(m->l1_w), PP(m->l1_b), WS(m->f1), FFN, MMDA_ACT_RELU);
-    g[0].drop_p = p_tf; g[0].drop_seed = seed; g[0].drop_site = SITE_FFN;
-    sk_launch(x, g, 1);
-    g[0] = sk_nt(6 * B, hs, FFN, WS(m->f1), FFN, PP(m->l2_w), PP(m->l2_b), WS(m->f2), hs);
-    sk_launch(x, g, 1);
+    if (m->fusion_fp8) {
+      if (!x.rc) x.rc = ffn_fp8(m, p_tf, seed, stream);
+    } else {
+      g[0] = sk_nt(6 * B, FFN, hs, WS(m->x1), hs, PP(m->l1_w), PP(m->l1_b), WS(m->f1), FFN, MMDA_ACT_RELU);
+      g[0].drop_p = p_tf; g[0].drop_seed = seed; g[0].drop_site = SITE_FFN;
+      sk_launch(x, g, 1);
+      g[0] = sk_nt(6 * B, hs, FFN, WS(m->f1), FFN, PP(m->l2_w), PP(m->l2_b), WS(m->f2), hs);
+      sk_launch(x, g, 1);
+    }
     if (!x.rc) {
       mmda_ln_args l2 = {};
       l2.rows = 6 * B; l2.n = hs; l2.x = WS(m->x1); l2.res = WS(m->f2); l2.gamma = PP(m->n2_w); l2.beta = PP(m->n2_b);
@@ -934,13 +981,15 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
       ln.drop_site = SITE_DROP1; ln.eps = 1e-5f;
       x.rc = mmda_layernorm_fwd(&ln, stream);
     }
-    {
+    if (m->fusion_fp8) {
+      if (!x.rc) x.rc = ffn_fp8(m, p_tf, seed, stream);
+    } else {
       mmda_gemm_args e = {};
       e.drop_p = p_tf; e.drop_seed = seed; e.drop_site = SITE_FFN;
       gemm(x, fmode, 0, 1, 6 * B, FFN, hs, WS(m->x1), hs, PP(m->l1_w), hs, WS(m->f1), FFN, PP(m->l1_b), nullptr, 0, MMDA_ACT_RELU, 1, 0,
            0, 0, 0, &e);
+      lin_fwd(x, fmode, 6 * B, hs, FFN, WS(m->f1), PP(m->l2_w), PP(m->l2_b), WS(m->f2));
     }
-    lin_fwd(x, fmode, 6 * B, hs, FFN, WS(m->f1), PP(m->l2_w), PP(m->l2_b), WS(m->f2));
     if (!x.rc) {
       mmda_ln_args ln = {};
       ln.rows = 6 * B; ln.n = hs; ln.x = WS(m->x1); ln.res = WS(m->f2); ln.gamma = PP(m->n2_w); ln.beta = PP(m->n2_b);

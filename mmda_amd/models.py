@@ -105,6 +105,10 @@ class MISA(nn.Module):
         _lib.check(lib.mmda_misa_create(C.byref(cc), C.byref(h)), "mmda_misa_create")
         self._h = h
         self._lib = lib
+        # BASELINE configs[4]: the fusion layer's feed-forward products on block-scaled fp8 (forward only; off by default)
+        self.fusion_fp8 = bool(getattr(config, "fusion_fp8", False))
+        if self.fusion_fp8:
+            _lib.check(lib.mmda_misa_set_fusion_fp8(h, 1), "set_fusion_fp8")
         self._layout: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
         for i in range(lib.mmda_misa_num_params(h)):
             name, off, rows, cols = C.c_char_p(), C.c_int64(), C.c_int(), C.c_int()
@@ -526,6 +530,12 @@ class MISA(nn.Module):
     def set_gemm_operands(self, bf16_copies: bool):
         """bf16 mode: LSTM-sized GEMMs on bf16 operand copies (default) or on fp32 tensors staged through the generic kernel."""
         _lib.check(self._lib.mmda_misa_set_gemm_operands(self._h, int(bf16_copies)), "set_gemm_operands")
+
+    def set_fusion_fp8(self, on: bool):
+        """Forward feed-forward products of the fusion transformer layer (linear1 / linear2, reference models.py:160-161) on
+        block-scaled fp8 MFMA operands; the backward pass stays exact (straight-through)."""
+        self.fusion_fp8 = bool(on)
+        _lib.check(self._lib.mmda_misa_set_fusion_fp8(self._h, int(on)), "set_fusion_fp8")
 
     def set_precision(self, precision: str):
         self.precision = precision

@@ -182,6 +182,33 @@ def embed_scatter_add(dW, ids, dX):
     return dW
 
 
+def mx8_quant(x):
+    """fp32 (rows, K) -> (element bytes (rows * K,) uint8 in MFMA operand order, scale bytes (rows * K / 32,) uint8): mmda_mx8_quant."""
+    lib = load()
+    rows, K = x.shape
+    q = torch.empty(rows * K, dtype=torch.uint8, device=x.device)
+    s = torch.empty(rows * K // 32 + 16, dtype=torch.uint8, device=x.device)
+    j = (_lib.Mx8QuantJob * 1)()
+    j[0].src = ptr(_f(x)); j[0].ld = K; j[0].rows = rows; j[0].K = K; j[0].q = ptr(q); j[0].s = ptr(s)
+    check(lib.mmda_mx8_quant(j, 1, stream_ptr()), "mmda_mx8_quant")
+    return q, s
+
+
+def gemm_mx8(A, B, *, bias=None, act="none", drop_p=0.0, seed=0, site=0):
+    """act(A (M, K) @ B (N, K)^T + bias) * dropout with both operands quantised to block-scaled fp8 (OCP MX e4m3): mmda_gemm_mx8."""
+    lib = load()
+    M, K = A.shape
+    N = B.shape[0]
+    Aq, As = mx8_quant(A)
+    Bq, Bs = mx8_quant(B)
+    out = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    g = _lib.Mx8Args()
+    g.M = M; g.N = N; g.K = K; g.Aq = ptr(Aq); g.As = ptr(As); g.Bq = ptr(Bq); g.Bs = ptr(Bs); g.C = ptr(out); g.ldc = N
+    g.bias = ptr(bias); g.act = ACT[act]; g.drop_p = drop_p; g.drop_seed = seed; g.drop_site = site
+    check(lib.mmda_gemm_mx8(C.byref(g), stream_ptr()), "mmda_gemm_mx8")
+    return out
+
+
 def embed_segment_sum(dW, ids, rows):
     """dW[id] = list-order sum of rows[p] over ids[p] == id (overwrites those rows; ids < 0 skipped): mmda_embed_segment_sum."""
     lib = load()

@@ -212,9 +212,16 @@ def _linear(x, P, name):
     return x @ P[name + ".weight"].t() + P[name + ".bias"]
 
 
-def fusion_layer(x, P: Params):
+def ffn_exact(x, P: Params):
+    """linear2(relu(linear1(x))) of the encoder layer (torch/nn/modules/transformer.py _ff_block, dropout off)."""
+    te = "transformer_encoder.layers.0."
+    return _linear(torch.relu(_linear(x, P, te + "linear1")), P, te + "linear2")
+
+
+def fusion_layer(x, P: Params, ffn=None):
     """Post-norm transformer encoder layer on (S=6, B, E) (models.py:160-161,243-245);
-    restated from torch/nn/modules/transformer.py slow path: x=LN(x+SA(x)); x=LN(x+FF(x))."""
+    restated from torch/nn/modules/transformer.py slow path: x=LN(x+SA(x)); x=LN(x+FF(x)).
+    ``ffn``: replacement for the feed-forward block (oracle/fp8_emul.py emulates the block-scaled fp8 products with it)."""
     te = "transformer_encoder.layers.0."
     S, B, E = x.shape
     hd = E // NHEAD
@@ -229,7 +236,7 @@ def fusion_layer(x, P: Params):
     ctx = (att @ v).permute(2, 0, 1, 3).reshape(S, B, E)
     sa = _linear(ctx, P, te + "self_attn.out_proj")
     x = F.layer_norm(x + sa, (E,), P[te + "norm1.weight"], P[te + "norm1.bias"], LN_EPS)
-    ff = _linear(torch.relu(_linear(x, P, te + "linear1")), P, te + "linear2")
+    ff = (ffn or ffn_exact)(x, P)
     return F.layer_norm(x + ff, (E,), P[te + "norm2.weight"], P[te + "norm2.bias"], LN_EPS)
 
 
@@ -245,7 +252,7 @@ class _GradReverse(torch.autograd.Function):
         return -g * ctx.p, None
 
 
-def forward(P: Params, cfg, t, v, a, lengths) -> SimpleNamespace:
+def forward(P: Params, cfg, t, v, a, lengths, ffn=None) -> SimpleNamespace:
     """Full model forward with all dropout disabled.  Returns every tensor the reference's
     solver reads off the module (SURVEY.md 8b side channel)."""
     dt, dv, da, hs = cfg.embedding_size, cfg.visual_size, cfg.acoustic_size, cfg.hidden_size
@@ -257,10 +264,10 @@ def forward(P: Params, cfg, t, v, a, lengths) -> SimpleNamespace:
     utt = {"t": encode_modality(emb, lengths, P, "t", dt, cell),
            "v": encode_modality(v, lengths, P, "v", dv, cell),
            "a": encode_modality(a, lengths, P, "a", da, cell)}
-    return fusion_from_utterances(P, cfg, utt)
+    return fusion_from_utterances(P, cfg, utt, ffn)
 
 
-def fusion_from_utterances(P: Params, cfg, utt) -> SimpleNamespace:
+def fusion_from_utterances(P: Params, cfg, utt, ffn=None) -> SimpleNamespace:
     """Everything of ``forward`` behind the encoders (models.py:216-249): projections, private/shared, discriminator,
     reconstruction, the transformer fusion layer and the heads, from the three utterance vectors {"t","v","a"}."""
     hs = cfg.hidden_size
@@ -287,7 +294,7 @@ def fusion_from_utterances(P: Params, cfg, utt) -> SimpleNamespace:
         setattr(o, f"utt_{m}_recon", _linear(s, P, f"recon_{m}.recon_{m}_1"))
     x = torch.stack((o.utt_private_t, o.utt_private_v, o.utt_private_a,
                      o.utt_shared_t, o.utt_shared_v, o.utt_shared_a), dim=0)
-    hfused = fusion_layer(x, P)
+    hfused = fusion_layer(x, P, ffn)
     o.h = hfused.permute(1, 0, 2).reshape(x.shape[1], 6 * hs)          # == cat(h[0..5], dim=1)
     o.tcp = torch.sigmoid(_linear(o.h, P, "confidence.confidence_layer_1"))
     o.scores = torch.sigmoid(_linear(o.h, P, "classifier.classifier_layer"))
@@ -408,12 +415,12 @@ class AdamState:
                 p.addcdiv_(self.m[k], denom, value=-self.lr / bc1)
 
 
-def loss_and_grads(P: Params, cfg, batch):
+def loss_and_grads(P: Params, cfg, batch, ffn=None):
     """One forward+backward (solver.py:139-183).  Returns (outputs, losses, grads) where grads
     has None for parameters outside the graph (sp_discriminator.*; confidence.* unless
     use_confidNet) exactly as autograd leaves them in the reference."""
     leaves = {k: p.detach().clone().requires_grad_(True) for k, p in P.items()}
-    o = forward(leaves, cfg, batch["t"], batch["v"], batch["a"], batch["l"])
+    o = forward(leaves, cfg, batch["t"], batch["v"], batch["a"], batch["l"], ffn)
     L = all_losses(o, batch["emo"], cfg)
     L.total.backward()
     grads = {k: (None if p.grad is None else p.grad.detach()) for k, p in leaves.items()}

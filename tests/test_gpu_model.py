@@ -543,3 +543,44 @@ def test_degenerate_shapes_against_the_oracle(B, T, precision):
         # bf16: the quantisation floor of these tiny cases is higher than at full size (rounding only the LSTM weights and the
         # inputs to bf16 inside the exact oracle moves vrnn1.weight_ih_l0 by 1.34e-1 at B=8,T=1: eight samples, nothing averages out)
         assert l2 <= (2e-4 if precision == "fp32" else 2e-1), f"{k}: relative L2 error {l2:.3e}"
+
+
+@pytest.mark.parametrize("name,precision", [("real_b8_t12_ragged", "fp32"), ("real_b16_t20_adv_confid", "fp32"), ("real_b32_t50_full", "bf16")])
+def test_fp8_fusion_ffn_matches_its_emulation_and_stays_near_the_exact_path(name, precision):
+    """BASELINE configs[4]: the fusion layer's feed-forward products (linear1 / linear2, models.py:160-161) on block-scaled fp8 MFMA.
+    (1) against the fp8-EMULATING oracle (oracle/fp8_emul.py: same MX quantisation of x1, W1, f1, W2 in the forward products,
+        straight-through backward): outputs within 1e-3, losses within 1e-4, every gradient within 1e-2 relative L2 (fp32 encoders;
+        with bf16 encoders the comparison is against the exact-fusion bf16 run instead, see below);
+    (2) against the exact fp32 oracle: outputs within 2e-2 of their max magnitude and losses within 1e-2 -- the price of 3 mantissa
+        bits in 2 % of the FLOPs; gradients by cosine >= 0.95 (fp8 noise in the FFN weights' own gradients is ~10 %)."""
+    from oracle import fp8_emul as f8
+    from mmda_amd import make_config, MISA
+    z, meta, cfg = load_case(name)
+    P = orc.synth_params(cfg, meta["seed"])
+    batch = batch_of(z)
+    b = to_dev(batch)
+    c = make_config(precision=precision, device=DEV, fusion_fp8=True, **vars(cfg))
+    model = MISA(c); model.load_state_dict(P); model.to(DEV)
+    model.train_step(b["t"], b["v"], b["a"], b["l"], b["emo"], lr=cfg.learning_rate, clip=cfg.clip, do_adam=False, training=False)
+    pub = {k: v.clone() for k, v in model._public().items()}
+    L = model.read_losses()
+    model._assign_grad_views()
+    none = set(meta["none_grads"])
+    if precision == "fp32":
+        o8, L8, G8 = f8.loss_and_grads(P, cfg, batch)
+        assert rel(pub["scores"], o8.scores) < 1e-3 and rel(pub["tcp"], o8.tcp) < 1e-3
+        for k in ("cls", "diff", "sim", "recon", "conf", "total"):
+            ref = float(getattr(L8, k).detach())
+            assert abs(L[k] - ref) < 1e-4 * abs(ref) + 1e-7, (k, L[k], ref)
+        for k, (l2, cos) in _grad_rel_l2(model, G8, cfg, none).items():
+            assert l2 <= 1e-2, f"{k}: relative L2 error vs the fp8-emulating oracle {l2:.3e}"
+    assert rel(pub["scores"], z["out::scores"]) < 2e-2 and rel(pub["tcp"], z["out::tcp"]) < 2e-2
+    for k in ("cls", "diff", "sim", "recon", "conf", "total"):
+        assert abs(L[k] - float(z["loss::" + k])) < 1e-2 * abs(float(z["loss::" + k])), k
+    _, _, G = orc.loss_and_grads(P, cfg, batch)
+    for k, (l2, cos) in _grad_rel_l2(model, G, cfg, none).items():
+        assert cos >= 0.95, f"{k}: cosine {cos:.5f} against the exact oracle"
+    # switching it off again restores the exact feed-forward
+    model.set_fusion_fp8(False)
+    model.train_step(b["t"], b["v"], b["a"], b["l"], b["emo"], lr=cfg.learning_rate, clip=cfg.clip, do_adam=False, training=False)
+    assert rel(model._public()["scores"], z["out::scores"]) < (1e-4 if precision == "fp32" else 1e-2)

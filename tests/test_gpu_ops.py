@@ -974,3 +974,31 @@ def test_allreduce_entry_on_a_single_rank_rccl_communicator():
     finally:
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+# ------------------------------------------------------------------------------------------------ block-scaled fp8 GEMM (configs[4])
+@pytest.mark.parametrize("M,N,K,scale", [(192, 2048, 128, 1.0), (192, 128, 2048, 1.0), (37, 48, 256, 1e-3), (16, 16, 128, 300.0),
+                                         (1536, 128, 2048, 1.0)])
+def test_gemm_mx8_equals_the_product_of_the_quantised_operands(M, N, K, scale):
+    """mmda_gemm_mx8 = exact product (fp32 accumulate) of the OCP-MX e4m3 images of A and B.  The reference computes the image the
+    documented way (oracle/fp8_emul.py: shared exponent floor(log2 amax) - 8 per 32 consecutive k, clamp +-448, round to nearest even
+    onto torch.float8_e4m3fn's grid); agreement to fp32 summation order means the quantiser, the operand packing of
+    v_mfma_scale_f32_16x16x128_f8f6f4 and its scale bytes are all what the header says.  Plus bias / relu epilogue."""
+    from mmda_amd import ops
+    from oracle import fp8_emul as f8
+    torch.manual_seed(M + N + K)
+    A = torch.randn(M, K) * scale
+    A[:, :32] *= 40.0                                   # blocks of very different magnitude in one row
+    A[0, 64:96] = 0.0                                   # an all-zero block
+    Bm = torch.randn(N, K) / math.sqrt(K)
+    b = torch.randn(N)
+    ref = f8.mx_quant(A).double() @ f8.mx_quant(Bm).double().t()
+    # (2e-4 of the largest output, not 1e-5: the matrix core aligns the 128 products of a step to a common exponent before it adds
+    # them, so with blocks of very different magnitude in one dot product the sum is not the sequential fp32 one; measured 6e-5)
+    out = ops.gemm_mx8(A.to(dev()), Bm.to(dev()))
+    assert relerr(out, ref.float()) < 2e-4
+    out2 = ops.gemm_mx8(A.to(dev()), Bm.to(dev()), bias=b.to(dev()), act="relu")
+    assert relerr(out2, torch.relu(ref.float() + b)) < 2e-4
+    # and the quantisation itself is what fp8 promises: a few percent per element, well under it per dot product
+    exact = A.double() @ Bm.double().t()
+    assert float((ref - exact).norm() / exact.norm()) < 6e-2
