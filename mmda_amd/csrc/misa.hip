@@ -67,6 +67,9 @@ struct mmda_misa {
   int64_t d_scores, d_tcp, d_x6, d_orig, d_recon, d_dom, d_logits, d_hfused, d_x1, d_f2, d_f1, d_attn_out, d_ctx, d_qkv, d_z,
       d_dom_h, d_dom_z;
   // block-scaled fp8 operands of the feed-forward products (fusion_fp8): element bytes and scale bytes, as float offsets
+  // fused train step without a gradient exchange: clamp+Adam of the bucket prefix whose gradients are final beside the layer-1 backward
+  // recurrence runs there, on the side stream (set by mmda_misa_train_step around its backward pass)
+  int adam_early_on = 0; float ae_lr = 0.f, ae_clip = 0.f; int ae_step = 0; int64_t adam_early_done = 0;
   int fusion_fp8 = 0;
   int64_t x1q, x1s, w1q, w1s, f1q, f1s, w2q, w2s;
   // state of the last forward (dropout replay in backward)
@@ -1389,9 +1392,11 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
         lb[i].rows = R; lb[i].n = 2 * md.H; lb[i].dy = WS(md.d_normed); lb[i].x = WS(md.hseq[0]); lb[i].gamma = PP(md.ln_w);
         lb[i].mean = WS(md.ln_mean); lb[i].rstd = WS(md.ln_rstd); lb[i].d_x = WS(md.d_hseq1);
       }
+      // (the input-gradient launch goes out BEFORE the fork: it reads the LayerNorm weights, which the early optimizer step below may
+      // update on the side stream -- the fork orders the side stream behind it)
+      x.rc = mmda_layernorm_bwd_multi(lb, 3, stream);
       void* ss = nullptr;
-      x.rc = side_fork(m, stream, &ss);
-      if (!x.rc) x.rc = mmda_layernorm_bwd_multi(lb, 3, stream);
+      if (!x.rc) x.rc = side_fork(m, stream, &ss);
       for (int i = 0; i < 3; ++i) { lb[i].dgamma = GG(m->mod[i].ln_w); lb[i].dbeta = GG(m->mod[i].ln_b); lb[i].d_x = nullptr; }
       if (!x.rc && dg_on_side) x.rc = mmda_convert_bf16(dgj, 3, ss);
       if (!x.rc) x.rc = mmda_layernorm_param_grads(lb, 3, ss);
@@ -1407,6 +1412,14 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
         if (!x.rc && hipEventRecord(m->ev_early, (hipStream_t)ss) != hipSuccess) x.rc = MMDA_ELAUNCH;
         m->early_floats = (l2_early && !is_gru(m) && mode == MMDA_BF16 && m->use_bf16_gemm) ? m->rnn1_begin : m->rnn2_begin;
         m->early_valid = 1;
+        // Single-GPU fused step: clip + Adam of that prefix right here, beside the layer-1 recurrence (nothing issued after this
+        // point reads those fp32 parameters: the remaining GEMMs of a bf16 step read bf16 copies made in the forward pass, and in
+        // the other modes the prefix ends in front of the recurrent layers).  The side stream is a real second stream only when
+        // use_side is on; otherwise this is simply the same work in front of the recurrence.
+        if (!x.rc && m->adam_early_on && m->early_floats > 0 && m->M1 && m->V1) {
+          x.rc = mmda_clamp_adam(m->P, m->G, m->M1, m->V1, m->early_floats, m->ae_lr, 0.9f, 0.999f, 1e-8f, m->ae_clip, 1.0f, m->ae_step, ss);
+          if (!x.rc) m->adam_early_done = m->early_floats;
+        }
       }
     } else if (!x.rc) {
       // text: gradient w.r.t. the embedding rows, scattered densely into embed.weight.grad (sparse=False)
@@ -1484,8 +1497,15 @@ extern "C" int mmda_misa_train_step(mmda_misa* m, const int64_t* t_ids, const fl
   if (m->zero_grad_pending) return MMDA_ELAUNCH;        // forward() always reaches its fusion block
   rc = mmda_misa_losses(m, emo, 1, stream);
   if (rc) return rc;
+  static const int adam_split = getenv("MMDA_ADAM_SPLIT") ? atoi(getenv("MMDA_ADAM_SPLIT")) : 1;     // 0: ablation (one launch at the end)
+  m->adam_early_on = (do_adam && adam_split) ? 1 : 0; m->ae_lr = lr; m->ae_clip = clip; m->ae_step = step; m->adam_early_done = 0;
   rc = mmda_misa_backward(m, t_ids, v, a, lengths, stream);
+  m->adam_early_on = 0;
   if (rc) return rc;
-  if (do_adam) rc = mmda_misa_adam_step(m, lr, clip, 1.0f, step, stream);
+  if (do_adam) {
+    // the rest of the bucket (layer-1 recurrent layers, embedding -- or everything, if the backward pass stepped nothing early)
+    const int64_t o = m->adam_early_done;
+    rc = mmda_clamp_adam(m->P + o, m->G + o, m->M1 + o, m->V1 + o, m->flat - o, lr, 0.9f, 0.999f, 1e-8f, clip, 1.0f, step, stream);
+  }
   return rc;
 }
