@@ -47,8 +47,12 @@ __device__ __forceinline__ u32x4 ld_chunk(const unsigned short* base, int row, i
 // global prefetch.  128 x 128 when the output alone fills the chip; 64 x 64 for the long-K / small-output gradient GEMMs,
 // where four times as many workgroups matter more than operand reuse.
 template <int T>
-__device__ __forceinline__ void gemm_bf16_tile(const mmda_gemm_bf16_args& g, int splitk, int bx, int by, int sp, unsigned short* As,
-                                               unsigned short* Bs) {
+__device__ __forceinline__ void gemm_bf16_tile(const mmda_gemm_bf16_args& g, int splitk, int bx, int by, int sp, unsigned short* AB) {
+  // two LDS buffers of (A block | B block): k-tile kt is computed out of buffer kt & 1 while tile kt + 1 is being stored into the
+  // other one -- ONE workgroup barrier per k-tile, and the LDS stores (ds_write_b128 runs at a third of the read rate) sit beside
+  // the other waves' MFMAs instead of between two barriers
+  constexpr int BUF = 2 * T * LDT;
+  unsigned short* As = AB;                   // (the epilogue stages the C tile over the first buffer)
   constexpr int W = T / 32;                  // MFMA tiles per wave per dimension
   constexpr int CH = T / 32;                 // 16-B chunks per thread per operand and k-tile (T rows x 8 chunks / 256 threads)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -66,8 +70,11 @@ __device__ __forceinline__ void gemm_bf16_tile(const mmda_gemm_bf16_args& g, int
 #pragma unroll
     for (int j = 0; j < W; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // staging: T rows x 64 k = T*8 chunks of 8 bf16 per operand; chunk c: row = c >> 3, k = (c & 7) * 8
-  u32x4 ra[2][CH], rb[2][CH];
+  // staging: T rows x 64 k = T*8 chunks of 8 bf16 per operand; chunk c: row = c >> 3, k = (c & 7) * 8.  NS register stages of global
+  // prefetch: these problems leave one to four workgroups on a CU, so what hides the memory latency is loads in flight, not
+  // occupancy -- two stages for the 128-tile (32 registers each), four for the 64-tile (16 each).
+  constexpr int NS = T == 128 ? 2 : 4;
+  u32x4 ra[NS][CH], rb[NS][CH];
   auto load_tile = [&](u32x4 (&a)[CH], u32x4 (&b)[CH], int k0) {
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
@@ -80,7 +87,9 @@ __device__ __forceinline__ void gemm_bf16_tile(const mmda_gemm_bf16_args& g, int
   // the virtual all-ones row n == N of B (bias gradient) is written straight into the LDS tile that holds column N: it never
   // touches the global-load path (a lane-dependent branch there serialises the loads behind s_waitcnt vmcnt(0))
   const bool tile_has_ones = ones_row && col0 <= N && N < col0 + T;       // block-uniform
-  auto store_tile = [&](const u32x4 (&a)[CH], const u32x4 (&b)[CH], int k0) {
+  auto store_tile = [&](const u32x4 (&a)[CH], const u32x4 (&b)[CH], int k0, int buf) {
+    unsigned short* As = AB + buf * BUF;
+    unsigned short* Bs = As + T * LDT;
     const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
@@ -108,9 +117,12 @@ __device__ __forceinline__ void gemm_bf16_tile(const mmda_gemm_bf16_args& g, int
   if (kt0 >= nk) return;
   const int fr = lane & 15, fq = lane >> 4;
 
-  load_tile(ra[0], rb[0], kt0 * TK);
-  if (kt0 + 1 < nk) load_tile(ra[1], rb[1], (kt0 + 1) * TK);
-  auto compute = [&]() {
+#pragma unroll
+  for (int u = 0; u < NS; ++u)
+    if (kt0 + u < nk) load_tile(ra[u], rb[u], (kt0 + u) * TK);
+  auto compute = [&](int buf) {
+    const unsigned short* As = AB + buf * BUF;
+    const unsigned short* Bs = As + T * LDT;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 a[W], b[W];
@@ -125,19 +137,24 @@ __device__ __forceinline__ void gemm_bf16_tile(const mmda_gemm_bf16_args& g, int
         for (int j = 0; j < W; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   };
-  // unrolled by two so that the two register stages are addressed statically
-  for (int kt = kt0; kt < nk; kt += 2) {
-    __syncthreads();
-    store_tile(ra[0], rb[0], kt * TK);
-    __syncthreads();
-    if (kt + 2 < nk) load_tile(ra[0], rb[0], (kt + 2) * TK);
-    compute();
-    if (kt + 1 < nk) {
-      __syncthreads();
-      store_tile(ra[1], rb[1], (kt + 1) * TK);
-      __syncthreads();
-      if (kt + 3 < nk) load_tile(ra[1], rb[1], (kt + 3) * TK);
-      compute();
+  // Unrolled by NS (even) so that register stages and LDS buffers are addressed statically: tile kt0 + u sits in stage u % NS and is
+  // computed out of buffer u & 1.  Each round: store tile kt + 1 into the other buffer (last read for tile kt - 1, behind the
+  // previous barrier), refill its stage with tile kt + 1 + NS, compute tile kt, barrier.
+  store_tile(ra[0], rb[0], kt0 * TK, 0);
+  if (kt0 + NS < nk) load_tile(ra[0], rb[0], (kt0 + NS) * TK);
+  __syncthreads();
+  for (int kt = kt0; kt < nk; kt += NS) {
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      if (kt + u < nk) {                                   // block-uniform
+        const int nx = (u + 1) % NS;
+        if (kt + u + 1 < nk) {
+          store_tile(ra[nx], rb[nx], (kt + u + 1) * TK, (u + 1) & 1);
+          if (kt + u + 1 + NS < nk) load_tile(ra[nx], rb[nx], (kt + u + 1 + NS) * TK);
+        }
+        compute(u & 1);
+        __syncthreads();
+      }
     }
   }
 
@@ -257,7 +274,7 @@ __device__ __forceinline__ void gemm_bf16_tile(const mmda_gemm_bf16_args& g, int
 // GEMMs that use it are bound by per-k-tile latency -- more resident workgroups per CU is what hides it.
 template <int T>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(Bf16Group G) {
-  __shared__ __attribute__((aligned(16))) unsigned short AB[2 * T * LDT];       // A block | B block (the C tile is staged over both)
+  __shared__ __attribute__((aligned(16))) unsigned short AB[2 * 2 * T * LDT];   // two buffers of (A block | B block); the C tile is staged over the first
   int pi = 0;
 #pragma unroll
   for (int k = 1; k < GROUP_MAX; ++k)
@@ -266,7 +283,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(Bf16Group G) {
   const int splitk = G.splitk[pi];
   const int local = blockIdx.x - G.start[pi];
   const int bx = local % G.tx[pi], by = (local / G.tx[pi]) % G.ty[pi], sp = local / (G.tx[pi] * G.ty[pi]);
-  gemm_bf16_tile<T>(g, splitk, bx, by, sp, AB, AB + T * LDT);
+  gemm_bf16_tile<T>(g, splitk, bx, by, sp, AB);
 }
 
 // ------------------------------------------------------------------------------------------------ conversion
@@ -486,6 +503,14 @@ extern "C" int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, vo
         while (sk > 1 && sk * out_mb > 6.0) --sk;
         if (sk > 16) sk = 16;
         if (sk < 1) sk = 1;
+      } else if (tiles < 1024 && nk >= 64) {
+        // a long k-walk (the weight-gradient GEMMs of a large batch: K = T * B) on fewer workgroups than the chip holds (four per CU):
+        // every k-tile is one memory latency, so the walk is cut until the slots are full -- while the atomic combine stays a small
+        // part of the walk it shortens (added bytes at ~1.3 TB/s against ~0.7 us per k-tile saved)
+        static const int long_k = getenv("MMDA_GEMM_LONGK_SPLIT") ? atoi(getenv("MMDA_GEMM_LONGK_SPLIT")) : 1;
+        const double out_mb = (double)a.M * a.N * 4.0 / 1048576.0;
+        sk = long_k ? ceil_div(1024, tiles) : 1;
+        while (sk > 1 && (nk / sk < 16 || sk * out_mb > 24.0)) --sk;
       }
       // a fresh (non-accumulated) output has to be cleared by a launch of its own before the slices can add into it: only worth
       // it for a long K loop in a launch that would otherwise leave the chip underfilled
