@@ -42,6 +42,15 @@ extern "C" {
 #define MMDA_ACT_ELU 5
 #define MMDA_ACT_HARDTANH 6
 #define MMDA_ACT_HARDSHRINK 7
+#define MMDA_ACT_PRELU 8          /* nn.PReLU(): x > 0 ? x : a x with ONE learned slope a (mmda_act_params.slope) */
+#define MMDA_ACT_RRELU 9          /* nn.RReLU(): x >= 0 ? x : s x; training: s ~ U(lo, hi) per element, else s = (lo + hi) / 2 */
+/* Parameters of the two parametrised activations of the reference's activation_dict (config.py:25-27); ignored by the others.
+ * slope / dslope: device pointers to the PReLU slope and (backward) its gradient, accumulated with one atomic per row.
+ * rand != 0 (training): the RReLU slope of element idx is lo + (hi - lo) * u(seed, site, idx), regenerated in the backward pass. */
+typedef struct mmda_act_params {
+  const float* slope; float* dslope;
+  float lo, hi; int rand; uint64_t seed; int site;
+} mmda_act_params;
 
 const char* mmda_last_error(void);
 int mmda_abi_version(void);
@@ -198,6 +207,7 @@ typedef struct mmda_ln_args {
   float drop_p; uint64_t drop_seed; int drop_site;   /* dropout on res */
   int permute_S, permute_B;                     /* 0,0 = no permutation */
   float eps;
+  mmda_act_params actp;                         /* act = MMDA_ACT_PRELU / MMDA_ACT_RRELU only */
 } mmda_ln_args;
 int mmda_layernorm_fwd(const mmda_ln_args* a, void* stream);
 /* backward: dx_pre = LN'(dy); outputs: d_x = dx_pre * act'(x) (written or accumulated), d_res = dx_pre*dropmask,
@@ -210,6 +220,7 @@ typedef struct mmda_ln_bwd_args {
   float* dgamma; float* dbeta;                  /* accumulated with atomics */
   int act; float drop_p; uint64_t drop_seed; int drop_site;
   int permute_S, permute_B;
+  mmda_act_params actp;                         /* act = MMDA_ACT_PRELU / MMDA_ACT_RRELU only (dslope accumulated when d_x is written) */
 } mmda_ln_bwd_args;
 int mmda_layernorm_bwd(const mmda_ln_bwd_args* a, void* stream);
 /* Several independent LayerNorms in one launch (the three modalities'): results as n single calls. */
@@ -321,6 +332,11 @@ int mmda_sigmoid_bwd_inplace(float* d, const float* y, int64_t n, void* stream);
 int mmda_act_dropout_fwd(const float* z, float* h, int64_t n, int act, float drop_p, uint64_t seed, int site, void* stream);
 int mmda_act_dropout_bwd(const float* dh, const float* z, float* dz, int64_t n, int act, float drop_p, uint64_t seed, int site,
                          void* stream);
+/* the same for the parametrised activations (MMDA_ACT_PRELU / MMDA_ACT_RRELU): parameters in *ap (host struct, copied) */
+int mmda_act_dropout_fwd_p(const float* z, float* h, int64_t n, int act, const mmda_act_params* ap, float drop_p, uint64_t seed, int site,
+                           void* stream);
+int mmda_act_dropout_bwd_p(const float* dh, const float* z, float* dz, int64_t n, int act, const mmda_act_params* ap, float drop_p,
+                           uint64_t seed, int site, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- heads + losses
  * logits12 (B,12) = h [W_conf;W_cls]^T + b.  tcp = sigmoid(logits[:, :6]); scores = sigmoid(dropout(logits[:,6:]));

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmmda_hip.so")
 
 F32, BF16 = 0, 1
-ACT = {"none": 0, "relu": 1, "sigmoid": 2, "leakyrelu": 3, "tanh": 4, "elu": 5, "hardtanh": 6, "hardshrink": 7}
+ACT = {"none": 0, "relu": 1, "sigmoid": 2, "leakyrelu": 3, "tanh": 4, "elu": 5, "hardtanh": 6, "hardshrink": 7, "prelu": 8, "rrelu": 9}
 
 c_f32p = C.c_void_p      # device pointers travel as integers
 c_stream = C.c_void_p
@@ -59,11 +59,16 @@ class TransposeJob(C.Structure):
     _fields_ = [("src", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("ld", C.c_int), ("dst", C.c_void_p), ("ldd", C.c_int)]
 
 
+class ActParams(C.Structure):
+    _fields_ = [("slope", C.c_void_p), ("dslope", C.c_void_p), ("lo", C.c_float), ("hi", C.c_float), ("rand", C.c_int),
+                ("seed", C.c_uint64), ("site", C.c_int)]
+
+
 class LnArgs(C.Structure):
     _fields_ = [("rows", C.c_int), ("n", C.c_int), ("x", C.c_void_p), ("res", C.c_void_p), ("gamma", C.c_void_p),
                 ("beta", C.c_void_p), ("y", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("act", C.c_int),
                 ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_site", C.c_int),
-                ("permute_S", C.c_int), ("permute_B", C.c_int), ("eps", C.c_float)]
+                ("permute_S", C.c_int), ("permute_B", C.c_int), ("eps", C.c_float), ("actp", ActParams)]
 
 
 class LnBwdArgs(C.Structure):
@@ -72,7 +77,7 @@ class LnBwdArgs(C.Structure):
                 ("d_x", C.c_void_p), ("accumulate_dx", C.c_int), ("d_res", C.c_void_p),
                 ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
                 ("act", C.c_int), ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_site", C.c_int),
-                ("permute_S", C.c_int), ("permute_B", C.c_int)]
+                ("permute_S", C.c_int), ("permute_B", C.c_int), ("actp", ActParams)]
 
 
 class LstmDesc(C.Structure):
@@ -152,6 +157,8 @@ SIGNATURES = {
     "mmda_sigmoid_bwd_inplace": (_I, [_P, _P, _I64, _P]),
     "mmda_act_dropout_fwd": (_I, [_P, _P, _I64, _I, _F, _U64, _I, _P]),
     "mmda_act_dropout_bwd": (_I, [_P, _P, _P, _I64, _I, _F, _U64, _I, _P]),
+    "mmda_act_dropout_fwd_p": (_I, [_P, _P, _I64, _I, C.POINTER(ActParams), _F, _U64, _I, _P]),
+    "mmda_act_dropout_bwd_p": (_I, [_P, _P, _P, _I64, _I, C.POINTER(ActParams), _F, _U64, _I, _P]),
     "mmda_heads_fwd": (_I, [_P, _I, _I, _F, _P, _P, _P, _F, _U64, _I, _P]),
     "mmda_heads_bwd": (_I, [_P, _P, _P, _P, _I, _I, _P, _F, _U64, _I, _P]),
     "mmda_loss_cls": (_I, [_P, _P, _I, _I, _F, _P, _P, _P]),

@@ -9,8 +9,7 @@ from __future__ import annotations
 import argparse
 from datetime import datetime
 
-ACTIVATIONS = ("elu", "hardshrink", "hardtanh", "leakyrelu", "relu", "tanh")   # prelu / rrelu: not supported
-UNSUPPORTED_ACTIVATIONS = ("prelu", "rrelu")
+ACTIVATIONS = ("elu", "hardshrink", "hardtanh", "leakyrelu", "prelu", "relu", "rrelu", "tanh")      # reference config.py:25-27
 
 
 def str2bool(v):
@@ -49,8 +48,6 @@ def activation_name(act) -> str:
     else:
         cls = act if isinstance(act, type) else type(act)
         name = cls.__name__.lower()
-    if name in UNSUPPORTED_ACTIVATIONS:
-        raise NotImplementedError(f"activation '{name}' is not supported by the HIP path (learned/random slope)")
     if name not in ACTIVATIONS:
         raise ValueError(f"unknown activation '{name}'")
     return name

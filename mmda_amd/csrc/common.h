@@ -108,3 +108,20 @@ __device__ __forceinline__ float act_bwd(int act, float x) {
     default: return 1.f;
   }
 }
+
+// ---- parametrised activations (nn.PReLU / nn.RReLU of the reference's activation_dict, config.py:25-27)
+__device__ __forceinline__ float act_slope_p(int act, const mmda_act_params& p, uint64_t idx) {
+  if (act == MMDA_ACT_PRELU) return p.slope[0];
+  if (!p.rand) return 0.5f * (p.lo + p.hi);
+  const float u = (float)(rng_u32(p.seed, p.site, idx) >> 8) * (1.0f / 16777216.0f);
+  return p.lo + (p.hi - p.lo) * u;
+}
+__device__ __forceinline__ bool act_is_p(int act) { return act == MMDA_ACT_PRELU || act == MMDA_ACT_RRELU; }
+__device__ __forceinline__ float act_fwd_p(int act, float x, const mmda_act_params& p, uint64_t idx) {
+  if (!act_is_p(act)) return act_fwd(act, x);
+  return x > 0.f ? x : act_slope_p(act, p, idx) * x;
+}
+__device__ __forceinline__ float act_bwd_p(int act, float x, const mmda_act_params& p, uint64_t idx) {
+  if (!act_is_p(act)) return act_bwd(act, x);
+  return x > 0.f ? 1.f : act_slope_p(act, p, idx);
+}

@@ -35,7 +35,8 @@ struct Mod {           // one modality: two stacked biLSTMs with a LayerNorm bet
   int64_t x, gates[2], c[2], hseq[2], normed, ln_mean, ln_rstd, utt, d_utt, d_hseq1, d_normed, d_x, xchg, xchg_floats;
 };
 
-enum { SITE_ATTN = 1, SITE_DROP1 = 2, SITE_FFN = 3, SITE_DROP2 = 4, SITE_CLS = 5, SITE_DISC = 6 };
+enum { SITE_ATTN = 1, SITE_DROP1 = 2, SITE_FFN = 3, SITE_DROP2 = 4, SITE_CLS = 5, SITE_DISC = 6,
+       SITE_RRELU = 7 /* .. 9: the three projections' random slopes */, SITE_RRELU_DISC = 10 };
 constexpr int FFN = 2048, NHEAD = 2, S6 = 6;
 
 }  // namespace
@@ -53,6 +54,7 @@ struct mmda_misa {
   int64_t priv_w, priv_b, sh_w, sh_b, rec_w, rec_b, d1_w = -1, d1_b = -1, d2_w = -1, d2_b = -1, sp_w, sp_b;
   int64_t head_w, head_b, embed;
   int64_t in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w, l2_b, n1_w, n1_b, n2_w, n2_b;
+  int64_t prelu_a = -1;                      // config.activation = prelu: the ONE learned slope (nn.PReLU() shared by every use, models.py:30)
   float *P = nullptr, *G = nullptr, *M1 = nullptr, *V1 = nullptr;
   // workspace
   float* ws = nullptr; int64_t ws_floats = 0; int B = 0, T = 0;
@@ -170,6 +172,7 @@ void build_params(mmda_misa* m) {
   m->n1_b = add_param(m, te + "norm1.bias", hs, 0);
   m->n2_w = add_param(m, te + "norm2.weight", hs, 0);
   m->n2_b = add_param(m, te + "norm2.bias", hs, 0);
+  if (c.act == MMDA_ACT_PRELU) m->prelu_a = add_param(m, "activation.weight", 1, 0);      // last of the block: what follows is re-aligned
   for (int l = 1; l >= 0; --l) {
     m->flat = (m->flat + 3) & ~(int64_t)3;
     (l == 1 ? m->rnn2_begin : m->rnn1_begin) = m->flat;
@@ -459,6 +462,14 @@ int gru_jobs(mmda_misa* m, float* base, bool grads, mmda_gru_pad_job* j) {
       j[n].pb_hh = grads ? nullptr : WS(r.pb_hh);
     }
   return n;
+}
+
+// parameters of a parametrised activation (prelu / rrelu) at one of its uses; zeros for every other activation
+mmda_act_params act_params(mmda_misa* m, int training, uint64_t seed, int site, bool grads) {
+  mmda_act_params p = {};
+  if (m->cfg.act == MMDA_ACT_PRELU) { p.slope = m->P + m->prelu_a; p.dslope = grads ? m->G + m->prelu_a : nullptr; }
+  if (m->cfg.act == MMDA_ACT_RRELU) { p.lo = 1.0f / 8.0f; p.hi = 1.0f / 3.0f; p.rand = training ? 1 : 0; p.seed = seed; p.site = site; }   // torch defaults
+  return p;
 }
 
 int check_ready(const mmda_misa* m) {
@@ -890,7 +901,7 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
       ln[i] = mmda_ln_args{};
       ln[i].rows = B; ln[i].n = hs; ln[i].x = WS(m->z + i * BH); ln[i].gamma = PP(md.plw); ln[i].beta = PP(md.plb);
       ln[i].y = WS(m->orig + i * BH); ln[i].mean = WS(m->pmean + i * B); ln[i].rstd = WS(m->prstd + i * B); ln[i].act = c.act;
-      ln[i].eps = 1e-5f;
+      ln[i].eps = 1e-5f; ln[i].actp = act_params(m, training, seed, SITE_RRELU + i, false);
     }
     sk_launch(x, g, 3);
     if (!x.rc) x.rc = mmda_layernorm_fwd_multi(ln, 3, stream);
@@ -912,7 +923,10 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
     if (!c.use_cmd_sim) g[n++] = sk_nt(3 * B, hs, hs, WS(m->x6 + 3 * BH), hs, PP(m->d1_w), PP(m->d1_b), WS(m->dom_z), hs);
     sk_launch(x, g, n);
     if (!c.use_cmd_sim && !x.rc)
-      x.rc = mmda_act_dropout_fwd(WS(m->dom_z), WS(m->dom_h), 3 * BH, c.act, p_cls, seed, SITE_DISC, stream);
+      {
+      const mmda_act_params ap = act_params(m, training, seed, SITE_RRELU_DISC, false);
+      x.rc = mmda_act_dropout_fwd_p(WS(m->dom_z), WS(m->dom_h), 3 * BH, c.act, &ap, p_cls, seed, SITE_DISC, stream);
+    }
     if (!x.rc) x.rc = mmda_attn_fwd(WS(m->qkv), S6, B, hs, NHEAD, WS(m->ctx), WS(m->probs), p_tf, seed, SITE_ATTN, stream);
     n = 0;
     g[n++] = sk_nt(6 * B, hs, hs, WS(m->ctx), hs, PP(m->out_w), PP(m->out_b), WS(m->attn_out), hs);
@@ -955,6 +969,7 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
       mmda_ln_args ln = {};
       ln.rows = B; ln.n = hs; ln.x = WS(m->z + i * BH); ln.gamma = PP(md.plw); ln.beta = PP(md.plb); ln.y = WS(m->orig + i * BH);
       ln.mean = WS(m->pmean + i * B); ln.rstd = WS(m->prstd + i * B); ln.act = c.act; ln.eps = 1e-5f;
+      ln.actp = act_params(m, training, seed, SITE_RRELU + i, false);
       x.rc = mmda_layernorm_fwd(&ln, stream);
     }
     // private (three weights, batched) and shared (one weight over the stacked 3B rows), sigmoid epilogue
@@ -970,7 +985,10 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
     // adversarial discriminator behind the gradient-reversal layer (models.py:219-227); identity in forward
     if (!c.use_cmd_sim) {
       lin_fwd(x, fmode, 3 * B, hs, hs, WS(m->x6 + 3 * BH), PP(m->d1_w), PP(m->d1_b), WS(m->dom_z));
-      if (!x.rc) x.rc = mmda_act_dropout_fwd(WS(m->dom_z), WS(m->dom_h), 3 * BH, c.act, p_cls, seed, SITE_DISC, stream);
+      if (!x.rc) {
+      const mmda_act_params ap = act_params(m, training, seed, SITE_RRELU_DISC, false);
+      x.rc = mmda_act_dropout_fwd_p(WS(m->dom_z), WS(m->dom_h), 3 * BH, c.act, &ap, p_cls, seed, SITE_DISC, stream);
+    }
       lin_fwd(x, fmode, 3 * B, 3, hs, WS(m->dom_h), PP(m->d2_w), PP(m->d2_b), WS(m->dom));
     }
     // 1-layer transformer fusion over the six tokens (models.py:243-245; torch post-norm encoder layer)
@@ -1125,7 +1143,10 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
     // adversarial branch: discriminator grads, then the REVERSED gradient into the shared codes (functions.py:17-21)
     if (!c.use_cmd_sim) {
       lin_dw(x, fmode, 3 * B, 3, hs, WS(m->d_dom), WS(m->dom_h), GG(m->d2_w), GG(m->d2_b));
-      if (!x.rc) x.rc = mmda_act_dropout_bwd(WS(m->d_dom_h), WS(m->dom_z), WS(m->d_dom_z), 3 * BH, c.act, p_cls, seed, SITE_DISC, stream);
+      if (!x.rc) {
+        const mmda_act_params ap = act_params(m, training, seed, SITE_RRELU_DISC, true);
+        x.rc = mmda_act_dropout_bwd_p(WS(m->d_dom_h), WS(m->dom_z), WS(m->d_dom_z), 3 * BH, c.act, &ap, p_cls, seed, SITE_DISC, stream);
+      }
       lin_dw(x, fmode, 3 * B, hs, hs, WS(m->d_dom_z), WS(m->x6 + 3 * BH), GG(m->d1_w), GG(m->d1_b));
       g[0] = wt ? sk_dx(3 * B, hs, hs, WS(m->d_dom_z), hs, WS(m->d1_wT), WS(m->d_x6 + 3 * BH), hs, 1)
                 : sk_nn(3 * B, hs, hs, WS(m->d_dom_z), hs, PP(m->d1_w), WS(m->d_x6 + 3 * BH), hs, 1);
@@ -1172,6 +1193,7 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
         l[i].rows = B; l[i].n = hs; l[i].dy = WS(m->d_orig + i * BH); l[i].x = WS(m->z + i * BH); l[i].gamma = PP(md.plw);
         l[i].mean = WS(m->pmean + i * B); l[i].rstd = WS(m->prstd + i * B); l[i].d_x = WS(m->d_z + i * BH);
         l[i].dgamma = GG(md.plw); l[i].dbeta = GG(md.plb); l[i].act = c.act;
+        l[i].actp = act_params(m, training, seed, SITE_RRELU + i, true);
       }
       x.rc = mmda_layernorm_bwd_multi(l, 3, stream);
     }
@@ -1223,7 +1245,10 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
     if (!c.use_cmd_sim) {
       lin_dx(x, fmode, 3 * B, 3, hs, WS(m->d_dom), PP(m->d2_w), WS(m->d_dom_h), 0);
       lin_dw(x, fmode, 3 * B, 3, hs, WS(m->d_dom), WS(m->dom_h), GG(m->d2_w), GG(m->d2_b));
-      if (!x.rc) x.rc = mmda_act_dropout_bwd(WS(m->d_dom_h), WS(m->dom_z), WS(m->d_dom_z), 3 * BH, c.act, p_cls, seed, SITE_DISC, stream);
+      if (!x.rc) {
+        const mmda_act_params ap = act_params(m, training, seed, SITE_RRELU_DISC, true);
+        x.rc = mmda_act_dropout_bwd_p(WS(m->d_dom_h), WS(m->dom_z), WS(m->d_dom_z), 3 * BH, c.act, &ap, p_cls, seed, SITE_DISC, stream);
+      }
       lin_dw(x, fmode, 3 * B, hs, hs, WS(m->d_dom_z), WS(m->x6 + 3 * BH), GG(m->d1_w), GG(m->d1_b));
       mmda_gemm_args e = {};
       e.alpha = -c.reverse_grad_weight;
@@ -1257,6 +1282,7 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
       l.rows = B; l.n = hs; l.dy = WS(m->d_orig + i * BH); l.x = WS(m->z + i * BH); l.gamma = PP(md.plw);
       l.mean = WS(m->pmean + i * B); l.rstd = WS(m->prstd + i * B); l.d_x = WS(m->d_z + i * BH);
       l.dgamma = GG(md.plw); l.dbeta = GG(md.plb); l.act = c.act;
+      l.actp = act_params(m, training, seed, SITE_RRELU + i, true);
       x.rc = mmda_layernorm_bwd(&l, stream);
       lin_dx(x, fmode, B, hs, 4 * md.H, WS(m->d_z + i * BH), PP(md.pw), WS(md.d_utt), 0);
       lin_dw(x, fmode, B, hs, 4 * md.H, WS(m->d_z + i * BH), WS(md.utt), GG(md.pw), GG(md.pb));

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnMulti L) {
     float x = 0.f;
     if (i < n) {
       int64_t idx = (int64_t)row * n + i;
-      x = act_fwd(a.act, a.x[idx]);
+      x = act_fwd_p(a.act, a.x[idx], a.actp, (uint64_t)idx);
       if (a.res) x += a.res[idx] * drop_mul(a.drop_p, a.drop_seed, a.drop_site, (uint64_t)idx);
     }
     v[q] = x;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdMulti L) {
       xh[q] = 0.f; gdy[q] = 0.f;
       if (i < n) {
         int64_t idx = (int64_t)row * n + i;
-        float x = act_fwd(a.act, a.x[idx]);
+        float x = act_fwd_p(a.act, a.x[idx], a.actp, (uint64_t)idx);
         if (a.res) x += a.res[idx] * drop_mul(a.drop_p, a.drop_seed, a.drop_site, (uint64_t)idx);
         float dy = a.dy[drow * n + i];
         xh[q] = (x - mean) * rstd;
@@ -105,6 +105,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdMulti L) {
     }
     s1 = wave_sum(s1) / n;
     s2 = wave_sum(s2) / n;
+    float dslope = 0.f;                                  // PReLU: d(slope) = sum of dx_pre * z over the elements with z <= 0
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       int i = lane + 64 * q;
@@ -112,11 +113,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdMulti L) {
         int64_t idx = (int64_t)row * n + i;
         float dxp = rstd * (gdy[q] - s1 - xh[q] * s2);
         if (a.d_x) {
-          float d = dxp * act_bwd(a.act, a.x[idx]);
+          const float z = a.x[idx];
+          float d = dxp * act_bwd_p(a.act, z, a.actp, (uint64_t)idx);
           a.d_x[idx] = a.accumulate_dx ? a.d_x[idx] + d : d;
+          if (a.act == MMDA_ACT_PRELU && z <= 0.f) dslope += dxp * z;
         }
         if (a.d_res) a.d_res[idx] = dxp * drop_mul(a.drop_p, a.drop_seed, a.drop_site, (uint64_t)idx);
       }
+    }
+    if (a.act == MMDA_ACT_PRELU && a.d_x && a.actp.dslope) {       // problem-uniform
+      dslope = wave_sum(dslope);
+      if (lane == 0) atomicAdd(a.actp.dslope, dslope);
     }
   }
   if (!want_pg) return;            // block-uniform: parameter gradients come from mmda_layernorm_param_grads instead
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(256) void ln_param_grads_kernel(LnBwdMulti L) {
     const float mean = a.mean[row], rstd = a.rstd[row];
     const int64_t drow = perm_row(row, a.permute_S, a.permute_B);
     const int64_t idx = (int64_t)row * n + ic;
-    float x = act_fwd(a.act, a.x[idx]);
+    float x = act_fwd_p(a.act, a.x[idx], a.actp, (uint64_t)idx);
     if (a.res) x += a.res[idx] * drop_mul(a.drop_p, a.drop_seed, a.drop_site, (uint64_t)idx);
     const float dy = a.dy[drow * n + ic];
     dg += dy * (x - mean) * rstd;
@@ -200,13 +207,24 @@ __global__ void sigmoid_bwd_kernel(float* d, const float* y, int64_t n) {
   }
 }
 
-__global__ void act_drop_fwd_kernel(const float* z, float* h, int64_t n, int act, float p, uint64_t seed, int site) {
+__global__ void act_drop_fwd_kernel(const float* z, float* h, int64_t n, int act, mmda_act_params ap, float p, uint64_t seed, int site) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    h[i] = act_fwd(act, z[i]) * drop_mul(p, seed, site, (uint64_t)i);
+    h[i] = act_fwd_p(act, z[i], ap, (uint64_t)i) * drop_mul(p, seed, site, (uint64_t)i);
 }
-__global__ void act_drop_bwd_kernel(const float* dh, const float* z, float* dz, int64_t n, int act, float p, uint64_t seed, int site) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    dz[i] = dh[i] * drop_mul(p, seed, site, (uint64_t)i) * act_bwd(act, z[i]);
+__global__ __launch_bounds__(256) void act_drop_bwd_kernel(const float* dh, const float* z, float* dz, int64_t n, int act, mmda_act_params ap,
+                                                           float p, uint64_t seed, int site) {
+  __shared__ float red[16];
+  float dslope = 0.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float g = dh[i] * drop_mul(p, seed, site, (uint64_t)i);
+    const float zi = z[i];
+    dz[i] = g * act_bwd_p(act, zi, ap, (uint64_t)i);
+    if (act == MMDA_ACT_PRELU && zi <= 0.f) dslope += g * zi;
+  }
+  if (act == MMDA_ACT_PRELU && ap.dslope) {              // launch-uniform
+    const float t = block_sum(dslope, red);
+    if (threadIdx.x == 0) atomicAdd(ap.dslope, t);
+  }
 }
 
 int ew_blocks(int64_t n) {
@@ -343,19 +361,31 @@ extern "C" int mmda_sigmoid_bwd_inplace(float* d, const float* y, int64_t n, voi
   return MMDA_OK;
 }
 
-extern "C" int mmda_act_dropout_fwd(const float* z, float* h, int64_t n, int act, float drop_p, uint64_t seed, int site, void* stream) {
+extern "C" int mmda_act_dropout_fwd_p(const float* z, float* h, int64_t n, int act, const mmda_act_params* ap, float drop_p, uint64_t seed,
+                                      int site, void* stream) {
   if (!z || !h || n < 0) return MMDA_EINVAL;
+  if ((act == MMDA_ACT_PRELU && (!ap || !ap->slope)) || (act == MMDA_ACT_RRELU && !ap)) return MMDA_EINVAL;
   if (n == 0) return MMDA_OK;
-  hipLaunchKernelGGL(act_drop_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, z, h, n, act, drop_p, seed, site);
+  const mmda_act_params p = ap ? *ap : mmda_act_params{};
+  hipLaunchKernelGGL(act_drop_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, z, h, n, act, p, drop_p, seed, site);
   MMDA_CHECK_LAUNCH("mmda_act_dropout_fwd");
   return MMDA_OK;
 }
+extern "C" int mmda_act_dropout_fwd(const float* z, float* h, int64_t n, int act, float drop_p, uint64_t seed, int site, void* stream) {
+  return mmda_act_dropout_fwd_p(z, h, n, act, nullptr, drop_p, seed, site, stream);
+}
 
-extern "C" int mmda_act_dropout_bwd(const float* dh, const float* z, float* dz, int64_t n, int act, float drop_p, uint64_t seed,
-                                    int site, void* stream) {
+extern "C" int mmda_act_dropout_bwd_p(const float* dh, const float* z, float* dz, int64_t n, int act, const mmda_act_params* ap, float drop_p,
+                                      uint64_t seed, int site, void* stream) {
   if (!dh || !z || !dz || n < 0) return MMDA_EINVAL;
+  if ((act == MMDA_ACT_PRELU && (!ap || !ap->slope)) || (act == MMDA_ACT_RRELU && !ap)) return MMDA_EINVAL;
   if (n == 0) return MMDA_OK;
-  hipLaunchKernelGGL(act_drop_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dh, z, dz, n, act, drop_p, seed, site);
+  const mmda_act_params p = ap ? *ap : mmda_act_params{};
+  hipLaunchKernelGGL(act_drop_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dh, z, dz, n, act, p, drop_p, seed, site);
   MMDA_CHECK_LAUNCH("mmda_act_dropout_bwd");
   return MMDA_OK;
+}
+extern "C" int mmda_act_dropout_bwd(const float* dh, const float* z, float* dz, int64_t n, int act, float drop_p, uint64_t seed,
+                                    int site, void* stream) {
+  return mmda_act_dropout_bwd_p(dh, z, dz, n, act, nullptr, drop_p, seed, site, stream);
 }

@@ -25,7 +25,7 @@ from .config import activation_name
 FFN_DIM = 2048          # torch default dim_feedforward of nn.TransformerEncoderLayer (reference models.py:160)
 FUSION_DROPOUT = 0.1    # torch default dropout of nn.TransformerEncoderLayer (not a reference flag)
 
-_TOP_ORDER = ["embed", "trnn1", "trnn2", "vrnn1", "vrnn2", "arnn1", "arnn2", "project_t", "project_v", "project_a",
+_TOP_ORDER = ["activation", "embed", "trnn1", "trnn2", "vrnn1", "vrnn2", "arnn1", "arnn2", "project_t", "project_v", "project_a",
               "private_t", "private_v", "private_a", "shared", "recon_t", "recon_v", "recon_a", "discriminator",
               "sp_discriminator", "confidence", "classifier", "tlayer_norm", "vlayer_norm", "alayer_norm",
               "transformer_encoder"]
@@ -118,8 +118,26 @@ class MISA(nn.Module):
         self._flat_floats = lib.mmda_misa_flat_floats(h)
         self._dense_floats = lib.mmda_misa_dense_floats(h)
         self._names: List[str] = sorted(self._layout, key=_reference_sort_key)
+        # config.activation = prelu: the reference instantiates ONE nn.PReLU() (models.py:30) and adds that module to the three
+        # projections and to the discriminator, so its slope shows up in state_dict() under every one of those names: aliases of the
+        # single native parameter "activation.weight", registered as the same nn.Parameter
+        self._aliases: Dict[str, str] = {}
+        if "activation.weight" in self._layout:
+            after = {f"project_{m_}.project_{m_}.bias": f"project_{m_}.project_{m_}_activation.weight" for m_ in "tva"}
+            after["discriminator.discriminator_layer_1.bias"] = "discriminator.discriminator_layer_1_activation.weight"
+            names = []
+            for n_ in self._names:
+                names.append(n_)
+                if n_ in after:
+                    names.append(after[n_])
+                    self._aliases[after[n_]] = "activation.weight"
+            self._names = names
         for name in self._names:
-            self._register(name, self._layout[name][1])
+            if name in self._aliases:
+                self._layout[name] = self._layout[self._aliases[name]]
+                self._register(name, None, shared=self._get(self._aliases[name]))
+            else:
+                self._register(name, self._layout[name][1])
         self._plist = [(n, self._get(n)) for n in self._names]
         self.reset_parameters()
 
@@ -138,14 +156,14 @@ class MISA(nn.Module):
         self._seg_work = None
 
     # ------------------------------------------------------------------ parameters
-    def _register(self, dotted: str, shape):
+    def _register(self, dotted: str, shape, shared=None):
         mod = self
         parts = dotted.split(".")
         for p in parts[:-1]:
             if not hasattr(mod, p):
                 mod.add_module(p, _Bag())
             mod = getattr(mod, p)
-        mod.register_parameter(parts[-1], nn.Parameter(torch.empty(shape, dtype=torch.float32)))
+        mod.register_parameter(parts[-1], shared if shared is not None else nn.Parameter(torch.empty(shape, dtype=torch.float32)))
 
     def _get(self, dotted: str) -> nn.Parameter:
         mod = self
@@ -158,7 +176,9 @@ class MISA(nn.Module):
         """Same distributions as the torch modules the reference instantiates (nn.LSTM, nn.Linear, nn.LayerNorm,
         nn.Embedding, nn.MultiheadAttention); the reference's solver then applies orthogonal_ to weight_hh*."""
         for name, p in self._plist:
-            if name == "embed.weight":
+            if name.endswith("activation.weight"):
+                p.fill_(0.25)                               # nn.PReLU() default
+            elif name == "embed.weight":
                 p.normal_(0.0, 1.0)
             elif "rnn" in name.split(".")[0]:
                 h = self._layout[name.rsplit(".", 1)[0] + ".weight_hh_l0"][1][1]

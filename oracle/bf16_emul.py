@@ -230,6 +230,9 @@ def forward(P, cfg, t, v, a, lengths, rounding: bool = True, tile_partials: bool
 def loss_and_grads(P, cfg, batch, rounding: bool = True, tile_partials: bool = True):
     """misa_oracle.loss_and_grads through the emulating encoders."""
     leaves = {k: p.detach().clone().requires_grad_(True) for k, p in P.items()}
+    for k in leaves:                                      # the shared PReLU slope is ONE leaf under all its names
+        if k.endswith("activation.weight"):
+            leaves[k] = leaves[orc.PRELU_KEY]
     o = forward(leaves, cfg, batch["t"], batch["v"], batch["a"], batch["l"], rounding, tile_partials)
     L = orc.all_losses(o, batch["emo"], cfg)
     L.total.backward()

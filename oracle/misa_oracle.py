@@ -44,6 +44,7 @@ from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
 
 Params = Dict[str, torch.Tensor]
 
+PRELU_KEY = "activation.weight"      # first registration of the shared nn.PReLU (self.activation, models.py:30); the rest alias it
 FFN_DIM = 2048      # nn.TransformerEncoderLayer default dim_feedforward (reference models.py:160)
 NHEAD = 2           # reference models.py:160
 LN_EPS = 1e-5       # torch default
@@ -71,7 +72,10 @@ def default_config(**kw) -> SimpleNamespace:
 def param_shapes(cfg) -> Dict[str, tuple]:
     """state_dict key -> shape, in the reference's registration order (models.py:47-161)."""
     dt, dv, da, hs = cfg.embedding_size, cfg.visual_size, cfg.acoustic_size, cfg.hidden_size
-    s: Dict[str, tuple] = {"embed.weight": (cfg.vocab_size, dt)}
+    s: Dict[str, tuple] = {}
+    if getattr(cfg, "activation", "leakyrelu") == "prelu":
+        s[PRELU_KEY] = (1,)
+    s["embed.weight"] = (cfg.vocab_size, dt)
 
     ng = 4 if getattr(cfg, "rnncell", "lstm") == "lstm" else 3      # models.py:39: nn.LSTM if rnncell == 'lstm' else nn.GRU
 
@@ -85,9 +89,12 @@ def param_shapes(cfg) -> Dict[str, tuple]:
     rnn("trnn1", dt, dt); rnn("trnn2", 2 * dt, dt)
     rnn("vrnn1", dv, dv); rnn("vrnn2", 2 * dv, dv)
     rnn("arnn1", da, da); rnn("arnn2", 2 * da, da)
+    prelu = getattr(cfg, "activation", "leakyrelu") == "prelu"     # ONE nn.PReLU() instance shared by every use (models.py:30): aliases
     for m, d in (("t", dt), ("v", dv), ("a", da)):
         s[f"project_{m}.project_{m}.weight"] = (hs, 4 * d)
         s[f"project_{m}.project_{m}.bias"] = (hs,)
+        if prelu:
+            s[f"project_{m}.project_{m}_activation.weight"] = (1,)
         s[f"project_{m}.project_{m}_layer_norm.weight"] = (hs,)
         s[f"project_{m}.project_{m}_layer_norm.bias"] = (hs,)
     for name in ("private_t.private_t_1", "private_v.private_v_1", "private_a.private_a_3",
@@ -97,6 +104,8 @@ def param_shapes(cfg) -> Dict[str, tuple]:
     if not cfg.use_cmd_sim:
         s["discriminator.discriminator_layer_1.weight"] = (hs, hs)
         s["discriminator.discriminator_layer_1.bias"] = (hs,)
+        if prelu:
+            s["discriminator.discriminator_layer_1_activation.weight"] = (1,)
         s["discriminator.discriminator_layer_2.weight"] = (3, hs)
         s["discriminator.discriminator_layer_2.bias"] = (3,)
     s["sp_discriminator.sp_discriminator_layer_1.weight"] = (4, hs)
@@ -129,7 +138,13 @@ def synth_params(cfg, seed: int) -> Params:
     import numpy as np
     rng = np.random.default_rng(seed)
     out: Params = {}
+    shared_prelu = None
     for k, shp in param_shapes(cfg).items():
+        if k.endswith("activation.weight"):              # the shared nn.PReLU slope: one tensor under every alias
+            if shared_prelu is None:
+                shared_prelu = torch.tensor([0.25 + float(rng.uniform(-0.1, 0.1))], dtype=torch.float32)
+            out[k] = shared_prelu
+            continue
         if k == "embed.weight":
             a = rng.standard_normal(shp) * 0.5
         elif "layer_norm.weight" in k or k.endswith("norm1.weight") or k.endswith("norm2.weight"):
@@ -256,8 +271,6 @@ def forward(P: Params, cfg, t, v, a, lengths, ffn=None) -> SimpleNamespace:
     """Full model forward with all dropout disabled.  Returns every tensor the reference's
     solver reads off the module (SURVEY.md 8b side channel)."""
     dt, dv, da, hs = cfg.embedding_size, cfg.visual_size, cfg.acoustic_size, cfg.hidden_size
-    act = _ACTS[cfg.activation]
-    o = SimpleNamespace()
     lengths = lengths.cpu()
     emb = P["embed.weight"][t]                                          # models.py:201
     cell = "lstm" if getattr(cfg, "rnncell", "lstm") == "lstm" else "gru"
@@ -271,7 +284,13 @@ def fusion_from_utterances(P: Params, cfg, utt, ffn=None) -> SimpleNamespace:
     """Everything of ``forward`` behind the encoders (models.py:216-249): projections, private/shared, discriminator,
     reconstruction, the transformer fusion layer and the heads, from the three utterance vectors {"t","v","a"}."""
     hs = cfg.hidden_size
-    act = _ACTS[cfg.activation]
+    if cfg.activation == "prelu":        # learned slope, one parameter shared by the three projections and the discriminator
+        slope = P[PRELU_KEY]
+        act = lambda x: F.prelu(x, slope)
+    elif cfg.activation == "rrelu":      # nn.RReLU() in evaluation mode: the mean slope (1/8 + 1/3) / 2; parity is defined dropout-off
+        act = lambda x: F.rrelu(x, training=False)
+    else:
+        act = _ACTS[cfg.activation]
     o = SimpleNamespace()
     o.utterance_t, o.utterance_v, o.utterance_a = utt["t"], utt["v"], utt["a"]
     priv_names = {"t": "private_t.private_t_1", "v": "private_v.private_v_1", "a": "private_a.private_a_3"}
@@ -401,10 +420,14 @@ class AdamState:
 
     def step(self, P: Params, G: Dict[str, Optional[torch.Tensor]]):
         with torch.no_grad():
+            seen = set()
             for k, p in P.items():
                 g = G.get(k)
                 if g is None:
                     continue
+                if p.data_ptr() in seen:                  # an alias of a shared parameter (the one nn.PReLU slope): stepped once
+                    continue
+                seen.add(p.data_ptr())
                 self.t[k] += 1
                 t = self.t[k]
                 self.m[k].mul_(self.b1).add_(g, alpha=1 - self.b1)
@@ -420,6 +443,9 @@ def loss_and_grads(P: Params, cfg, batch, ffn=None):
     has None for parameters outside the graph (sp_discriminator.*; confidence.* unless
     use_confidNet) exactly as autograd leaves them in the reference."""
     leaves = {k: p.detach().clone().requires_grad_(True) for k, p in P.items()}
+    for k in leaves:                                      # the shared PReLU slope is ONE leaf under all its names
+        if k.endswith("activation.weight"):
+            leaves[k] = leaves[PRELU_KEY]
     o = forward(leaves, cfg, batch["t"], batch["v"], batch["a"], batch["l"], ffn)
     L = all_losses(o, batch["emo"], cfg)
     L.total.backward()

@@ -32,7 +32,7 @@ import models as ref_models                      # noqa: E402  (the reference)
 from utils import DiffLoss, CMD                  # noqa: E402  (the reference)
 from oracle import misa_oracle as orc            # noqa: E402  (only for synth_params/synth_batch/default_config)
 
-ACT = {"leakyrelu": nn.LeakyReLU, "relu": nn.ReLU, "tanh": nn.Tanh, "elu": nn.ELU}
+ACT = {"leakyrelu": nn.LeakyReLU, "relu": nn.ReLU, "tanh": nn.Tanh, "elu": nn.ELU, "prelu": nn.PReLU, "rrelu": nn.RReLU}
 SAMPLE_TARGET = 2048
 
 
@@ -55,6 +55,8 @@ def build_reference(cfg, params):
     for mod in m.modules():                       # parity is defined dropout-off
         if isinstance(mod, nn.Dropout):
             mod.p = 0.0
+        if isinstance(mod, nn.RReLU):             # random slopes are a regulariser like dropout: its evaluation form (the mean slope)
+            mod.eval()
     m.transformer_encoder.layers[0].self_attn.dropout = 0.0
     return m
 
@@ -184,6 +186,10 @@ def main():
              full_tensors=False, steps=3)
     run_case("real_b16_t20_adv_confid", orc.default_config(use_cmd_sim=False, use_confidNet=True, **real),
              B=16, T=20, seed=6, ragged=True, full_tensors=False)
+    # config.activation = prelu / rrelu (config.py:25-27): the learned slope is ONE nn.PReLU shared by the projections and the discriminator
+    run_case("tiny_prelu_adv_ragged", orc.default_config(activation="prelu", use_cmd_sim=False, **tiny), B=6, T=7, seed=12, ragged=True,
+             full_tensors=True)
+    run_case("tiny_rrelu_ragged", orc.default_config(activation="rrelu", **tiny), B=5, T=6, seed=13, ragged=True, full_tensors=True)
     # BASELINE.json configs[3] (seq_len = 500) and the per-GPU batch of configs[2] (B = 256), one step each
     run_case("real_b32_t500_ragged", orc.default_config(**real), B=32, T=500, seed=10, ragged=True, full_tensors=False, steps=1,
              store_inputs=False)

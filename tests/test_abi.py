@@ -32,10 +32,10 @@ def test_struct_sizes_match_c_layout():
     code = textwrap.dedent("""
         #include <stdio.h>
         #include "mmda_hip.h"
-        int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mmda_gemm_args), sizeof(mmda_ln_args), sizeof(mmda_ln_bwd_args),
+        int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mmda_gemm_args), sizeof(mmda_ln_args), sizeof(mmda_ln_bwd_args),
                           sizeof(mmda_lstm_desc), sizeof(mmda_misa_config), sizeof(mmda_gemm_bf16_args),
                           sizeof(mmda_convert_job), sizeof(mmda_skinny_args), sizeof(mmda_transpose_job), sizeof(mmda_gru_pad_job),
-                          sizeof(mmda_mx8_quant_job), sizeof(mmda_mx8_args));
+                          sizeof(mmda_mx8_quant_job), sizeof(mmda_mx8_args), sizeof(mmda_act_params));
                    return 0;}""")
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "s.c"), "w").write(code)
@@ -43,7 +43,7 @@ def test_struct_sizes_match_c_layout():
         out = subprocess.run([os.path.join(d, "s")], check=True, capture_output=True, text=True).stdout.split()
     sizes = [ctypes.sizeof(x) for x in (_lib.GemmArgs, _lib.LnArgs, _lib.LnBwdArgs, _lib.LstmDesc, _lib.MisaConfig,
                                        _lib.GemmBf16Args, _lib.ConvertJob, _lib.SkinnyArgs, _lib.TransposeJob, _lib.GruPadJob,
-                                       _lib.Mx8QuantJob, _lib.Mx8Args)]
+                                       _lib.Mx8QuantJob, _lib.Mx8Args, _lib.ActParams)]
     assert [int(x) for x in out] == sizes
 
 

@@ -584,3 +584,41 @@ def test_fp8_fusion_ffn_matches_its_emulation_and_stays_near_the_exact_path(name
     model.set_fusion_fp8(False)
     model.train_step(b["t"], b["v"], b["a"], b["l"], b["emo"], lr=cfg.learning_rate, clip=cfg.clip, do_adam=False, training=False)
     assert rel(model._public()["scores"], z["out::scores"]) < (1e-4 if precision == "fp32" else 1e-2)
+
+
+def test_rrelu_training_mode_draws_slopes_and_replays_them_in_backward():
+    """config.activation = rrelu (config.py:27): in training mode nn.RReLU draws a slope ~ U(1/8, 1/3) per negative element.  The draws
+    cannot match torch's CPU stream, so: two training forwards differ, the evaluation forward equals the mean-slope form (pinned by the
+    tiny_rrelu_ragged fixture), and the backward pass replays the forward's draws -- a finite-difference check through the projection
+    of one weight agrees with the analytic gradient of the SAME seed."""
+    cfg = orc.default_config(vocab_size=50, activation="rrelu", dropout=0.0)
+    model, c, P = make_model(cfg, 5, "fp32")
+    b = to_dev(orc.synth_batch(cfg, 6, 5, 3, ragged=True))
+    model.train()
+    with torch.no_grad():
+        s1, _ = model(b["t"], b["v"], b["a"], b["l"]); s1 = s1.clone()
+        s2, _ = model(b["t"], b["v"], b["a"], b["l"]); s2 = s2.clone()
+    assert not torch.equal(s1, s2)
+    # same seed -> same draws: the step is a deterministic function of (weights, seed); compare d total / d w with a central difference
+    import mmda_amd.models as mm
+    mm_fd = getattr(mm, "FUSION_DROPOUT")
+    try:
+        mm.FUSION_DROPOUT = 0.0
+        model, c, P = make_model(cfg, 5, "fp32")
+        seed = 1234567
+        def total():
+            model.train_step(b["t"], b["v"], b["a"], b["l"], b["emo"], lr=0.0, clip=1.0, do_adam=False, training=True, seed=seed)
+            return model.read_losses()["total"]
+        total()
+        model._assign_grad_views()
+        w = model.project_v.project_v.weight
+        g = w.grad.clone()
+        idx = int(g.abs().flatten().argmax())
+        i, j = idx // g.shape[1], idx % g.shape[1]
+        eps = 2e-3
+        with torch.no_grad():
+            w[i, j] += eps; lp = total(); w[i, j] -= 2 * eps; lm = total(); w[i, j] += eps
+        fd = (lp - lm) / (2 * eps)
+        assert abs(fd - float(g[i, j])) <= 5e-2 * abs(float(g[i, j])) + 1e-4, (fd, float(g[i, j]))
+    finally:
+        mm.FUSION_DROPOUT = mm_fd

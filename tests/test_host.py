@@ -62,8 +62,17 @@ def test_config_mirror_defaults_and_errors(monkeypatch):
     assert c.recon_weight == 0.7 and c.conf_weight == 0.3 and c.clip == 1.0 and c.threshold == 0.35 and c.hidden_size == 128
     assert c.model == "MISA" and c.activation == "leakyrelu" and c.batch_size == 64 and c.n_epoch == 40
     assert activation_name(torch.nn.LeakyReLU) == "leakyrelu" and activation_name(torch.nn.ReLU()) == "relu"
-    with pytest.raises(NotImplementedError):
-        activation_name("prelu")
+    # the whole activation_dict of the reference (config.py:25-27), by name, class or instance
+    assert activation_name("prelu") == "prelu" and activation_name(torch.nn.RReLU) == "rrelu" and activation_name(torch.nn.PReLU()) == "prelu"
+    with pytest.raises(ValueError):
+        activation_name("gelu")
+    # prelu: ONE shared nn.PReLU slope under the reference's five state_dict names (models.py:30,64-79,125), one Parameter
+    from oracle import misa_oracle as orc
+    pc = orc.default_config(vocab_size=10, activation="prelu", use_cmd_sim=False)
+    pm = MISA(make_config(**vars(pc)))
+    assert list(pm.state_dict().keys()) == list(orc.param_shapes(pc).keys())
+    assert pm.activation.weight is pm.project_v.project_v_activation.weight is pm.discriminator.discriminator_layer_1_activation.weight
+    assert float(pm.activation.weight) == 0.25 and sum(1 for n, _ in pm.named_parameters() if "activation" in n) == 1
     g = MISA(make_config(vocab_size=10, rnncell="gru"))          # reference models.py:39: anything but 'lstm' is nn.GRU
     sd = g.state_dict()
     assert sd["trnn1.weight_ih_l0"].shape == (900, 300) and sd["vrnn2.weight_hh_l0_reverse"].shape == (105, 35)

@@ -35,6 +35,9 @@ def test_oracle_forward_losses_grads(name):
         np.testing.assert_allclose(getattr(L, k).item(), float(z["loss::" + k]), rtol=1e-5, atol=1e-6, err_msg=k)
     none = set(meta["none_grads"])
     for k, g in G.items():
+        if k != orc.PRELU_KEY and k.endswith("activation.weight"):
+            assert g is G[orc.PRELU_KEY] or torch.equal(g, G[orc.PRELU_KEY])      # an alias of the one shared nn.PReLU slope
+            continue
         if k in none:
             assert g is None, k
             continue
