@@ -75,13 +75,28 @@ __device__ __forceinline__ void gemm_bf16_tile(const mmda_gemm_bf16_args& g, int
   // occupancy -- two stages for the 128-tile (32 registers each), four for the 64-tile (16 each).
   constexpr int NS = T == 128 ? 2 : 4;
   u32x4 ra[NS][CH], rb[NS][CH];
+  // Operand loads go through buffer descriptors with 32-bit byte offsets: rows past the matrix land beyond the descriptor's size and
+  // read as zero in hardware, k past the (8-padded) depth is sent there by one select on the OFFSET -- no clamps, no 64-bit address
+  // arithmetic and no selects on the loaded data in the k-loop (they were most of the wave's issue slots: the matrix pipe was 20 % busy
+  // with the waves 38 % of their time in issue stalls, tools/prof_gemm_pmc.sh).  Host side guarantees (M + T) * lda * 2 < 4 GiB.
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(A), 0, (int)(((int64_t)(M - 1) * g.lda + Kp) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Bm), 0, (int)(((int64_t)(N - 1) * g.ldb + Kp) * 2), 0x00020000);
+  constexpr unsigned OOB_OFF = 0xFFFFFF00u;
+  unsigned offA[CH], offB[CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int c = tid + 256 * i;
+    const int r = c >> 3, k = (c & 7) * 8;
+    offA[i] = (unsigned)(((row0 + r) * g.lda + k) * 2);
+    offB[i] = (unsigned)(((col0 + r) * g.ldb + k) * 2);
+  }
   auto load_tile = [&](u32x4 (&a)[CH], u32x4 (&b)[CH], int k0) {
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       const int c = tid + 256 * i;
-      const int r = c >> 3, k = k0 + (c & 7) * 8;
-      a[i] = ld_chunk(A, row0 + r, M, g.lda, k, Kp);
-      b[i] = ld_chunk(Bm, col0 + r, N, g.ldb, k, Kp);
+      const bool k_ok = k0 + (c & 7) * 8 < Kp;
+      a[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, k_ok ? offA[i] + (unsigned)k0 * 2u : OOB_OFF, 0, 0);
+      b[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, k_ok ? offB[i] + (unsigned)k0 * 2u : OOB_OFF, 0, 0);
     }
   };
   // the virtual all-ones row n == N of B (bias gradient) is written straight into the LDS tile that holds column N: it never
@@ -90,14 +105,12 @@ __device__ __forceinline__ void gemm_bf16_tile(const mmda_gemm_bf16_args& g, int
   auto store_tile = [&](const u32x4 (&a)[CH], const u32x4 (&b)[CH], int k0, int buf) {
     unsigned short* As = AB + buf * BUF;
     unsigned short* Bs = As + T * LDT;
-    const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       const int c = tid + 256 * i;
       const int r = c >> 3, k = (c & 7) * 8;
-      const bool k_ok = k0 + k < Kp;
-      *reinterpret_cast<u32x4*>(&As[r * LDT + k]) = (k_ok && row0 + r < M) ? a[i] : z;
-      u32x4 v = (k_ok && col0 + r < N) ? b[i] : z;
+      *reinterpret_cast<u32x4*>(&As[r * LDT + k]) = a[i];        // (rows / k out of range arrived as zeros)
+      u32x4 v = b[i];
       if (tile_has_ones) {                                     // block-uniform
         // bf16 1.0 = 0x3F80; elements past K stay zero so the sum runs over the real depth only
         unsigned e[8];
@@ -449,6 +462,8 @@ extern "C" int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, vo
     if (!a.A || !a.B || !a.C || a.M < 0 || a.N < 0 || a.K <= 0) return MMDA_EINVAL;
     if ((a.lda & 7) || (a.ldb & 7) || (((uintptr_t)a.A | (uintptr_t)a.B) & 15)) return MMDA_EINVAL;
     if (a.lda < ((a.K + 7) & ~7) || a.ldb < ((a.K + 7) & ~7)) return MMDA_EINVAL;
+    // operands are addressed with 32-bit byte offsets through buffer descriptors (row clamping is done by the descriptor's size)
+    if (((double)a.M + 128.0) * a.lda * 2.0 >= 4.0e9 || ((double)a.N + 129.0) * a.ldb * 2.0 >= 4.0e9) return MMDA_EINVAL;
     if (a.perm_n_H < 0 || a.perm_m_H < 0 || (a.perm_n_H && a.N % (4 * a.perm_n_H)) || (a.perm_m_H && a.M % (4 * a.perm_m_H))) return MMDA_EINVAL;
   }
   // 128 x 128 tiles when they alone fill the chip twice over; else 64 x 64 (4x the workgroups, 2x the residency)
