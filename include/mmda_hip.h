@@ -246,6 +246,10 @@ int mmda_lstm_pack_whh_cluster(int H, const float* whh, void* packed_c, void* st
 int mmda_lstm_pack_whh_multi(int mode, int n, const int* H, const float* const* whh, void* const* packed_fwd,
                              void* const* packed_bwd /* entries may be NULL: that packing is skipped (as may packed_fwd's, not both) */,
                              void* const* packed_c /* NULL or per-matrix (bf16) */, void* stream);
+/* The same packings (bf16 mode) and up to 16 conversion jobs (mmda_convert_bf16) in ONE launch: both depend only on the step's inputs
+ * and weights; as two launches on two streams they cost a fork and a cross-stream wait in front of the first recurrent kernel. */
+int mmda_lstm_pack_whh_and_convert(int n, const int* H, const float* const* whh, void* const* packed_fwd, void* const* packed_bwd,
+                                   void* const* packed_c, const mmda_convert_job* jobs, int njobs, void* stream);
 
 typedef struct mmda_lstm_desc {
   int H;

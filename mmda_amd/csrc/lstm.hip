@@ -12,6 +12,7 @@
 // the backward kernel needs).  Variable lengths: sample b is updated only while t < len_b; the reverse direction
 // walks t = T-1..0 from a zero state, so it effectively starts at len_b-1 (packed-sequence semantics).
 #include "common.h"
+#include "convert_tile.h"
 
 namespace {
 
@@ -75,13 +76,13 @@ __global__ void pack_kernel(int H, const float* __restrict__ W, void* outF, void
 
 struct PackMulti { int H[16]; const float* W[16]; void* F[16]; void* Bk[16]; void* Ck[16]; int start[17]; int n; };
 template <int MODE>
-__global__ void pack_multi_kernel(PackMulti P) {
-  // blockIdx.x -> matrix through the prefix table.  One thread per (fragment, lane): it gathers the lane's 8 bf16 (4 fp32) values
+__device__ __forceinline__ void pack_block(const PackMulti& P, int block) {
+  // block -> matrix through the prefix table.  One thread per (fragment, lane): it gathers the lane's 8 bf16 (4 fp32) values
   // and writes them with one 16-byte store; loads are unconditional from clamped addresses (values outside H are zeroed after).
   int i = 0;
 #pragma unroll
   for (int k = 1; k < 16; ++k)
-    if (k < P.n && (int)blockIdx.x >= P.start[k]) i = k;
+    if (k < P.n && block >= P.start[k]) i = k;
   const int H = P.H[i];
   const float* __restrict__ W = P.W[i];
   const int Hp = pad16(H), nHT = Hp / 16;
@@ -91,7 +92,7 @@ __global__ void pack_multi_kernel(PackMulti P) {
   const int KSB = 4 * Hp / kspan;
   const int64_t gF = (int64_t)nHT * 4 * KS * 64, gB = (int64_t)nHT * KSB * 64;        // (fragment, lane) pairs per packing
   const int64_t gC = (MODE == MMDA_BF16 && P.Ck[i]) ? (int64_t)nHT * nHT * 2 * 64 : 0;
-  const int64_t q0 = (int64_t)(blockIdx.x - P.start[i]) * blockDim.x + threadIdx.x;
+  const int64_t q0 = (int64_t)(block - P.start[i]) * blockDim.x + threadIdx.x;
   if (q0 >= gF + gB + gC) return;
   float v[per];
   void* dst;
@@ -144,6 +145,18 @@ __global__ void pack_multi_kernel(PackMulti P) {
   } else {
     reinterpret_cast<float4*>(dst)[q] = float4{v[0], v[1], v[2], v[3]};
   }
+}
+
+template <int MODE>
+__global__ void pack_multi_kernel(PackMulti P) { pack_block<MODE>(P, (int)blockIdx.x); }
+
+// The twelve W_hh packings of a step AND its first bf16 conversions (W_ih of both layers, the layer-1 inputs incl. the embedding
+// lookup) in ONE launch: blocks [0, pack_blocks) pack, the rest convert.  Both only depend on the step's inputs and weights, and as
+// two launches on two streams they cost the main stream a fork and a cross-stream wait in front of the first recurrent kernel.
+__global__ __launch_bounds__(256) void pack_convert_kernel(PackMulti P, ConvLaunch L, int pack_blocks) {
+  __shared__ __attribute__((aligned(16))) unsigned short tile[64][66];
+  if ((int)blockIdx.x < pack_blocks) pack_block<MMDA_BF16>(P, (int)blockIdx.x);
+  else convert_block(L, (int)blockIdx.x - pack_blocks, tile);
 }
 
 template <int MODE> __device__ __forceinline__ float sig_(float x) { return MODE == MMDA_BF16 ? sigmoid_fast(x) : sigmoidf_(x); }
@@ -537,12 +550,12 @@ extern "C" int mmda_lstm_pack_whh(int mode, int H, const float* whh, void* packe
   return MMDA_OK;
 }
 
-extern "C" int mmda_lstm_pack_whh_multi(int mode, int n, const int* H, const float* const* whh, void* const* packed_fwd,
-                                        void* const* packed_bwd, void* const* packed_c, void* stream) {
+namespace {
+int pack_build(int mode, int n, const int* H, const float* const* whh, void* const* packed_fwd, void* const* packed_bwd,
+               void* const* packed_c, PackMulti& P, int& blocks) {
   if (n <= 0 || n > 16 || !H || !whh || !packed_fwd || !packed_bwd || (mode != MMDA_BF16 && mode != MMDA_F32)) return MMDA_EINVAL;
-  PackMulti P;
   P.n = n;
-  int blocks = 0;
+  blocks = 0;
   for (int i = 0; i < n; ++i) {
     if (H[i] <= 0 || H[i] > 512 || !whh[i] || (!packed_fwd[i] && !packed_bwd[i])) return MMDA_EINVAL;
     P.H[i] = H[i]; P.W[i] = whh[i]; P.F[i] = packed_fwd[i]; P.Bk[i] = packed_bwd[i];
@@ -555,6 +568,32 @@ extern "C" int mmda_lstm_pack_whh_multi(int mode, int n, const int* H, const flo
   }
   for (int i = n; i < 16; ++i) { P.H[i] = P.H[0]; P.W[i] = P.W[0]; P.F[i] = P.F[0]; P.Bk[i] = P.Bk[0]; P.Ck[i] = P.Ck[0]; }
   for (int i = n; i <= 16; ++i) P.start[i] = blocks;
+  return MMDA_OK;
+}
+}  // namespace
+
+extern "C" int mmda_lstm_pack_whh_and_convert(int n, const int* H, const float* const* whh, void* const* packed_fwd, void* const* packed_bwd,
+                                              void* const* packed_c, const mmda_convert_job* jobs, int njobs, void* stream) {
+  if (!jobs || njobs < 0 || njobs > CONV_MAX) return MMDA_EINVAL;
+  PackMulti P;
+  int pblocks = 0, cblocks = 0;
+  int rc = pack_build(MMDA_BF16, n, H, whh, packed_fwd, packed_bwd, packed_c, P, pblocks);
+  if (rc) return rc;
+  ConvLaunch L;
+  rc = conv_build(jobs, njobs, L, cblocks);
+  if (rc) return rc;
+  if (pblocks + cblocks == 0) return MMDA_OK;
+  hipLaunchKernelGGL(pack_convert_kernel, dim3(pblocks + cblocks), dim3(256), 0, (hipStream_t)stream, P, L, pblocks);
+  MMDA_CHECK_LAUNCH("mmda_lstm_pack_whh_and_convert");
+  return MMDA_OK;
+}
+
+extern "C" int mmda_lstm_pack_whh_multi(int mode, int n, const int* H, const float* const* whh, void* const* packed_fwd,
+                                        void* const* packed_bwd, void* const* packed_c, void* stream) {
+  PackMulti P;
+  int blocks = 0;
+  const int rc0 = pack_build(mode, n, H, whh, packed_fwd, packed_bwd, packed_c, P, blocks);
+  if (rc0) return rc0;
   hipStream_t s = (hipStream_t)stream;
   if (mode == MMDA_BF16) hipLaunchKernelGGL(pack_multi_kernel<MMDA_BF16>, dim3(blocks), dim3(256), 0, s, P);
   else hipLaunchKernelGGL(pack_multi_kernel<MMDA_F32>, dim3(blocks), dim3(256), 0, s, P);

@@ -72,6 +72,7 @@ struct mmda_misa {
   // fused train step without a gradient exchange: clamp+Adam of the bucket prefix whose gradients are final beside the layer-1 backward
   // recurrence runs there, on the side stream (set by mmda_misa_train_step around its backward pass)
   int adam_early_on = 0; float ae_lr = 0.f, ae_clip = 0.f; int ae_step = 0; int64_t adam_early_done = 0;
+  int wT_pending = 0;              // the K-major fusion-weight copies of this step are still to be made (on the next fork)
   int fusion_fp8 = 0;
   int64_t x1q, x1s, w1q, w1s, f1q, f1s, w2q, w2s;
   // state of the last forward (dropout replay in backward)
@@ -615,6 +616,27 @@ extern "C" int mmda_misa_cluster_status(const mmda_misa* m, int* aborted_host) {
 
 // =============================================================================================== forward
 namespace {
+// K-major (transposed) fp32 copies of the fusion block's weights for its input-gradient GEMMs in the backward pass; issued on a side
+// stream that the end of forward() joins
+int weight_transposes(mmda_misa* m, void* ss) {
+  const mmda_misa_config& c = m->cfg;
+  const int hs_ = c.hidden, NC_ = 6 + c.ncls;
+  std::vector<mmda_transpose_job> tj;
+  auto T_ = [&](int64_t src, int rows, int cols, int64_t dst) { tj.push_back(mmda_transpose_job{PP(src), rows, cols, cols, WS(dst), rows}); };
+  T_(m->head_w, NC_, 6 * hs_, m->head_wT); T_(m->l2_w, hs_, FFN, m->l2_wT); T_(m->l1_w, FFN, hs_, m->l1_wT);
+  T_(m->out_w, hs_, hs_, m->out_wT); T_(m->in_w, 3 * hs_, hs_, m->in_wT); T_(m->sh_w, hs_, hs_, m->sh_wT);
+  for (int i = 0; i < 3; ++i) {
+    T_(m->rec_w + (int64_t)i * hs_ * hs_, hs_, hs_, m->rec_wT + (int64_t)i * hs_ * hs_);
+    T_(m->priv_w + (int64_t)i * hs_ * hs_, hs_, hs_, m->priv_wT + (int64_t)i * hs_ * hs_);
+    T_(m->mod[i].pw, hs_, 4 * m->mod[i].H, m->pwT[i]);
+  }
+  if (!c.use_cmd_sim) { T_(m->d1_w, hs_, hs_, m->d1_wT); T_(m->d2_w, 3, hs_, m->d2_wT); }
+  const int rc = mmda_transpose_f32(tj.data(), (int)tj.size(), ss);
+  m->wT_valid = rc ? 0 : 1;
+  m->wT_pending = 0;
+  return rc;
+}
+
 // side stream, right after x6 = [private x3, shared x3] exists: clear the loss sums and the loss-seeded activation gradients,
 // then DiffLoss and CMD with their gradients (they read x6 only), then the gradient bucket if train_step left that to forward()
 int eager_side_losses(mmda_misa* m, void* stream, bool hseq2_t) {
@@ -624,6 +646,7 @@ int eager_side_losses(mmda_misa* m, void* stream, bool hseq2_t) {
   const int64_t BH = (int64_t)B * hs;
   void* ss = nullptr;
   int rc = side_fork(m, stream, &ss);
+  if (!rc && m->wT_pending) rc = weight_transposes(m, ss);
   if (!rc && hseq2_t) {            // hseq^T of layer 2 for its dW_hh (every fork puts a marker packet on the main stream: one for both)
     mmda_convert_job cj[3];
     for (int i = 0; i < 3; ++i) {
@@ -715,46 +738,6 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
     }
     return mmda_lstm_resident_applicable(mode, 3, probe, B, T, backward) != 0;
   };
-  {
-    // The forward packing always; the resident-weights backward packing when those kernels will run the backward pass and the
-    // streaming backward packing only when they will not; neither for an evaluation pass.
-    const bool infer = m->inference != 0;
-    const bool want_c = !infer && m->use_cluster && mode == MMDA_BF16;
-    const bool want_b = !infer && !(want_c && probe_resident(0, 1));
-    int Hs[12]; const float* Wp[12]; void* Fp[12]; void* Bp[12]; void* Cp[12];
-    int k = 0;
-    for (int i = 0; i < 3; ++i)
-      for (int l = 0; l < 2; ++l)
-        for (int d = 0; d < 2; ++d, ++k) {
-          Rnn& r = m->mod[i].rnn[l];
-          Hs[k] = r.H; Wp[k] = rW_hh(m, r, d); Fp[k] = WS(r.pack_f[d]); Bp[k] = want_b ? WS(r.pack_b[d]) : nullptr; Cp[k] = WS(r.pack_c[d]);
-        }
-    void* ss = nullptr;
-    x.rc = side_fork(m, stream, &ss);
-    if (!x.rc) x.rc = mmda_lstm_pack_whh_multi(mode, 12, Hs, Wp, Fp, Bp, want_c ? Cp : nullptr, ss);
-    // the first recurrent kernel waits for the packing only, not for the transposes issued behind it
-    if (!x.rc && ss != stream && hipEventRecord(m->ev_pack, (hipStream_t)ss) != hipSuccess) x.rc = MMDA_ELAUNCH;
-    m->pack_b_valid = want_b ? 1 : 0;
-    m->packed_c_valid = want_c ? 1 : 0;
-    m->wT_valid = 0;
-    if (!x.rc && B <= SKINNY_MAX_B && !m->inference) {
-      // K-major copies of the fusion block's weights for the backward pass, also underneath the first input GEMM
-      const int hs_ = c.hidden, NC_ = 6 + c.ncls;
-      std::vector<mmda_transpose_job> tj;
-      auto T_ = [&](int64_t src, int rows, int cols, int64_t dst) { tj.push_back(mmda_transpose_job{PP(src), rows, cols, cols, WS(dst), rows}); };
-      T_(m->head_w, NC_, 6 * hs_, m->head_wT); T_(m->l2_w, hs_, FFN, m->l2_wT); T_(m->l1_w, FFN, hs_, m->l1_wT);
-      T_(m->out_w, hs_, hs_, m->out_wT); T_(m->in_w, 3 * hs_, hs_, m->in_wT); T_(m->sh_w, hs_, hs_, m->sh_wT);
-      for (int i = 0; i < 3; ++i) {
-        T_(m->rec_w + (int64_t)i * hs_ * hs_, hs_, hs_, m->rec_wT + (int64_t)i * hs_ * hs_);
-        T_(m->priv_w + (int64_t)i * hs_ * hs_, hs_, hs_, m->priv_wT + (int64_t)i * hs_ * hs_);
-        T_(m->mod[i].pw, hs_, 4 * m->mod[i].H, m->pwT[i]);
-      }
-      if (!c.use_cmd_sim) { T_(m->d1_w, hs_, hs_, m->d1_wT); T_(m->d2_w, 3, hs_, m->d2_wT); }
-      x.rc = mmda_transpose_f32(tj.data(), (int)tj.size(), ss);
-      m->wT_valid = 1;
-    }
-  }
-  if (x.rc) return x.rc;
   // bf16 mode: the input GEMMs read bf16 operand copies (K-major, 16-B rows): W_ih of both layers (plain for the forward,
   // transposed for dX) and the layer-1 inputs -- the text rows are gathered from the embedding matrix by the conversion itself
   // (models.py:201), so no fp32 copy of them is made.
@@ -776,8 +759,7 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
   // than the smaller main-stream conversions save, so this stays an ablation switch, off by default)
   static const int late_t_on = getenv("MMDA_LATE_T") ? atoi(getenv("MMDA_LATE_T")) : 0;
   const bool late_t = bfg && m->use_side && !inf && late_t_on;
-  auto first_converts = [&](bool plain, bool transposed, void* st) -> int {
-    mmda_convert_job cj[9];
+  auto first_jobs = [&](bool plain, bool transposed, mmda_convert_job* cj) -> int {
     int n = 0;
     for (int i = 0; i < 3; ++i) {
       for (int l = 0; l < 2; ++l) {
@@ -790,9 +772,56 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
       cj[n++] = mmda_convert_job{src, r0.D, R, r0.D, i == 0 ? t_ids : nullptr, plain ? WS(r0.xb) : nullptr, plain ? r0.ldD : 0,
                                  transposed ? WS(r0.xbT) : nullptr, transposed ? ldR : 0};
     }
+    return n;
+  };
+  auto first_converts = [&](bool plain, bool transposed, void* st) -> int {
+    mmda_convert_job cj[9];
+    const int n = first_jobs(plain, transposed, cj);
     return mmda_convert_bf16(cj, n, st);
   };
-  if (bfg) {
+  // Merged form (bf16 operand copies in use): the twelve packings and the first conversions go out as ONE launch on the main stream
+  // (mmda_lstm_pack_whh_and_convert) -- no fork, no cross-stream wait in front of the first recurrent kernel (each costs the main stream
+  // 4 - 14 us).  The K-major copies of the fusion block's weights, which only the backward pass reads, then ride on the first fork that
+  // happens anyway (wT_pending).  MMDA_PACK_MERGE=0: round 1's form (packing on the side stream, joined by an event).
+  static const int pack_merge = getenv("MMDA_PACK_MERGE") ? atoi(getenv("MMDA_PACK_MERGE")) : 1;
+  const bool merged = bfg && pack_merge && !late_t;
+  m->wT_pending = 0;
+  {
+    // The forward packing always; the resident-weights backward packing when those kernels will run the backward pass and the
+    // streaming backward packing only when they will not; neither for an evaluation pass.
+    const bool infer = m->inference != 0;
+    const bool want_c = !infer && m->use_cluster && mode == MMDA_BF16;
+    const bool want_b = !infer && !(want_c && probe_resident(0, 1));
+    int Hs[12]; const float* Wp[12]; void* Fp[12]; void* Bp[12]; void* Cp[12];
+    int k = 0;
+    for (int i = 0; i < 3; ++i)
+      for (int l = 0; l < 2; ++l)
+        for (int d = 0; d < 2; ++d, ++k) {
+          Rnn& r = m->mod[i].rnn[l];
+          Hs[k] = r.H; Wp[k] = rW_hh(m, r, d); Fp[k] = WS(r.pack_f[d]); Bp[k] = want_b ? WS(r.pack_b[d]) : nullptr; Cp[k] = WS(r.pack_c[d]);
+        }
+    m->pack_b_valid = want_b ? 1 : 0;
+    m->packed_c_valid = want_c ? 1 : 0;
+    m->wT_valid = 0;
+    const bool want_wT = B <= SKINNY_MAX_B && !m->inference;
+    if (merged) {
+      mmda_convert_job cj[9];
+      const int nj = first_jobs(true, !inf, cj);
+      x.rc = mmda_lstm_pack_whh_and_convert(12, Hs, Wp, Fp, Bp, want_c ? Cp : nullptr, cj, nj, stream);
+      m->wT_pending = want_wT ? 1 : 0;
+    } else {
+      void* ss = nullptr;
+      x.rc = side_fork(m, stream, &ss);
+      if (!x.rc) x.rc = mmda_lstm_pack_whh_multi(mode, 12, Hs, Wp, Fp, Bp, want_c ? Cp : nullptr, ss);
+      // the first recurrent kernel waits for the packing only, not for the transposes issued behind it
+      if (!x.rc && ss != stream && hipEventRecord(m->ev_pack, (hipStream_t)ss) != hipSuccess) x.rc = MMDA_ELAUNCH;
+      if (!x.rc && want_wT) x.rc = weight_transposes(m, ss);
+    }
+  }
+  if (x.rc) return x.rc;
+  if (merged) {
+    // (done by the merged launch above)
+  } else if (bfg) {
     x.rc = first_converts(true, !inf && !late_t, stream);
   } else {
     // embedding rows (models.py:201)
@@ -872,11 +901,12 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
         }
         x.rc = mmda_convert_bf16(cj, (inf || late_t) ? 3 : 6, stream);
       }
-    } else if (!x.rc && !m->eager_losses && ((bfg && !inf) || m->zero_grad_pending)) {
+    } else if (!x.rc && !m->eager_losses && ((bfg && !inf) || m->zero_grad_pending || m->wT_pending)) {
       // side stream, beside the fusion block: the gradient bucket is cleared (train_step) and hseq^T of layer 2 is made for its
       // dW_hh.  Joined at the end of forward(), so everything the backward pass issues on either stream is ordered behind both.
       void* ss = nullptr;
       x.rc = side_fork(m, stream, &ss);
+      if (!x.rc && m->wT_pending) x.rc = weight_transposes(m, ss);
       if (!x.rc && m->zero_grad_pending && !m->eager_losses) { x.rc = mmda_misa_zero_grad(m, ss); m->zero_grad_pending = 0; }
       if (bfg && !inf && !x.rc) {
         mmda_convert_job cj[3];
@@ -1025,6 +1055,11 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
                             stream);
   }
   if (!m->ev.empty()) { if (m->ev_seen_f % m->ev_stride == 0) m->ev_fwd++; m->ev_seen_f++; }
+  if (!x.rc && m->wT_pending) {                // no fork came by (the eager losses are off and nothing else was pending)
+    void* ss = nullptr;
+    x.rc = side_fork(m, stream, &ss);
+    if (!x.rc) x.rc = weight_transposes(m, ss);
+  }
   if (!x.rc) x.rc = side_join(m, stream);      // (the side stream finished long ago: this only orders later work behind it)
   return x.rc;
 }
