@@ -465,7 +465,7 @@ __device__ __forceinline__ bool xcc_all_local(const unsigned char* tile_flag, bo
 //   publish the wave's 16 x 16 bf16 tile goes through 512 B of wave-private LDS (fragment order -> row order) and out as 32
 //           16-byte write-through stores covering whole 64-byte sectors; the wave drains them and raises ITS OWN flag
 //           (line m-tile*2 + local tile of its workgroup's flag block)
-template <int KSM, bool GM, int CELL>
+template <int KSM, bool GM, int CELL, bool DBG>
 __global__ __launch_bounds__(256, 1) void lstm_fwd_wave_kernel(CLaunch L) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __builtin_amdgcn_s_setprio(3);
@@ -568,8 +568,8 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wave_kernel(CLaunch L) {
   const unsigned pub_off = lane < 32 ? (unsigned)((((ht * 2 + mt) * 256) + lane * 8) * 2) : OOB;
 
   unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last = 0;
-#define STAMP(i) do { if (L.dbg && tid == 0) { unsigned long long now_ = __builtin_readcyclecounter(); ph[i] += now_ - last; last = now_; } } while (0)
-  if (L.dbg && tid == 0) last = __builtin_readcyclecounter();
+#define STAMP(i) do { if (DBG && L.dbg && tid == 0) { unsigned long long now_ = __builtin_readcyclecounter(); ph[i] += now_ - last; last = now_; } } while (0)
+  if (DBG && L.dbg && tid == 0) last = __builtin_readcyclecounter();
 
   bool alive = true;
   float sv[4][6];                                       // stash of the previous step, flushed behind the next step's fragment loads
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wave_kernel(CLaunch L) {
           for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k2], wreg[g][k2], acc[g], 0, 0, 0);
         }
       }
-      if (L.dbg) { asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0])); STAMP(2); }
+      if (DBG && L.dbg) { asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0])); STAMP(2); }
     }
     // lane-local cell update, branch-free (inactive lanes compute on zeros and are masked by the selects / OOB stores)
 #pragma unroll
@@ -674,7 +674,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wave_kernel(CLaunch L) {
     if (step < T && alive) { do_step(step, pre[0], pre[1]); ++step; }
     if (alive && T > 0) flush(T - 1, (T - 1) & 1 ? pre[1] : pre[0]);
   }
-  if (L.dbg && tid == 0)
+  if (DBG && L.dbg && tid == 0)
     for (int i = 0; i < 8; ++i) L.dbg[(size_t)role * 8 + i] = ph[i];
 #undef STAMP
   // final hidden state straight into the utterance layout [h1_fwd, h2_fwd, h1_bwd, h2_bwd] (models.py:203)
@@ -972,7 +972,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(CLaunch L) {
 // four bf16 = 8 bytes per lane).  The consumer of tile nt reads its nHT partials with one 8-byte sc1 load per lane and
 // producer, sums them in fp32 straight in fragment order and runs the lane-local cell backward: no workgroup barrier, no
 // LDS staging of gathered data, no transposition on the consumer side.
-template <int NTM, bool GM, int CELL>
+template <int NTM, bool GM, int CELL, bool DBG>
 __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __builtin_amdgcn_s_setprio(3);
@@ -1143,8 +1143,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
   bool paired = false;                                  // arrangement of the image the NEXT gather reads (= what the last publish used)
 
   unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last = 0;
-#define STAMP(i) do { if (L.dbg && tid == 0) { unsigned long long now_ = __builtin_readcyclecounter(); ph[i] += now_ - last; last = now_; } } while (0)
-  if (L.dbg && tid == 0) last = __builtin_readcyclecounter();
+#define STAMP(i) do { if (DBG && L.dbg && tid == 0) { unsigned long long now_ = __builtin_readcyclecounter(); ph[i] += now_ - last; last = now_; } } while (0)
+  if (DBG && L.dbg && tid == 0) last = __builtin_readcyclecounter();
   bool alive = true;
   typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
   float dgv[4][4];                                      // fp32 dG of the previous step, stored behind the next step's gather loads
@@ -1219,7 +1219,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
         }
       }
     }
-    if (L.dbg) { asm volatile("s_nop 0" :: "v"(dh_rec[0]), "v"(dh_rec[1]), "v"(dh_rec[2]), "v"(dh_rec[3])); STAMP(2); }
+    if (DBG && L.dbg) { asm volatile("s_nop 0" :: "v"(dh_rec[0]), "v"(dh_rec[1]), "v"(dh_rec[2]), "v"(dh_rec[3])); STAMP(2); }
     // lane-local gate gradients of the own hidden units: linear in dh / dc with the factors derive() prepared
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -1293,7 +1293,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
     for (; step < T && alive; ++step) do_step(step);
     if (alive && T > 0) flush(T - 1);
   }
-  if (L.dbg && tid == 0)
+  if (DBG && L.dbg && tid == 0)
     for (int i = 0; i < 8; ++i) L.dbg[(size_t)role * 8 + i] = ph[i];
 #undef STAMP
 }
@@ -1503,14 +1503,18 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
     const bool reserve = wpb == 1 && grid_blocks <= 160;
     const size_t lds_launch = fwd_wave ? (reserve ? (size_t)(lds_kb < 8 ? 8 : lds_kb > 160 ? 160 : lds_kb) * 1024 : (size_t)4 * 2048) : lds;
     dim3 grid(grid_blocks), block(fwd_wave ? 64 * wpb : 256);
+    // the cycle stamps of tools/diag_lstm_phases.py live in a kernel instance of their own (gate-minor LSTM only): even a never-taken
+    // branch per phase costs the production kernels scheduling freedom
+    const bool dbgk = g_dbg != nullptr && fwd_wave && !gru && L.gate_minor;
 #define LAUNCH_C()                                                                                               \
   do {                                                                                                           \
-    auto kfn = gru ? (bwd ? (L.gate_minor ? lstm_bwd_wave_kernel<20, true, MMDA_CELL_GRU> : lstm_bwd_wave_kernel<20, false, MMDA_CELL_GRU>) \
-                          : (L.gate_minor ? lstm_fwd_wave_kernel<10, true, MMDA_CELL_GRU> : lstm_fwd_wave_kernel<10, false, MMDA_CELL_GRU>)) \
-             : bwd ? (fwd_wave ? (L.gate_minor ? lstm_bwd_wave_kernel<20, true, MMDA_CELL_LSTM> : lstm_bwd_wave_kernel<20, false, MMDA_CELL_LSTM>) \
+    auto kfn = dbgk ? (bwd ? lstm_bwd_wave_kernel<20, true, MMDA_CELL_LSTM, true> : lstm_fwd_wave_kernel<10, true, MMDA_CELL_LSTM, true>)          \
+             : gru ? (bwd ? (L.gate_minor ? lstm_bwd_wave_kernel<20, true, MMDA_CELL_GRU, false> : lstm_bwd_wave_kernel<20, false, MMDA_CELL_GRU, false>) \
+                          : (L.gate_minor ? lstm_fwd_wave_kernel<10, true, MMDA_CELL_GRU, false> : lstm_fwd_wave_kernel<10, false, MMDA_CELL_GRU, false>)) \
+             : bwd ? (fwd_wave ? (L.gate_minor ? lstm_bwd_wave_kernel<20, true, MMDA_CELL_LSTM, false> : lstm_bwd_wave_kernel<20, false, MMDA_CELL_LSTM, false>) \
                     : bwd_regs ? (L.gate_minor ? lstm_bwd_cluster_kernel<10, true> : lstm_bwd_cluster_kernel<10, false>)                \
                               : (L.gate_minor ? lstm_bwd_cluster_kernel<0, true> : lstm_bwd_cluster_kernel<0, false>))                  \
-                   : fwd_wave ? (L.gate_minor ? lstm_fwd_wave_kernel<10, true, MMDA_CELL_LSTM> : lstm_fwd_wave_kernel<10, false, MMDA_CELL_LSTM>) \
+                   : fwd_wave ? (L.gate_minor ? lstm_fwd_wave_kernel<10, true, MMDA_CELL_LSTM, false> : lstm_fwd_wave_kernel<10, false, MMDA_CELL_LSTM, false>) \
                               : (L.gate_minor ? lstm_fwd_cluster_kernel<10, true> : lstm_fwd_cluster_kernel<10, false>);                 \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,     \
                             (int)lds_launch) != hipSuccess) { (void)hipGetLastError(); }                         \
