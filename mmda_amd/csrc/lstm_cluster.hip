@@ -972,7 +972,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(CLaunch L) {
 // four bf16 = 8 bytes per lane).  The consumer of tile nt reads its nHT partials with one 8-byte sc1 load per lane and
 // producer, sums them in fp32 straight in fragment order and runs the lane-local cell backward: no workgroup barrier, no
 // LDS staging of gathered data, no transposition on the consumer side.
-template <int NTM, bool GM, int CELL, bool DBG>
+// HDH / D16: compile-time knowledge of "d_hseq is given" (layer 1) and "dG leaves as bf16 only" (0 / 1; 2 = decided at run time)
+template <int NTM, bool GM, int CELL, bool DBG, int HDH = 2, int D16 = 2>
 __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __builtin_amdgcn_s_setprio(3);
@@ -1055,7 +1056,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
   Raw raw;
   Dv dv;
   float c_keep[4] = {0.f, 0.f, 0.f, 0.f};               // cell state of the step being derived (LSTM)
-  const bool has_dh = D.d_hseq != nullptr;
+  const bool has_dh = HDH == 2 ? D.d_hseq != nullptr : HDH == 1;
   auto load_raw = [&](int step) {
     const int t = dir ? step : T - 1 - step;
     const int tp = dir ? t + 1 : t - 1;
@@ -1149,8 +1150,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
   typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
   float dgv[4][4];                                      // fp32 dG of the previous step, stored behind the next step's gather loads
   const __amdgpu_buffer_rsrc_t rg16 = make_rsrc(D.dg16, D.dg16 ? (unsigned)T * B * 2u * G4 * 2u : 0u);
-  const bool has_dg16 = gm && D.dg16 != nullptr;       // workgroup-uniform
-  const bool f32_dg = !(has_dg16 && D.dg16_only);
+  const bool has_dg16 = D16 == 2 ? (gm && D.dg16 != nullptr) : (D16 == 1);       // workgroup-uniform
+  const bool f32_dg = D16 == 2 ? !(has_dg16 && D.dg16_only) : (D16 == 0);
   auto flush = [&](int ps) {
     const int t = dir ? ps : T - 1 - ps;
 #pragma unroll
@@ -1506,12 +1507,28 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
     // the cycle stamps of tools/diag_lstm_phases.py live in a kernel instance of their own (gate-minor LSTM only): even a never-taken
     // branch per phase costs the production kernels scheduling freedom
     const bool dbgk = g_dbg != nullptr && fwd_wave && !gru && L.gate_minor;
+    // backward, production form (gate-minor, dG as bf16 only): instances that know at compile time whether d_hseq exists (layer 1: 2,
+    // layer 2: 1); anything else takes the instance that decides at run time (0)
+    int spec = 0;
+    if (bwd && fwd_wave && L.gate_minor) {
+      bool all16 = true, any_dh = false, all_dh = true;
+      for (int i = 0; i < n; ++i) {
+        all16 = all16 && L.d[i].dg16 != nullptr && L.d[i].dg16_only;
+        any_dh = any_dh || L.d[i].d_hseq != nullptr;
+        all_dh = all_dh && L.d[i].d_hseq != nullptr;
+      }
+      static const int no_spec = getenv("MMDA_LSTM_NO_SPEC") ? 1 : 0;
+      if (all16 && !no_spec) spec = !any_dh ? 1 : (all_dh ? 2 : 0);
+    }
 #define LAUNCH_C()                                                                                               \
   do {                                                                                                           \
     auto kfn = dbgk ? (bwd ? lstm_bwd_wave_kernel<20, true, MMDA_CELL_LSTM, true> : lstm_fwd_wave_kernel<10, true, MMDA_CELL_LSTM, true>)          \
              : gru ? (bwd ? (L.gate_minor ? lstm_bwd_wave_kernel<20, true, MMDA_CELL_GRU, false> : lstm_bwd_wave_kernel<20, false, MMDA_CELL_GRU, false>) \
                           : (L.gate_minor ? lstm_fwd_wave_kernel<10, true, MMDA_CELL_GRU, false> : lstm_fwd_wave_kernel<10, false, MMDA_CELL_GRU, false>)) \
-             : bwd ? (fwd_wave ? (L.gate_minor ? lstm_bwd_wave_kernel<20, true, MMDA_CELL_LSTM, false> : lstm_bwd_wave_kernel<20, false, MMDA_CELL_LSTM, false>) \
+             : bwd ? (fwd_wave ? (L.gate_minor ? (spec == 1 ? lstm_bwd_wave_kernel<20, true, MMDA_CELL_LSTM, false, 0, 1>                        \
+                                                 : spec == 2 ? lstm_bwd_wave_kernel<20, true, MMDA_CELL_LSTM, false, 1, 1>                        \
+                                                             : lstm_bwd_wave_kernel<20, true, MMDA_CELL_LSTM, false>)                             \
+                                               : lstm_bwd_wave_kernel<20, false, MMDA_CELL_LSTM, false>)                                           \
                     : bwd_regs ? (L.gate_minor ? lstm_bwd_cluster_kernel<10, true> : lstm_bwd_cluster_kernel<10, false>)                \
                               : (L.gate_minor ? lstm_bwd_cluster_kernel<0, true> : lstm_bwd_cluster_kernel<0, false>))                  \
                    : fwd_wave ? (L.gate_minor ? lstm_fwd_wave_kernel<10, true, MMDA_CELL_LSTM, false> : lstm_fwd_wave_kernel<10, false, MMDA_CELL_LSTM, false>) \
