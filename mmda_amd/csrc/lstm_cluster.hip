@@ -22,6 +22,7 @@
 #include "common.h"
 #include <algorithm>
 #include <stdlib.h>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -465,7 +466,8 @@ __device__ __forceinline__ bool xcc_all_local(const unsigned char* tile_flag, bo
 //   publish the wave's 16 x 16 bf16 tile goes through 512 B of wave-private LDS (fragment order -> row order) and out as 32
 //           16-byte write-through stores covering whole 64-byte sectors; the wave drains them and raises ITS OWN flag
 //           (line m-tile*2 + local tile of its workgroup's flag block)
-template <int KSM, bool GM, int CELL, bool DBG>
+// NST: compile-time knowledge of "no stash" (evaluation pass): 0 = stash, 1 = none, 2 = decided at run time
+template <int KSM, bool GM, int CELL, bool DBG, int NST = 2>
 __global__ __launch_bounds__(256, 1) void lstm_fwd_wave_kernel(CLaunch L) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __builtin_amdgcn_s_setprio(3);
@@ -575,13 +577,14 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wave_kernel(CLaunch L) {
   float sv[4][6];                                       // stash of the previous step, flushed behind the next step's fragment loads
   // off the chain: the stash of step `ps` for the backward pass and the pre-activations of step ps + 2 into the buffer that
   // step used.  Issued right after a step's fragment loads (in front of the poll they would delay every wave's flag reads).
+  const bool no_stash = NST == 2 ? L.no_stash != 0 : NST == 1;      // launch-uniform
   auto flush = [&](int ps, float (&Pp)[4][4]) {
     const int t = dir ? T - 1 - ps : ps;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool act = t < len_r[r];
-      const unsigned o = (act && !L.no_stash) ? og[r] + (unsigned)t * sg : OOB;
-      if (!L.no_stash) {                                 // launch-uniform
+      const unsigned o = (act && !no_stash) ? og[r] + (unsigned)t * sg : OOB;
+      if (!no_stash) {
         if (gm) {
           stf4(rg, o, f32x4{sv[r][0], sv[r][1], sv[r][2], sv[r][3]});
         } else {
@@ -593,25 +596,31 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wave_kernel(CLaunch L) {
       stf(rh, inb[r] ? oh[r] + (unsigned)t * sc : OOB, sv[r][5]);     // zero at padded positions (pad_packed_sequence)
     }
     // batch-minor stash: the lane's four samples in one 16-byte store (rows past their length carry the frozen state: never read)
-    if (gm && !L.no_stash) stf4(rc, inb[0] ? oc[0] + (unsigned)t * scc : OOB, f32x4{sv[0][4], sv[1][4], sv[2][4], sv[3][4]});
+    if (gm && !no_stash) stf4(rc, inb[0] ? oc[0] + (unsigned)t * scc : OOB, f32x4{sv[0][4], sv[1][4], sv[2][4], sv[3][4]});
     load_pre(Pp, ps + 2);
   };
   bool fast = false;                                    // XCD-local hand-off in force (wave-uniform, same in every wave of the m-tile)
   const unsigned xcc = my_xcc_id() ^ ((L.xcd_local == 3 && (ht & 1)) ? 8u : 0u);   // (3: test hook, odd tiles announce a wrong id)
   if (L.xcd_local && lane == 0) xcc_announce(my_flag, L.epoch_base, xcc);
-  // P: pre-activations of this step; Pp: the buffer the previous step used (refilled for step + 1 by flush)
-  auto do_step = [&](int step, float (&P)[4][4], float (&Pp)[4][4]) {
+  // One time step.  P: pre-activations of this step; Pp: the buffer the previous step used (refilled for step + 1 by flush).
+  // FIRST (step 0: h = 0, nothing to wait for) and FM (hand-off form: 0 = the `fast` variable -- steps 0 and 1, before and while the
+  // placement is being checked --, 1 = XCD-local for sure, 2 = write-through for sure) are compile-time tags: the steady-state
+  // steps carry no step-number or form branches -- every such branch, taken or not, splits the wave's instruction schedule.
+  auto do_step = [&](int step, float (&P)[4][4], float (&Pp)[4][4], auto first_tag, auto fm_tag) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    constexpr int FM = decltype(fm_tag)::value;
+    constexpr bool ALLK = false;          // true: all KSM k-steps unconditionally (measured slower: see the note at the loop)
     const int t = dir ? T - 1 - step : step;
     const unsigned epoch = L.epoch_base + (unsigned)step + 1u;
     f32x4 acc[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (step > 0) {
+    if (!FIRST) {
       // every hidden tile of this m-tile must have published the previous step
       const unsigned need = epoch - 1u;
       alive = poll_tiles(poll_flag, abort_w, lane < nHT, need);
       if (!alive) { if (lane == 0) st_flag(abort_w, 1u); return; }
-      if (L.xcd_local && step == 1) fast = xcc_all_local(poll_flag, lane < nHT, L.epoch_base, xcc);
+      if (FM == 0 && L.xcd_local && step == 1) fast = xcc_all_local(poll_flag, lane < nHT, L.epoch_base, xcc);
       STAMP(0);
       const unsigned par = (need & 1u) * slot_b;
       bf16x8 af[KSM];
@@ -620,9 +629,11 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wave_kernel(CLaunch L) {
         af[k2] = __builtin_bit_cast(bf16x8, ld16_sc1(xr, (k2 < KS && 2 * k2 + (fq >> 1) < nHT) ? par + frag_base + (unsigned)k2 * 2048u : OOB));
       flush(step - 1, Pp);
       STAMP(1);
+      // (skipping the k-steps past a narrow modality's depth by a wave-uniform test per k-step; issuing all of them on zero operands
+      // instead was measured slower)
 #pragma unroll
       for (int k2 = 0; k2 < KSM; ++k2) {
-        if (k2 < KS) {                                   // workgroup-uniform
+        if (ALLK || k2 < KS) {                           // workgroup-uniform
 #pragma unroll
           for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k2], wreg[g][k2], acc[g], 0, 0, 0);
         }
@@ -657,21 +668,37 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wave_kernel(CLaunch L) {
       STAMP(3);
       const unsigned par = (epoch & 1u) * slot_b;
       const u32x4 v = *reinterpret_cast<const u32x4*>(&Tr[(lane & 31) * 8]);
-      if (fast) st16_plain(xr, pub_off == OOB ? OOB : par + pub_off, v);
+      const bool fst = FM == 0 ? fast : FM == 1;
+      if (fst) st16_plain(xr, pub_off == OOB ? OOB : par + pub_off, v);
       else st16_sc1(xr, pub_off == OOB ? OOB : par + pub_off, v);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's stores have landed (in L2 / written through)
       STAMP(4);
-      if (lane == 0) { if (fast) st_flag_plain(my_flag, epoch); else st_flag(my_flag, epoch); }
+      if (lane == 0) { if (fst) st_flag_plain(my_flag, epoch); else st_flag(my_flag, epoch); }
     }
   };
   {
+    typedef std::integral_constant<bool, true> TrueT;
+    typedef std::integral_constant<bool, false> FalseT;
+    typedef std::integral_constant<int, 0> FmVar;
+    typedef std::integral_constant<int, 1> FmLocal;
+    typedef std::integral_constant<int, 2> FmThrough;
     // pre[0] holds step 0, pre[1] step 1; afterwards flush() refills the buffer of step s - 1 with step s + 1
     int step = 0;
-    for (; step + 1 < T && alive; step += 2) {
-      do_step(step, pre[0], pre[1]);
-      if (alive) do_step(step + 1, pre[1], pre[0]);
+    if (T > 0) { do_step(0, pre[0], pre[1], TrueT{}, FmVar{}); step = 1; }
+    if (T > 1 && alive) { do_step(1, pre[1], pre[0], FalseT{}, FmVar{}); step = 2; }
+    if (fast) {
+      for (; step + 1 < T && alive; step += 2) {
+        do_step(step, pre[0], pre[1], FalseT{}, FmLocal{});
+        if (alive) do_step(step + 1, pre[1], pre[0], FalseT{}, FmLocal{});
+      }
+      if (step < T && alive) { do_step(step, pre[0], pre[1], FalseT{}, FmLocal{}); ++step; }
+    } else {
+      for (; step + 1 < T && alive; step += 2) {
+        do_step(step, pre[0], pre[1], FalseT{}, FmThrough{});
+        if (alive) do_step(step + 1, pre[1], pre[0], FalseT{}, FmThrough{});
+      }
+      if (step < T && alive) { do_step(step, pre[0], pre[1], FalseT{}, FmThrough{}); ++step; }
     }
-    if (step < T && alive) { do_step(step, pre[0], pre[1]); ++step; }
     if (alive && T > 0) flush(T - 1, (T - 1) & 1 ? pre[1] : pre[0]);
   }
   if (DBG && L.dbg && tid == 0)
@@ -1531,7 +1558,9 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
                                                : lstm_bwd_wave_kernel<20, false, MMDA_CELL_LSTM, false>)                                           \
                     : bwd_regs ? (L.gate_minor ? lstm_bwd_cluster_kernel<10, true> : lstm_bwd_cluster_kernel<10, false>)                \
                               : (L.gate_minor ? lstm_bwd_cluster_kernel<0, true> : lstm_bwd_cluster_kernel<0, false>))                  \
-                   : fwd_wave ? (L.gate_minor ? lstm_fwd_wave_kernel<10, true, MMDA_CELL_LSTM, false> : lstm_fwd_wave_kernel<10, false, MMDA_CELL_LSTM, false>) \
+                   : fwd_wave ? (L.gate_minor ? (L.no_stash ? lstm_fwd_wave_kernel<10, true, MMDA_CELL_LSTM, false, 1>                         \
+                                                            : lstm_fwd_wave_kernel<10, true, MMDA_CELL_LSTM, false, 0>)                         \
+                                              : lstm_fwd_wave_kernel<10, false, MMDA_CELL_LSTM, false>)                                           \
                               : (L.gate_minor ? lstm_fwd_cluster_kernel<10, true> : lstm_fwd_cluster_kernel<10, false>);                 \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,     \
                             (int)lds_launch) != hipSuccess) { (void)hipGetLastError(); }                         \
