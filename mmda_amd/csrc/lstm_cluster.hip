@@ -1199,17 +1199,23 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
   bool fast = false;                                    // XCD-local hand-off in force (see xcc_announce)
   const unsigned xcc = my_xcc_id() ^ ((L.xcd_local == 3 && (ht & 1)) ? 8u : 0u);   // (3: test hook, odd tiles announce a wrong id)
   if (L.xcd_local && lane == 0) xcc_announce(my_flag, L.epoch_base, xcc);
-  auto do_step = [&](int step) {
+  // One step of the walk.  FIRST (step 0: nothing to gather) and FM (hand-off form: 0 = the `fast` / `paired` variables -- steps 0 and
+  // 1, before and while the placement is being checked --, 1 = XCD-local and paired for sure, 2 = write-through and unpaired for sure)
+  // are compile-time tags: the steady-state steps carry no step-number or form branches (each one, taken or not, splits the wave's
+  // instruction schedule; see the forward kernel).
+  auto do_step = [&](int step, auto first_tag, auto fm_tag) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    constexpr int FM = decltype(fm_tag)::value;
     const unsigned epoch = L.epoch_base + (unsigned)step + 1u;
     float dh_rec[4] = {0.f, 0.f, 0.f, 0.f};
-    if (step > 0) {
+    if (!FIRST) {
       const unsigned need = epoch - 1u;
       alive = poll_tiles(poll_flag, abort_w, lane < nHT, need);
       if (!alive) { if (lane == 0) st_flag(abort_w, 1u); return; }
-      if (L.xcd_local && step == 1) fast = xcc_all_local(poll_flag, lane < nHT, L.epoch_base, xcc);
+      if (FM == 0 && L.xcd_local && step == 1) fast = xcc_all_local(poll_flag, lane < nHT, L.epoch_base, xcc);
       STAMP(0);
       const unsigned par = (need & 1u) * slot_b;
-      if (paired) {                                      // wave-uniform
+      if (FM == 0 ? paired : FM == 1) {                  // wave-uniform (compile-time in the steady state)
         u32x4 gq[NTM / 2];
 #pragma unroll
         for (int q = 0; q < NTM / 2; ++q)
@@ -1292,7 +1298,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
       for (int nt = 0; nt < NTM; ++nt) accs[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wreg[nt][1], accs[nt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       // the tile-dependent part of the offset is wave-uniform (scalar select, one vector add); tiles past nHT go out of range
-      if (fast) {
+      const bool fst = FM == 0 ? fast : FM == 1;
+      if (fst) {
 #pragma unroll
         for (int nt = 0; nt < NTM; ++nt) {
           const u32x2 pk = {pack_bf16x2(accs[nt][0], accs[nt][1]), pack_bf16x2(accs[nt][2], accs[nt][3])};
@@ -1310,15 +1317,23 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
       STAMP(4);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's stores have landed (in L2 / written through)
       STAMP(5);
-      if (lane == 0) { if (fast) st_flag_plain(my_flag, epoch); else st_flag(my_flag, epoch); }
-      paired = fast;
+      if (lane == 0) { if (fst) st_flag_plain(my_flag, epoch); else st_flag(my_flag, epoch); }
+      paired = fst;
       __builtin_amdgcn_sched_barrier(0);                             // keep the folding behind the hand-off
       derive(step + 1);
     }
   };
   {
     int step = 0;
-    for (; step < T && alive; ++step) do_step(step);
+    typedef std::integral_constant<bool, true> TrueT;
+    typedef std::integral_constant<bool, false> FalseT;
+    typedef std::integral_constant<int, 0> FmVar;
+    typedef std::integral_constant<int, 1> FmLocal;
+    typedef std::integral_constant<int, 2> FmThrough;
+    if (T > 0) { do_step(0, TrueT{}, FmVar{}); step = 1; }
+    if (T > 1 && alive) { do_step(1, FalseT{}, FmVar{}); step = 2; }
+    if (fast) { for (; step < T && alive; ++step) do_step(step, FalseT{}, FmLocal{}); }
+    else { for (; step < T && alive; ++step) do_step(step, FalseT{}, FmThrough{}); }
     if (alive && T > 0) flush(T - 1);
   }
   if (DBG && L.dbg && tid == 0)
