@@ -1341,6 +1341,301 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
 #undef STAMP
 }
 
+// ------------------------------------------------------------------------------------------------ forward, four waves per tile
+// The wave-autonomous kernel above spends its step inside ONE wave: 40 MFMAs (~640 cycles), 40 quarter-rate transcendentals plus the
+// cell arithmetic for 16 elements per lane (~1200 cycles), 24 memory instructions.  Here a (16-sample m-tile, 16-unit hidden tile)
+// belongs to a WORKGROUP of four waves that split the step's serial work four ways:
+//   k-split  wave w multiplies k-steps w, w+4, w+8 of h_{t-1} W_hh^T for all four gates (<= 12 MFMAs); it polls the flags of -- and
+//            loads fragments from -- the <= 6 hidden tiles those k-steps cover, nothing else
+//   reduce   the four partial 16 x 64 gate tiles meet in LDS (one 16-byte write per accumulator row, ONE workgroup barrier per step,
+//            double buffered by step parity), summed in a fixed order (wave 0..3)
+//   cell     wave w then owns samples 4w..4w+3 of the tile: ONE element per lane (5 exp + 5 rcp instead of 20 + 20), one 16-byte
+//            stash store, one cell-state and one h store per lane
+//   publish  the wave's four rows of the tile are 128 contiguous bytes of the exchange image (one line): one 2-byte store per lane,
+//            drained, then the wave raises ITS flag (dword w of the tile's flag line, bytes 32..47; the placement announcement sits at
+//            bytes 48..55 -- the wave-autonomous kernels use bytes 0..15 of the same lines)
+// A publish at step s+2 overwrites the image of step s: it happens after the workgroup barrier of step s+2, i.e. after the four
+// waves together have seen every tile's four flags for step s+1, hence after every reader of the step-s image has finished with it.
+// A wave whose poll times out raises the abort word and from then on stops waiting (its results are garbage, the host discards the
+// launch) but keeps arriving at the barriers, so the grid always drains.
+constexpr int QUAD_LDS = 2 * 4 * 16 * 16 * 4 * 4;      // bytes: parity x source wave x 16 rows x 16 units x 4 gates, fp32
+
+__device__ __forceinline__ bool flags4_reached(u32x4 f, unsigned need) {
+  return (int)(f[0] - need) >= 0 && (int)(f[1] - need) >= 0 && (int)(f[2] - need) >= 0 && (int)(f[3] - need) >= 0;
+}
+// lane-per-tile poll of the four wave flags of a tile (one 16-byte L1-bypassing load); three reads in flight (see poll_tiles)
+__device__ __forceinline__ bool poll_tiles4(__amdgpu_buffer_rsrc_t fr4, unsigned off, const unsigned char* abort_w, bool watching, unsigned need) {
+  u32x4 f0 = ld16_sc1(fr4, off);
+  __builtin_amdgcn_s_sleep(2);
+  u32x4 f1 = ld16_sc1(fr4, off);
+  __builtin_amdgcn_s_sleep(2);
+  u32x4 f2 = ld16_sc1(fr4, off);
+  for (unsigned spins = 0;; spins += 3) {
+    if (__all(!watching || flags4_reached(f0, need))) return true;
+    f0 = ld16_sc1(fr4, off);
+    if (__all(!watching || flags4_reached(f1, need))) return true;
+    f1 = ld16_sc1(fr4, off);
+    if (__all(!watching || flags4_reached(f2, need))) return true;
+    f2 = ld16_sc1(fr4, off);
+    if (spins > SPIN_LIMIT || ((spins & 255u) == 0 && spins && ld_flag(abort_w) != 0)) return false;
+  }
+}
+
+template <int CELL, int NST>
+__global__ __launch_bounds__(256, 1) void lstm_fwd_quad_kernel(CLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __builtin_amdgcn_s_setprio(3);
+  const int role = L.blk2role[blockIdx.x];
+  if (role < 0) return;
+  Where wh;
+  wh.di = 0;
+#pragma unroll
+  for (int i = 1; i < MAXD; ++i)
+    if (i < L.n && role >= L.d[i].wg_begin) wh.di = i;
+  const CDesc& D = L.d[wh.di];
+  {
+    const int local = role - D.wg_begin;
+    wh.dir = local / (L.ng * D.NCw);
+    const int rem = local % (L.ng * D.NCw);
+    wh.grp = L.g0 + rem / D.NCw;
+    wh.me = rem % D.NCw;
+  }
+  const int H = D.H, Hp = D.Hp, KS = D.KS, nHT = D.nHT, NC = D.NC;
+  const int B = L.B, T = L.T, dir = wh.dir;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;             // MFMA frame: operand row / accumulator column fr, accumulator rows 4 fq ..+3
+  const int rho = wh.me;                                // one workgroup per (hidden tile, m-tile)
+  const int mt = rho & 1, ht = rho >> 1;
+  const int row = 4 * w + fq, b = wh.grp * GROUP + mt * 16 + row, col = ht * 16 + fr;      // cell frame: the lane's one element
+  const int ngt = (B + GROUP - 1) / GROUP;
+  const unsigned G4 = 4u * H;
+  float* red = reinterpret_cast<float*>(smem);
+
+  unsigned char* abort_w = D.xchg;
+  unsigned char* flags = D.xchg + xchg_flags_off() + ((size_t)(dir * ngt + wh.grp) * NC) * FLAG_STRIDE;
+  unsigned char* Xb = D.xchg + xchg_x_off(ngt, NC) + ((size_t)(dir * ngt + wh.grp) * 2) * xchg_slot(NC, Hp);
+  unsigned char* my_line = flags + (size_t)rho * 64;
+  unsigned char* my_flag = my_line + 32 + 4 * w;
+  const __amdgpu_buffer_rsrc_t fr4 = make_rsrc(flags, (unsigned)(2 * nHT) * 64u);
+  // steady state: lane j < 6 watches tile 2 (w + 4 (j >> 1)) + (j & 1); step 1: lane tau watches tile tau (placement check)
+  const int pk2 = w + 4 * (lane >> 1), ptile = 2 * pk2 + (lane & 1);
+  const bool pwatch = lane < 6 && pk2 < KS && ptile < nHT;
+  const unsigned poff = pwatch ? (unsigned)(ptile * 2 + mt) * 64u + 32u : OOB;
+  const bool awatch = lane < nHT;
+  const unsigned aoff = awatch ? (unsigned)(lane * 2 + mt) * 64u + 32u : OOB;
+
+  bf16x8 wreg[4][3];
+  {
+    const bf16x8* src = reinterpret_cast<const bf16x8*>(D.wpack[dir]);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int k2 = w + 4 * j;
+        wreg[g][j] = k2 < KS ? src[((size_t)(ht * 4 + g) * KS + k2) * 64 + lane] : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+  }
+  const __amdgpu_buffer_rsrc_t rg = make_rsrc(D.gates, (unsigned)T * B * 2u * G4 * 4u);
+  const __amdgpu_buffer_rsrc_t rc = make_rsrc(D.cstash, (unsigned)T * (unsigned)((B + 3) & ~3) * 2u * H * 4u);
+  const unsigned scc = (unsigned)((B + 3) >> 2) * 2u * H * 16u;
+  const __amdgpu_buffer_rsrc_t rh = make_rsrc(D.hseq, (unsigned)T * B * 2u * H * 4u);
+  const unsigned sg = (unsigned)B * 2u * G4 * 4u, sc = (unsigned)B * 2u * H * 4u;
+  const bool inb = col < H && b < B;
+  const int len = inb ? L.lengths[min(b, B - 1)] : 0;
+  const unsigned og = (((unsigned)b * 2u + dir) * G4 + col * 4) * 4u;
+  const unsigned oc = ((((((unsigned)b >> 2) * 2u + dir) * H + col) << 2) + ((unsigned)b & 3u)) * 4u;
+  const unsigned oh = ((unsigned)b * 2u * H + dir * H + col) * 4u;
+  float c_reg = 0.f, h_reg = 0.f;
+  f32x4 pre[2];
+  auto load_pre = [&](f32x4& dst, int step) {
+    const int t = dir ? T - 1 - step : step;
+    dst = ldf4(rg, (step < T && t < len) ? og + (unsigned)t * sg : OOB);
+  };
+  load_pre(pre[0], 0);
+  load_pre(pre[1], 1);
+  const unsigned slot_b = (unsigned)xchg_slot(NC, Hp);
+  const unsigned img_b = (unsigned)nHT * 2u * 512u;
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(Xb, slot_b + img_b);
+  // A fragment of k-step k2: tile 2 k2 + (fq >> 1), row fr, units 8 (fq & 1) ..+7 (the tile-major image of the wave-autonomous form)
+  unsigned foff[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int k2 = w + 4 * j;
+    foff[j] = (k2 < KS && 2 * k2 + (fq >> 1) < nHT) ? (unsigned)(((((fq >> 1) * 2 + mt) * 256) + fr * 16 + 8 * (fq & 1)) * 2) + (unsigned)k2 * 2048u : FAR;
+  }
+  const unsigned pub_off = (unsigned)((((ht * 2 + mt) * 256) + row * 16 + fr) * 2);
+  constexpr unsigned TAGS = 0x40004000u;                // bit 14 of both bf16 halves of a dword
+  unsigned chk[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) chk[j] = foff[j] != FAR ? TAGS : 0u;
+  // LDS: partial of source wave s, element (row, unit): 4 gates = 16 bytes at ((s * 16 + row) * 16 + unit) * 4 floats
+  const unsigned wr_base = (unsigned)(((w * 16 + 4 * fq) * 16 + fr) * 4);              // + rr * 64 floats, + parity * 4096
+  const unsigned rd_base = (unsigned)((row * 16 + fr) * 4);                              // + s * 1024 floats, + parity * 4096
+
+  bool dead = false;                                    // a poll of this wave timed out (or the launch was aborted): stop waiting
+  float sv[6];
+  constexpr bool no_stash = NST == 1;
+  auto flush = [&](int ps, f32x4& Pp) {
+    const int t = dir ? T - 1 - ps : ps;
+    const bool act = t < len;
+    if (!no_stash) {
+      stf4(rg, act ? og + (unsigned)t * sg : OOB, f32x4{sv[0], sv[1], sv[2], sv[3]});
+      stf(rc, inb ? oc + (unsigned)t * scc : OOB, sv[4]);        // rows past their length carry the frozen state (never read)
+    }
+    stf(rh, inb ? oh + (unsigned)t * sc : OOB, sv[5]);           // zero at padded positions (pad_packed_sequence)
+    load_pre(Pp, ps + 2);
+  };
+  bool fast = false;
+  const unsigned xcc = my_xcc_id() ^ ((L.xcd_local == 3 && (ht & 1)) ? 8u : 0u);
+  if (L.xcd_local && tid == 0)
+    __hip_atomic_store((gu64*)(my_line + 48), ((unsigned long long)xcc << 32) | L.epoch_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+  auto do_step = [&](int step, f32x4& P, f32x4& Pp, auto first_tag, auto fm_tag) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    constexpr int FM = decltype(fm_tag)::value;
+    const int t = dir ? T - 1 - step : step;
+    const unsigned epoch = L.epoch_base + (unsigned)step + 1u;
+    f32x4 z = P;
+    if (!FIRST) {
+      const unsigned need = epoch - 1u;
+      const unsigned par = (need & 1u) * slot_b;
+      const unsigned tm = ((need >> 1) & 1u) ? TAGS : 0u;           // the tag bits the image of epoch `need` carries
+      u32x4 fa[3];
+      if (FM == 0) {                                     // steps 1 and 2: flags (the image may hold a previous launch's tags)
+        if (!dead) {
+          const bool ok = poll_tiles4(fr4, aoff, abort_w, awatch, need);
+          if (!ok) { dead = true; if (lane == 0) st_flag(abort_w, 1u); }
+        }
+        if (L.xcd_local && step == 1) {
+          const unsigned long long v = __hip_atomic_load((const gu64*)(flags + (size_t)((awatch ? lane : 0) * 2 + mt) * 64 + 48), __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT);
+          fast = __all(!awatch || v == (((unsigned long long)xcc << 32) | L.epoch_base));
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) fa[j] = ld16_sc1(xr, par + foff[j]);
+      } else {                                           // steady state: the fragments themselves say when they are there
+        u32x4 fb[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) fa[j] = ld16_sc1(xr, par + foff[j]);
+        __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) fb[j] = ld16_sc1(xr, par + foff[j]);
+        auto stale = [&](const u32x4 (&f)[3]) {          // some element of a fragment this lane needs still carries the other tag
+          unsigned t = 0;
+#pragma unroll
+          for (int j = 0; j < 3; ++j) t |= (((f[j][0] ^ tm) | (f[j][1] ^ tm)) | ((f[j][2] ^ tm) | (f[j][3] ^ tm))) & chk[j];
+          return t != 0;
+        };
+        if (!dead) {
+          for (unsigned spins = 0;; spins += 2) {
+            if (!__any(stale(fa))) break;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) fa[j] = ld16_sc1(xr, par + foff[j]);
+            if (!__any(stale(fb))) {
+#pragma unroll
+              for (int j = 0; j < 3; ++j) fa[j] = fb[j];
+              break;
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) fb[j] = ld16_sc1(xr, par + foff[j]);
+            if (spins > SPIN_LIMIT || ((spins & 255u) == 0 && spins && ld_flag(abort_w) != 0)) {
+              dead = true;
+              if (lane == 0) st_flag(abort_w, 1u);
+              break;
+            }
+          }
+        }
+      }
+      bf16x8 af[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {                      // tags off (nonexistent tiles read as zero and stay zero)
+        const unsigned cl = chk[j] ? tm : 0u;
+        af[j] = __builtin_bit_cast(bf16x8, u32x4{fa[j][0] ^ cl, fa[j][1] ^ cl, fa[j][2] ^ cl, fa[j][3] ^ cl});
+      }
+      flush(step - 1, Pp);
+      f32x4 acc[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        if (w + 4 * j < KS) {                            // wave-uniform
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], wreg[g][j], acc[g], 0, 0, 0);
+        }
+      }
+      float* wr = red + (step & 1) * 4096 + wr_base;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) *reinterpret_cast<f32x4*>(wr + rr * 64) = f32x4{acc[0][rr], acc[1][rr], acc[2][rr], acc[3][rr]};
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      const float* rd = red + (step & 1) * 4096 + rd_base;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(rd), v1 = *reinterpret_cast<const f32x4*>(rd + 1024);
+      const f32x4 v2 = *reinterpret_cast<const f32x4*>(rd + 2048), v3 = *reinterpret_cast<const f32x4*>(rd + 3072);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) z[g] = (((v0[g] + v1[g]) + v2[g]) + v3[g]) + P[g];
+    }
+    {
+      const bool act = t < len;
+      const float gi = sigmoid_fast(z[0]);
+      const float gf = sigmoid_fast(z[1]);
+      float gg, go, cn, hn;
+      if (CELL == MMDA_CELL_GRU) {       // four-slot GRU (see lstm.hip): slots r, z, x-part of n, h-part of n; stash [r, z, n, q], h
+        go = z[3];
+        gg = tanh_fast(z[2] + gi * go);
+        hn = (1.f - gf) * gg + gf * h_reg;
+        cn = hn;
+      } else {
+        gg = tanh_fast(z[2]);
+        go = sigmoid_fast(z[3]);
+        cn = gf * c_reg + gi * gg;
+        hn = go * tanh_fast(cn);
+      }
+      c_reg = act ? cn : c_reg;
+      h_reg = act ? hn : h_reg;
+      sv[0] = gi; sv[1] = gf; sv[2] = gg; sv[3] = go; sv[4] = c_reg; sv[5] = act ? hn : 0.f;
+    }
+    if (step + 1 < T) {
+      const unsigned par = (epoch & 1u) * slot_b;
+      const bool fst = FM == 0 ? fast : FM == 1;
+      // |h| < 1, so bit 14 of its bf16 form is free: it carries bit 1 of the epoch -- the value alternates between the successive
+      // uses of an image (epochs e, e + 2, ...) and lets a reader tell, element by element, that what it fetched is this step's
+      const short hv = (short)(f2bf(h_reg) | (((epoch >> 1) & 1u) << 14));
+      if (fst) __builtin_amdgcn_raw_buffer_store_b16(hv, xr, par + pub_off, 0, 0);
+      else __builtin_amdgcn_raw_buffer_store_b16(hv, xr, par + pub_off, 0, 16);
+      if (FM == 0 && step < 2) {                         // steps 0 and 1 are announced by flag as well (read by steps 1 and 2)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's stores have landed (in L2 / written through)
+        if (lane == 0) { if (fst) st_flag_plain(my_flag, epoch); else st_flag(my_flag, epoch); }
+      }
+    }
+  };
+  {
+    typedef std::integral_constant<bool, true> TrueT;
+    typedef std::integral_constant<bool, false> FalseT;
+    typedef std::integral_constant<int, 0> FmVar;
+    typedef std::integral_constant<int, 1> FmLocal;
+    typedef std::integral_constant<int, 2> FmThrough;
+    int step = 0;
+    if (T > 0) { do_step(0, pre[0], pre[1], TrueT{}, FmVar{}); step = 1; }
+    if (T > 1) { do_step(1, pre[1], pre[0], FalseT{}, FmVar{}); step = 2; }
+    if (T > 2) { do_step(2, pre[0], pre[1], FalseT{}, FmVar{}); step = 3; }
+    if (fast) {
+      for (; step + 1 < T; step += 2) {
+        do_step(step, pre[1], pre[0], FalseT{}, FmLocal{});
+        do_step(step + 1, pre[0], pre[1], FalseT{}, FmLocal{});
+      }
+      if (step < T) { do_step(step, pre[1], pre[0], FalseT{}, FmLocal{}); ++step; }
+    } else {
+      for (; step + 1 < T; step += 2) {
+        do_step(step, pre[1], pre[0], FalseT{}, FmThrough{});
+        do_step(step + 1, pre[0], pre[1], FalseT{}, FmThrough{});
+      }
+      if (step < T) { do_step(step, pre[1], pre[0], FalseT{}, FmThrough{}); ++step; }
+    }
+    if (T > 0) flush(T - 1, (T - 1) & 1 ? pre[1] : pre[0]);
+  }
+  // final hidden state straight into the utterance layout [h1_fwd, h2_fwd, h1_bwd, h2_bwd] (models.py:203)
+  if (inb) D.utt[(int64_t)b * 4 * H + (dir * 2 + D.layer) * H + col] = h_reg;
+}
+
 struct Plan { int TPW, NC, maxtw; size_t lds_f, lds_b; bool ok; };
 
 Plan plan_for(int H) {
@@ -1464,6 +1759,20 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
   int wpb = 4;
   const bool fwd_wave = wave_form_ok(n, descs, bwd, &wpb, ngt);   // (named for the forward kernel; selects the wave-autonomous form of either pass)
   const bool gru = descs[0].cell == MMDA_CELL_GRU;            // cluster_applicable() admitted GRU only together with the wave form
+  // Four waves per tile (lstm_fwd_quad_kernel): gate-minor layout, every group's tiles in one launch at one workgroup per tile.
+  // MMDA_LSTM_NO_QUAD: ablation (the one-wave-per-tile kernels).
+  bool quad = false;
+  {
+    static const int no_quad = getenv("MMDA_LSTM_NO_QUAD") ? 1 : 0;
+    int tiles = 0;
+    bool okq = fwd_wave && !bwd && !no_quad && g_dbg == nullptr;
+    for (int i = 0; i < n; ++i) {
+      okq = okq && descs[i].gate_minor && round_up(descs[i].H, 32) / 32 <= 12;
+      tiles += 2 * 2 * (round_up(descs[i].H, 16) / 16);
+    }
+    quad = okq && tiles * ngt <= MAX_WG_PER_LAUNCH;
+    if (quad) wpb = 1;
+  }
   int members[MAXD];                       // workgroups per cluster
   int wg_per_group = 0;
   for (int i = 0; i < n; ++i) {
@@ -1544,8 +1853,8 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
     // members of a cluster must all be resident at once -- a launch that wants most of the 256 CUs keeps the small allocation, so
     // that its blocks can share CUs if something else (another process on the GPU) holds some.
     const bool reserve = wpb == 1 && grid_blocks <= 160;
-    const size_t lds_launch = fwd_wave ? (reserve ? (size_t)(lds_kb < 8 ? 8 : lds_kb > 160 ? 160 : lds_kb) * 1024 : (size_t)4 * 2048) : lds;
-    dim3 grid(grid_blocks), block(fwd_wave ? 64 * wpb : 256);
+    const size_t lds_launch = fwd_wave ? (reserve ? (size_t)(lds_kb < 32 ? 32 : lds_kb > 160 ? 160 : lds_kb) * 1024 : (quad ? (size_t)QUAD_LDS : (size_t)4 * 2048)) : lds;
+    dim3 grid(grid_blocks), block(quad ? 256 : (fwd_wave ? 64 * wpb : 256));
     // the cycle stamps of tools/diag_lstm_phases.py live in a kernel instance of their own (gate-minor LSTM only): even a never-taken
     // branch per phase costs the production kernels scheduling freedom
     const bool dbgk = g_dbg != nullptr && fwd_wave && !gru && L.gate_minor;
@@ -1564,7 +1873,9 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
     }
 #define LAUNCH_C()                                                                                               \
   do {                                                                                                           \
-    auto kfn = dbgk ? (bwd ? lstm_bwd_wave_kernel<20, true, MMDA_CELL_LSTM, true> : lstm_fwd_wave_kernel<10, true, MMDA_CELL_LSTM, true>)          \
+    auto kfn = quad ? (gru ? (L.no_stash ? lstm_fwd_quad_kernel<MMDA_CELL_GRU, 1> : lstm_fwd_quad_kernel<MMDA_CELL_GRU, 0>)                           \
+                           : (L.no_stash ? lstm_fwd_quad_kernel<MMDA_CELL_LSTM, 1> : lstm_fwd_quad_kernel<MMDA_CELL_LSTM, 0>))                        \
+             : dbgk ? (bwd ? lstm_bwd_wave_kernel<20, true, MMDA_CELL_LSTM, true> : lstm_fwd_wave_kernel<10, true, MMDA_CELL_LSTM, true>)          \
              : gru ? (bwd ? (L.gate_minor ? lstm_bwd_wave_kernel<20, true, MMDA_CELL_GRU, false> : lstm_bwd_wave_kernel<20, false, MMDA_CELL_GRU, false>) \
                           : (L.gate_minor ? lstm_fwd_wave_kernel<10, true, MMDA_CELL_GRU, false> : lstm_fwd_wave_kernel<10, false, MMDA_CELL_GRU, false>)) \
              : bwd ? (fwd_wave ? (L.gate_minor ? (spec == 1 ? lstm_bwd_wave_kernel<20, true, MMDA_CELL_LSTM, false, 0, 1>                        \

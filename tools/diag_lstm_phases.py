@@ -19,7 +19,7 @@ for it in range(3):
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
-    fw = ops.lstm_bidir_fwd(pre, wf, wr, lengths, mode="bf16", resident=True)
+    fw = ops.lstm_bidir_fwd(pre, wf, wr, lengths, mode="bf16", resident=True, gate_minor=True)   # the stamped kernel instances are gate-minor
     e1.record(); torch.cuda.synchronize()
     lib.mmda_debug_set_lstm_stamps(None)
     print(f"iter {it}: whole op (pack + kernel) {e0.elapsed_time(e1)*1e3:.0f} us; aborted={ops.lstm_aborted(fw)}")
