@@ -1417,10 +1417,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_quad_kernel(CLaunch L) {
   unsigned char* my_line = flags + (size_t)rho * 64;
   unsigned char* my_flag = my_line + 32 + 4 * w;
   const __amdgpu_buffer_rsrc_t fr4 = make_rsrc(flags, (unsigned)(2 * nHT) * 64u);
-  // steady state: lane j < 6 watches tile 2 (w + 4 (j >> 1)) + (j & 1); step 1: lane tau watches tile tau (placement check)
-  const int pk2 = w + 4 * (lane >> 1), ptile = 2 * pk2 + (lane & 1);
-  const bool pwatch = lane < 6 && pk2 < KS && ptile < nHT;
-  const unsigned poff = pwatch ? (unsigned)(ptile * 2 + mt) * 64u + 32u : OOB;
+  // steps 1 and 2 (flags): lane tau watches the four wave flags of tile tau
   const bool awatch = lane < nHT;
   const unsigned aoff = awatch ? (unsigned)(lane * 2 + mt) * 64u + 32u : OOB;
 
@@ -1636,6 +1633,324 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_quad_kernel(CLaunch L) {
   if (inb) D.utt[(int64_t)b * 4 * H + (dir * 2 + D.layer) * H + col] = h_reg;
 }
 
+// ------------------------------------------------------------------------------------------------ backward, four waves per tile
+// The same split for dh_{t-1} = dG_t W_hh (see lstm_bwd_wave_kernel for the reduce-scatter this implements).  The workgroup of a
+// (m-tile, hidden tile) owns the gate gradients of its 16 x 16 elements:
+//   gather   wave w sums the partial dh of rows 4w..4w+3 over all producers.  The image is the write-through form of the wave kernel
+//            ([consumer tile][m-tile][producer][lane] x 8 B, a lane's 8 bytes = rows 4 fq..+3 of unit fr), so those rows are 128
+//            contiguous bytes per producer: lane (producer slot pl = lane >> 3, unit pair uc = lane & 7) fetches 16 bytes (two units
+//            x four rows) of producers pl, pl + 8, pl + 16, adds them in fp32, and a three-stage reduce-scatter across the eight
+//            producer slots (lane bits 5, 4, 3) leaves every lane with the sum of ONE element: unit 2 uc + bit 5, row 2 bit 4 + bit 3
+//   cell     one element per lane, factors prepared at the end of the previous step (derive)
+//   dG tile  16 x 64 bf16 through LDS (each wave writes its four rows, ONE workgroup barrier per step, double buffered)
+//   MFMA     wave w multiplies the tile with the W_hh columns of hidden tiles w, w+4, ... (<= 5 tiles, 10 MFMAs), publishes them
+// Hand-off without flags, as in the forward kernel -- except that a partial dh has no spare bit of its own: the dG tile is scaled
+// by 2^-32 on its way to the matrix cores (a power of two: exact), so that every published bf16 partial is below 2 in magnitude
+// and its bit 14 is free for the epoch tag; the gatherer multiplies the fp32 sum by 2^32.  (Gradients beyond 2^33 -- or NaN -- read
+// as a tag that never matches or matches early: the first times out into the abort word, both belong to a diverged run.)
+template <int CELL, int HDH, int D16>
+__global__ __launch_bounds__(256, 1) void lstm_bwd_quad_kernel(CLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __builtin_amdgcn_s_setprio(3);
+  const int role = L.blk2role[blockIdx.x];
+  if (role < 0) return;
+  Where wh;
+  wh.di = 0;
+#pragma unroll
+  for (int i = 1; i < MAXD; ++i)
+    if (i < L.n && role >= L.d[i].wg_begin) wh.di = i;
+  const CDesc& D = L.d[wh.di];
+  {
+    const int local = role - D.wg_begin;
+    wh.dir = local / (L.ng * D.NCw);
+    const int rem = local % (L.ng * D.NCw);
+    wh.grp = L.g0 + rem / D.NCw;
+    wh.me = rem % D.NCw;
+  }
+  const int H = D.H, Hp = D.Hp, nHT = D.nHT, NC = D.NC;
+  const int B = L.B, T = L.T, dir = wh.dir;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;             // MFMA frame
+  const int rho = wh.me;
+  const int mt = rho & 1, ht = rho >> 1;
+  // cell frame: the element the reduce-scatter leaves in this lane
+  const int uc = lane & 7, pl = lane >> 3;
+  const bool b3 = (lane >> 3) & 1, b4 = (lane >> 4) & 1, b5 = (lane >> 5) & 1;
+  const int cu = 2 * uc + (b5 ? 1 : 0), crow = 2 * (b4 ? 1 : 0) + (b3 ? 1 : 0);
+  const int row = 4 * w + crow, b = wh.grp * GROUP + mt * 16 + row, col = ht * 16 + cu;
+  const int ngt = (B + GROUP - 1) / GROUP;
+  const unsigned G4 = 4u * H;
+  unsigned short* Tr = reinterpret_cast<unsigned short*>(smem);       // [parity][16 rows][64 gate columns] bf16
+
+  unsigned char* abort_w = D.xchg;
+  unsigned char* flags = D.xchg + xchg_flags_off() + ((size_t)(dir * ngt + wh.grp) * NC) * FLAG_STRIDE;
+  unsigned char* Xb = D.xchg + xchg_x_off(ngt, NC) + ((size_t)(dir * ngt + wh.grp) * 2) * xchg_slot(NC, Hp);
+  unsigned char* my_line = flags + (size_t)rho * 64;
+  unsigned char* my_flag = my_line + 32 + 4 * w;
+  const __amdgpu_buffer_rsrc_t fr4 = make_rsrc(flags, (unsigned)(2 * nHT) * 64u);
+  const bool awatch = lane < nHT;
+  const unsigned aoff = awatch ? (unsigned)(lane * 2 + mt) * 64u + 32u : OOB;
+
+  // W_hh fragments: gate rows of the own hidden tile (two k-steps) x the column tiles w, w + 4, ...
+  bf16x8 wreg[5][2];
+  {
+    const bf16x8* src = reinterpret_cast<const bf16x8*>(D.wpack_c[dir]);
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int ks2 = 0; ks2 < 2; ++ks2) {
+        const int nt = w + 4 * j;
+        wreg[j][ks2] = nt < nHT ? src[((size_t)(ht * nHT + nt) * 2 + ks2) * 64 + lane] : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+  }
+  const __amdgpu_buffer_rsrc_t rg = make_rsrc(D.gates, (unsigned)T * B * 2u * G4 * 4u);
+  const __amdgpu_buffer_rsrc_t rc = make_rsrc(D.cstash, (unsigned)T * (unsigned)((B + 3) & ~3) * 2u * H * 4u);
+  const unsigned scc = (unsigned)((B + 3) >> 2) * 2u * H * 16u;
+  const __amdgpu_buffer_rsrc_t rd = make_rsrc(const_cast<float*>(D.d_hseq), D.d_hseq ? (unsigned)T * B * 2u * H * 4u : 0u);
+  const unsigned sg = (unsigned)B * 2u * G4 * 4u, sc = (unsigned)B * 2u * H * 4u;
+  const bool inb = col < H && b < B;
+  const int len = inb ? L.lengths[min(b, B - 1)] : 0;
+  const unsigned og = (((unsigned)b * 2u + dir) * G4 + col * 4) * 4u;
+  const unsigned oc = ((((((unsigned)b >> 2) * 2u + dir) * H + col) << 2) + ((unsigned)b & 3u)) * 4u;
+  const unsigned oh = ((unsigned)b * 2u * H + dir * H + col) * 4u;
+  const float d_fin = inb ? D.utt[(size_t)b * 4u * H + (dir * 2 + D.layer) * H + col] : 0.f;
+  float dc = 0.f;
+  struct Raw { f32x4 g; float cp, dh; } raw;
+  struct Dv { float a[6], dh; } dv;
+  float c_keep = 0.f;
+  const bool has_dh = HDH == 2 ? D.d_hseq != nullptr : HDH == 1;
+  auto load_raw = [&](int step) {
+    const int t = dir ? step : T - 1 - step;
+    const int tp = dir ? t + 1 : t - 1;
+    const bool act = step < T && t < len;
+    raw.g = ldf4(rg, act ? og + (unsigned)t * sg : OOB);
+    raw.cp = ldf(rc, (step < T && tp >= 0 && tp < len) ? oc + (unsigned)tp * scc : OOB);
+    raw.dh = has_dh ? ldf(rd, act ? oh + (unsigned)t * sc : OOB) : 0.f;
+  };
+  auto derive = [&](int step) {                         // see lstm_bwd_wave_kernel
+    const int t = dir ? step : T - 1 - step;
+    const bool act = step < T && t < len;
+    const bool fin = dir ? (t == 0) : (t == len - 1);
+    const float gi = raw.g[0], gf = raw.g[1], gg = raw.g[2], go = raw.g[3];
+    dv.dh = raw.dh + ((act && fin) ? d_fin : 0.f);
+    if (CELL == MMDA_CELL_GRU) {
+      dv.a[0] = act ? (1.f - gf) * (1.f - gg * gg) : 0.f;
+      dv.a[1] = go * gi * (1.f - gi);
+      dv.a[2] = (raw.cp - gg) * gf * (1.f - gf);
+      dv.a[3] = gi;
+      dv.a[4] = 0.f;
+      dv.a[5] = gf;
+    } else {
+      const float tc = tanh_fast(c_keep);
+      dv.a[0] = gg * gi * (1.f - gi);
+      dv.a[1] = raw.cp * gf * (1.f - gf);
+      dv.a[2] = gi * (1.f - gg * gg);
+      dv.a[3] = tc * go * (1.f - go);
+      dv.a[4] = go * (1.f - tc * tc);
+      dv.a[5] = gf;
+      c_keep = raw.cp;
+    }
+  };
+  if (CELL == MMDA_CELL_LSTM) {
+    const int t0 = dir ? 0 : T - 1;
+    c_keep = ldf(rc, t0 < len ? oc + (unsigned)t0 * scc : OOB);
+  }
+  load_raw(0);
+  derive(0);
+  load_raw(1);
+  const unsigned slot_b = (unsigned)xchg_slot(NC, Hp);
+  const unsigned RS = (unsigned)((nHT + 1) & ~1) * 512u;
+  const unsigned img_b = (unsigned)(nHT * 2) * RS;
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(Xb, slot_b + img_b);
+  constexpr unsigned TAGS = 0x40004000u;
+  unsigned goff[3], chk[3];
+#pragma unroll
+  for (int l = 0; l < 3; ++l) {
+    const int p = pl + 8 * l;
+    goff[l] = p < nHT ? (unsigned)(ht * 2 + mt) * RS + (unsigned)p * 512u + (unsigned)w * 128u + (unsigned)uc * 16u : FAR;
+    chk[l] = p < nHT ? TAGS : 0u;
+  }
+  const unsigned pub_base = (unsigned)mt * RS + (unsigned)(ht * 64 + lane) * 8u;         // + consumer tile nt * pub_stride
+  const unsigned pub_stride = 2u * RS;
+
+  bool dead = false;
+  typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+  float dgv[4];
+  const __amdgpu_buffer_rsrc_t rg16 = make_rsrc(D.dg16, D.dg16 ? (unsigned)T * B * 2u * G4 * 2u : 0u);
+  const bool has_dg16 = D16 == 2 ? D.dg16 != nullptr : true;
+  const bool f32_dg = D16 == 2 ? !(has_dg16 && D.dg16_only) : false;
+  auto flush = [&](int ps) {
+    const int t = dir ? ps : T - 1 - ps;
+    const unsigned o = inb ? og + (unsigned)t * sg : OOB;               // zero at padded positions too
+    if (f32_dg) stf4(rg, o, f32x4{dgv[0], dgv[1], dgv[2], dgv[3]});
+    if (has_dg16) {
+      const u32x2 pk = {pack_bf16x2(dgv[0], dgv[1]), pack_bf16x2(dgv[2], dgv[3])};
+      __builtin_amdgcn_raw_buffer_store_b64(pk, rg16, inb ? (og + (unsigned)t * sg) >> 1 : OOB, 0, 0);
+    }
+  };
+  bool fast = false;
+  const unsigned xcc = my_xcc_id() ^ ((L.xcd_local == 3 && (ht & 1)) ? 8u : 0u);
+  if (L.xcd_local && tid == 0)
+    __hip_atomic_store((gu64*)(my_line + 48), ((unsigned long long)xcc << 32) | L.epoch_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const float up = 4294967296.f, down = 1.f / 4294967296.f;            // 2^32, 2^-32
+
+  auto do_step = [&](int step, auto first_tag, auto fm_tag) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    constexpr int FM = decltype(fm_tag)::value;
+    const unsigned epoch = L.epoch_base + (unsigned)step + 1u;
+    float dh_rec = 0.f;
+    if (!FIRST) {
+      const unsigned need = epoch - 1u;
+      const unsigned par = (need & 1u) * slot_b;
+      const unsigned tm = ((need >> 1) & 1u) ? TAGS : 0u;
+      u32x4 fa[3];
+      if (FM == 0) {
+        if (!dead) {
+          const bool ok = poll_tiles4(fr4, aoff, abort_w, awatch, need);
+          if (!ok) { dead = true; if (lane == 0) st_flag(abort_w, 1u); }
+        }
+        if (L.xcd_local && step == 1) {
+          const unsigned long long v = __hip_atomic_load((const gu64*)(flags + (size_t)((awatch ? lane : 0) * 2 + mt) * 64 + 48), __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT);
+          fast = __all(!awatch || v == (((unsigned long long)xcc << 32) | L.epoch_base));
+        }
+#pragma unroll
+        for (int l = 0; l < 3; ++l) fa[l] = ld16_sc1(xr, par + goff[l]);
+      } else {
+        u32x4 fb[3];
+#pragma unroll
+        for (int l = 0; l < 3; ++l) fa[l] = ld16_sc1(xr, par + goff[l]);
+        __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+        for (int l = 0; l < 3; ++l) fb[l] = ld16_sc1(xr, par + goff[l]);
+        auto stale = [&](const u32x4 (&f)[3]) {
+          unsigned t = 0;
+#pragma unroll
+          for (int l = 0; l < 3; ++l) t |= (((f[l][0] ^ tm) | (f[l][1] ^ tm)) | ((f[l][2] ^ tm) | (f[l][3] ^ tm))) & chk[l];
+          return t != 0;
+        };
+        if (!dead) {
+          for (unsigned spins = 0;; spins += 2) {
+            if (!__any(stale(fa))) break;
+#pragma unroll
+            for (int l = 0; l < 3; ++l) fa[l] = ld16_sc1(xr, par + goff[l]);
+            if (!__any(stale(fb))) {
+#pragma unroll
+              for (int l = 0; l < 3; ++l) fa[l] = fb[l];
+              break;
+            }
+#pragma unroll
+            for (int l = 0; l < 3; ++l) fb[l] = ld16_sc1(xr, par + goff[l]);
+            if (spins > SPIN_LIMIT || ((spins & 255u) == 0 && spins && ld_flag(abort_w) != 0)) {
+              dead = true;
+              if (lane == 0) st_flag(abort_w, 1u);
+              break;
+            }
+          }
+        }
+      }
+      flush(step - 1);
+      load_raw(step + 1);                                // consumed by derive() at the end of this step
+      // a[unit bit * 4 + row] of units 2 uc, 2 uc + 1, summed over this lane's producers in the order pl, pl + 8, pl + 16
+      float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int l = 0; l < 3; ++l) {
+        const unsigned cl = chk[l] ? tm : 0u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const unsigned x = fa[l][q] ^ cl;
+          a[2 * q] += __builtin_bit_cast(float, x << 16);
+          a[2 * q + 1] += __builtin_bit_cast(float, x & 0xffff0000u);
+        }
+      }
+      // reduce-scatter over the producer slots: bit 5 picks the unit, bits 4 and 3 the row
+      float k4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float keep = b5 ? a[4 + i] : a[i], send = b5 ? a[i] : a[4 + i];
+        k4[i] = keep + __shfl_xor(send, 32);
+      }
+      float k2[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float keep = b4 ? k4[2 + i] : k4[i], send = b4 ? k4[i] : k4[2 + i];
+        k2[i] = keep + __shfl_xor(send, 16);
+      }
+      {
+        const float keep = b3 ? k2[1] : k2[0], send = b3 ? k2[0] : k2[1];
+        dh_rec = (keep + __shfl_xor(send, 8)) * up;
+      }
+    }
+    // gate gradients of the lane's element: linear in dh / dc with the factors derive() prepared
+    {
+      float dh = dh_rec + dv.dh;
+      float dp[4];
+      if (CELL == MMDA_CELL_GRU) {
+        dh += dc;
+        const float dpn = dh * dv.a[0];
+        dp[0] = dpn * dv.a[1];
+        dp[1] = dh * dv.a[2];
+        dp[2] = dpn;
+        dp[3] = dpn * dv.a[3];
+        dc = dh * dv.a[5];
+      } else {
+        const float dct = dc + dh * dv.a[4];
+        dp[0] = dct * dv.a[0];
+        dp[1] = dct * dv.a[1];
+        dp[2] = dct * dv.a[2];
+        dp[3] = dh * dv.a[3];
+        dc = dct * dv.a[5];
+      }
+      unsigned short* tr = Tr + (step & 1) * 1024 + row * 64 + cu;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        tr[g * 16] = f2bf(dp[g] * down);
+        dgv[g] = dp[g];
+      }
+    }
+    if (step + 1 < T) {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      const unsigned short* tr = Tr + (step & 1) * 1024;
+      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&tr[fr * 64 + fq * 8]);
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&tr[fr * 64 + 32 + fq * 8]);
+      const unsigned par = (epoch & 1u) * slot_b;
+      const unsigned tg = ((epoch >> 1) & 1u) ? TAGS : 0u;
+      f32x4 accs[5];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) accs[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wreg[j][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 5; ++j) accs[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wreg[j][1], accs[j], 0, 0, 0);
+      const bool fst = FM == 0 ? fast : FM == 1;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const u32x2 pk = {pack_bf16x2(accs[j][0], accs[j][1]) | tg, pack_bf16x2(accs[j][2], accs[j][3]) | tg};
+        const unsigned so = (w + 4 * j) < nHT ? par + (unsigned)(w + 4 * j) * pub_stride : FAR;
+        if (fst) __builtin_amdgcn_raw_buffer_store_b64(pk, xr, pub_base + so, 0, 0);
+        else __builtin_amdgcn_raw_buffer_store_b64(pk, xr, pub_base + so, 0, 16);
+      }
+      if (FM == 0 && step < 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) { if (fst) st_flag_plain(my_flag, epoch); else st_flag(my_flag, epoch); }
+      }
+      derive(step + 1);
+    }
+  };
+  {
+    typedef std::integral_constant<bool, true> TrueT;
+    typedef std::integral_constant<bool, false> FalseT;
+    typedef std::integral_constant<int, 0> FmVar;
+    typedef std::integral_constant<int, 1> FmLocal;
+    typedef std::integral_constant<int, 2> FmThrough;
+    int step = 0;
+    if (T > 0) { do_step(0, TrueT{}, FmVar{}); step = 1; }
+    if (T > 1) { do_step(1, FalseT{}, FmVar{}); step = 2; }
+    if (T > 2) { do_step(2, FalseT{}, FmVar{}); step = 3; }
+    if (fast) { for (; step < T; ++step) do_step(step, FalseT{}, FmLocal{}); }
+    else { for (; step < T; ++step) do_step(step, FalseT{}, FmThrough{}); }
+    if (T > 0) flush(T - 1);
+  }
+}
+
 struct Plan { int TPW, NC, maxtw; size_t lds_f, lds_b; bool ok; };
 
 Plan plan_for(int H) {
@@ -1765,9 +2080,9 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
   {
     static const int no_quad = getenv("MMDA_LSTM_NO_QUAD") ? 1 : 0;
     int tiles = 0;
-    bool okq = fwd_wave && !bwd && !no_quad && g_dbg == nullptr;
+    bool okq = fwd_wave && !no_quad && g_dbg == nullptr;
     for (int i = 0; i < n; ++i) {
-      okq = okq && descs[i].gate_minor && round_up(descs[i].H, 32) / 32 <= 12;
+      okq = okq && descs[i].gate_minor && round_up(descs[i].H, 32) / 32 <= 12 && round_up(descs[i].H, 16) / 16 <= 20;
       tiles += 2 * 2 * (round_up(descs[i].H, 16) / 16);
     }
     quad = okq && tiles * ngt <= MAX_WG_PER_LAUNCH;
@@ -1873,7 +2188,10 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
     }
 #define LAUNCH_C()                                                                                               \
   do {                                                                                                           \
-    auto kfn = quad ? (gru ? (L.no_stash ? lstm_fwd_quad_kernel<MMDA_CELL_GRU, 1> : lstm_fwd_quad_kernel<MMDA_CELL_GRU, 0>)                           \
+    auto kfn = (quad && bwd) ? (gru ? lstm_bwd_quad_kernel<MMDA_CELL_GRU, 2, 2>                                                                       \
+                                    : spec == 1 ? lstm_bwd_quad_kernel<MMDA_CELL_LSTM, 0, 1>                                                           \
+                                    : spec == 2 ? lstm_bwd_quad_kernel<MMDA_CELL_LSTM, 1, 1> : lstm_bwd_quad_kernel<MMDA_CELL_LSTM, 2, 2>)              \
+             : quad ? (gru ? (L.no_stash ? lstm_fwd_quad_kernel<MMDA_CELL_GRU, 1> : lstm_fwd_quad_kernel<MMDA_CELL_GRU, 0>)                           \
                            : (L.no_stash ? lstm_fwd_quad_kernel<MMDA_CELL_LSTM, 1> : lstm_fwd_quad_kernel<MMDA_CELL_LSTM, 0>))                        \
              : dbgk ? (bwd ? lstm_bwd_wave_kernel<20, true, MMDA_CELL_LSTM, true> : lstm_fwd_wave_kernel<10, true, MMDA_CELL_LSTM, true>)          \
              : gru ? (bwd ? (L.gate_minor ? lstm_bwd_wave_kernel<20, true, MMDA_CELL_GRU, false> : lstm_bwd_wave_kernel<20, false, MMDA_CELL_GRU, false>) \
