@@ -32,6 +32,11 @@ constexpr int GROUP = 32;            // samples per cluster (two 16-row MFMA til
 constexpr int MAXD = 4;
 constexpr unsigned SPIN_LIMIT = 1u << 20;
 constexpr int MAX_WG_PER_LAUNCH = 240;
+constexpr int MAXB = 1024;           // blocks per launch (the four-waves-per-tile kernels share CUs: up to 4 blocks each)
+// Measured (MOSEI shapes, 108 tiles per 32-sample group): 216 and 432 workgroups (B = 64, 128) beat the one-wave-per-tile kernels by
+// 8 % and 6 % of the step, 864 (B = 256, 3.4 workgroups per CU) lose 3 % -- there the CUs' issue slots, not the hand-off, set the pace
+// (sleeping longer between polls changes nothing).
+constexpr int MAX_WG_QUAD = 512;
 
 typedef unsigned long long u64;
 typedef __attribute__((address_space(1))) u64 gu64;
@@ -57,7 +62,7 @@ struct CLaunch {
   int xcd_local;                     // the waves may keep the exchange inside one XCD's L2 after checking their placement (see xcc_announce)
   int wpb;                           // wave-autonomous forward: waves per block (1, 2 or 4)
   int no_stash;                      // forward only (evaluation): gates / cell states are not stashed
-  short blk2role[256];               // blockIdx -> linear role (-1: no role, exit at once); roles of one cluster share blockIdx % 8
+  short blk2role[MAXB];              // blockIdx -> linear role (-1: no role, exit at once); roles of one cluster share blockIdx % 8
 };
 
 // xchg layout per descriptor: [0,64) abort word | flags: (dir, group, wg) x FLAG_STRIDE B | X: (dir, group, parity) x slot
@@ -1382,7 +1387,7 @@ __device__ __forceinline__ bool poll_tiles4(__amdgpu_buffer_rsrc_t fr4, unsigned
 }
 
 template <int CELL, int NST>
-__global__ __launch_bounds__(256, 1) void lstm_fwd_quad_kernel(CLaunch L) {
+__global__ __launch_bounds__(256, 4) void lstm_fwd_quad_kernel(CLaunch L) {   // (<= 128 registers: four workgroups share a CU at large batches)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __builtin_amdgcn_s_setprio(3);
   const int role = L.blk2role[blockIdx.x];
@@ -1649,7 +1654,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_quad_kernel(CLaunch L) {
 // and its bit 14 is free for the epoch tag; the gatherer multiplies the fp32 sum by 2^32.  (Gradients beyond 2^33 -- or NaN -- read
 // as a tag that never matches or matches early: the first times out into the abort word, both belong to a diverged run.)
 template <int CELL, int HDH, int D16>
-__global__ __launch_bounds__(256, 1) void lstm_bwd_quad_kernel(CLaunch L) {
+__global__ __launch_bounds__(256, 4) void lstm_bwd_quad_kernel(CLaunch L) {   // (<= 128 registers: four workgroups share a CU at large batches)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __builtin_amdgcn_s_setprio(3);
   const int role = L.blk2role[blockIdx.x];
@@ -2085,7 +2090,19 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
       okq = okq && descs[i].gate_minor && round_up(descs[i].H, 32) / 32 <= 12 && round_up(descs[i].H, 16) / 16 <= 20;
       tiles += 2 * 2 * (round_up(descs[i].H, 16) / 16);
     }
-    quad = okq && tiles * ngt <= MAX_WG_PER_LAUNCH;
+    // every block of the launch must be resident at once: at most what the occupancy query grants per CU (registers, 32 KB of LDS)
+    auto per_cu = [](const void* f) {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f, 256, QUAD_LDS) != hipSuccess) { (void)hipGetLastError(); nb = 1; }
+      return nb < 1 ? 1 : (nb > 4 ? 4 : nb);
+    };
+    static const int occ_f = std::min(per_cu(reinterpret_cast<const void*>(lstm_fwd_quad_kernel<MMDA_CELL_LSTM, 0>)),
+                                      per_cu(reinterpret_cast<const void*>(lstm_fwd_quad_kernel<MMDA_CELL_GRU, 0>)));
+    static const int occ_b = std::min(per_cu(reinterpret_cast<const void*>(lstm_bwd_quad_kernel<MMDA_CELL_LSTM, 2, 2>)),
+                                      per_cu(reinterpret_cast<const void*>(lstm_bwd_quad_kernel<MMDA_CELL_GRU, 2, 2>)));
+    static const int quad_cap = getenv("MMDA_LSTM_QUAD_CAP") ? atoi(getenv("MMDA_LSTM_QUAD_CAP")) : MAX_WG_QUAD;
+    const int cap = std::min(quad_cap, 240 * (bwd ? occ_b : occ_f));
+    quad = okq && tiles * ngt <= cap;
     if (quad) wpb = 1;
   }
   int members[MAXD];                       // workgroups per cluster
@@ -2094,7 +2111,7 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
     members[i] = fwd_wave ? ceil_div(2 * (round_up(descs[i].H, 16) / 16), wpb) : plans[i].NC;
     wg_per_group += 2 * members[i];
   }
-  const int groups_per_launch = MAX_WG_PER_LAUNCH / wg_per_group;
+  const int groups_per_launch = quad ? ngt : MAX_WG_PER_LAUNCH / wg_per_group;
   hipStream_t s = (hipStream_t)stream;
   for (int g0 = 0; g0 < ngt; g0 += groups_per_launch) {
     CLaunch L;
@@ -2124,11 +2141,12 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
     static const int use_place = getenv("MMDA_NO_PLACEMENT") ? 0 : 1;
     static const int xcd_env = getenv("MMDA_XCD_LOCAL") ? atoi(getenv("MMDA_XCD_LOCAL")) : 1;      // 0: ablation (always write through)
     L.xcd_local = xcd_env;
-    for (int b = 0; b < 256; ++b) L.blk2role[b] = -1;
+    for (int b = 0; b < MAXB; ++b) L.blk2role[b] = -1;
     int grid_blocks = wg;
     {
       int used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      bool fits = use_place && wg <= 256;
+      const int per_xcd = quad ? 32 * 4 : 32;             // block slots per XCD
+      bool fits = use_place && wg <= 8 * per_xcd;
       // (first role, members).  Wave form with one wave per block: a wave exchanges data only with the waves of its own m-tile
       // (roles first + mt, first + mt + 2, ...), so each m-tile is a cluster of its own (19 blocks for text: fits an XCD's 32 CUs).
       const bool by_mt = fwd_wave && wpb == 1;
@@ -2141,19 +2159,19 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
           else clusters.push_back({first, members[i]});
         }
       std::stable_sort(clusters.begin(), clusters.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.second > b.second; });
-      short map[256];
-      for (int b = 0; b < 256; ++b) map[b] = -1;
+      short map[MAXB];
+      for (int b = 0; b < MAXB; ++b) map[b] = -1;
       int max_slots = 0;
       for (auto& cl : clusters) {
         int x = 0;
         for (int k = 1; k < 8; ++k) if (used[k] < used[x]) x = k;
-        if (used[x] + cl.second > 32) { fits = false; break; }
+        if (used[x] + cl.second > per_xcd) { fits = false; break; }
         for (int j = 0; j < cl.second; ++j) map[(used[x] + j) * 8 + x] = (short)(cl.first + j * stride);
         used[x] += cl.second;
         if (used[x] > max_slots) max_slots = used[x];
       }
-      if (fits) { for (int b = 0; b < 256; ++b) L.blk2role[b] = map[b]; grid_blocks = 8 * max_slots; }
-      else { for (int b = 0; b < wg && b < 256; ++b) L.blk2role[b] = (short)b; L.xcd_local = 0; }
+      if (fits) { for (int b = 0; b < MAXB; ++b) L.blk2role[b] = map[b]; grid_blocks = 8 * max_slots; }
+      else { for (int b = 0; b < wg && b < MAXB; ++b) L.blk2role[b] = (short)b; L.xcd_local = 0; }
       // only the wave kernels verify the placement (per m-tile: every wave reads the XCC ids of all hidden tiles of its m-tile)
       // before they rely on it; the barrier-form kernels' unchecked variant stays an experiment (MMDA_XCD_LOCAL=2)
       if (!fwd_wave && xcd_env != 2) L.xcd_local = 0;
