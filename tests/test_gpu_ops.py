@@ -844,12 +844,15 @@ def test_transpose_f32_multi():
         assert torch.equal(o.cpu(), m.t().contiguous())
 
 
-@pytest.mark.parametrize("xcd_local", ["0", "3"])
-def test_recurrence_hand_off_fallbacks_in_a_fresh_process(xcd_local):
+@pytest.mark.parametrize("switches", [{"MMDA_XCD_LOCAL": "0"}, {"MMDA_XCD_LOCAL": "3"}, {"MMDA_LSTM_NO_QUAD": "1"},
+                                      {"MMDA_LSTM_NO_QUAD": "1", "MMDA_XCD_LOCAL": "3"}],
+                         ids=["write_through", "placement_check_fails", "one_wave_per_tile", "one_wave_per_tile_check_fails"])
+def test_recurrence_hand_off_fallbacks_in_a_fresh_process(switches):
     """The XCD-local hand-off is taken only after the waves have verified that their cluster shares an XCD.  MMDA_XCD_LOCAL=0 never
     tries (write-through form throughout); =3 is a test hook that makes the odd hidden tiles announce a wrong XCC id, so every
-    cluster's check fails at step 1 and the kernels must carry on in the write-through form.  Both must reproduce nn.LSTM.
-    (The switch is read once per process, hence the subprocess.)"""
+    cluster's check fails at step 1 and the kernels must carry on in the write-through form.  MMDA_LSTM_NO_QUAD=1 selects the
+    one-wave-per-tile kernels (what batches beyond 128 run) at this small batch.  All must reproduce nn.LSTM.
+    (The switches are read once per process, hence the subprocess.)"""
     import subprocess, sys
     code = r'''
 import math, sys, torch
@@ -881,7 +884,7 @@ dx = ops.gemm(dG, wih, mode="bf16", transB=False).view(T, B, D)
 assert rel(dx, x.grad) < 3e-2, rel(dx, x.grad)
 print("ok")
 ''' % ROOT
-    env = dict(os.environ, MMDA_XCD_LOCAL=xcd_local)
+    env = dict(os.environ, **switches)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
 
