@@ -344,15 +344,12 @@ extern "C" int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, vo
     }
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return args[x].K > args[y].K; });
     const bool crowded = all_tiles >= 512;
+    // pass 1: the split of every problem on its own
+    std::vector<int> sks(n, 1);
+    auto tiles_of = [&](const mmda_gemm_bf16_args& a) { return ceil_div(a.N + (a.bias_grad ? 1 : 0), T) * ceil_div(a.M, T); };
     for (int i : order) {
       const mmda_gemm_bf16_args& a = args[i];
-      if (G.n == GROUP_MAX) { int rc = flush(); if (rc) return rc; }
-      const int k = G.n++;
-      G.p[k] = a;
-      const int Ne = a.N + (a.bias_grad ? 1 : 0);
-      G.tile[k] = T;
-      G.tx[k] = ceil_div(Ne, T); G.ty[k] = ceil_div(a.M, T);
-      const int tiles = G.tx[k] * G.ty[k];
+      const int tiles = tiles_of(a);
       const int nk = ceil_div(a.K, TK);
       // split-K combines through float atomics, which the chip retires at ~1.3 TB/s of added bytes: split only while the
       // added bytes stay small (<= 6 MB, ~5 us) and every slice keeps >= 4 k-tiles
@@ -376,10 +373,34 @@ extern "C" int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, vo
       // a fresh (non-accumulated) output has to be cleared by a launch of its own before the slices can add into it: only worth
       // it for a long K loop in a launch that would otherwise leave the chip underfilled
       if (sk > 1 && !a.accumulate && (crowded || nk < 16)) sk = 1;
-      if (sk > 1 && !a.accumulate) {
-        if (a.ldc != a.N) sk = 1;
-        else if (hipMemsetAsync(a.C, 0, sizeof(float) * (size_t)a.M * a.N, s) != hipSuccess) return MMDA_ELAUNCH;
+      if (sk > 1 && !a.accumulate && a.ldc != a.N) sk = 1;
+      sks[i] = sk;
+    }
+    // pass 2: the launch as a whole.  The chip holds SLOTS workgroups of this kernel at once; a launch of 1.x times that runs a second,
+    // mostly empty round.  While the launch sits between one and two rounds, the most finely split problems give slices back.
+    {
+      static const int slots = getenv("MMDA_GEMM_SLOTS") ? atoi(getenv("MMDA_GEMM_SLOTS")) : (T == 64 ? 1024 : 512);
+      auto total = [&]() { int64_t t = 0; for (int i : order) t += (int64_t)tiles_of(args[i]) * sks[i]; return t; };
+      int64_t tot = total();
+      while (slots > 0 && tot > slots && tot < 2 * (int64_t)slots) {
+        int best = -1;
+        for (int i : order) if (sks[i] > 1 && (best < 0 || sks[i] > sks[best] || (sks[i] == sks[best] && tiles_of(args[i]) > tiles_of(args[best])))) best = i;
+        if (best < 0) break;
+        --sks[best];
+        tot = total();
       }
+    }
+    for (int i : order) {
+      const mmda_gemm_bf16_args& a = args[i];
+      if (G.n == GROUP_MAX) { int rc = flush(); if (rc) return rc; }
+      const int k = G.n++;
+      G.p[k] = a;
+      const int Ne = a.N + (a.bias_grad ? 1 : 0);
+      G.tile[k] = T;
+      G.tx[k] = ceil_div(Ne, T); G.ty[k] = ceil_div(a.M, T);
+      const int tiles = G.tx[k] * G.ty[k];
+      const int sk = sks[i];
+      if (sk > 1 && !a.accumulate && hipMemsetAsync(a.C, 0, sizeof(float) * (size_t)a.M * a.N, s) != hipSuccess) return MMDA_ELAUNCH;
       G.splitk[k] = sk;
       G.start[k] = blocks;
       blocks += tiles * sk;
