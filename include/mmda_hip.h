@@ -399,6 +399,14 @@ int mmda_loss_domain(const float* dom, int B, float scale, float* loss, float* d
 int mmda_clamp_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                     float eps, float clip, float grad_scale, int step, void* stream);
 int mmda_clamp(float* g, int64_t n, float clip, void* stream);
+/* The same update over the rows of a (rows, dim) table whose mask byte equals `want`; mmda_mark_rows clears a mask of `rows` bytes and
+ * sets the bytes of the ids that occur (ids outside [0, rows) are ignored).  The fused training step uses the pair to update the
+ * embedding rows a batch does not touch (zero gradient, known from the ids alone) beside the last recurrence -- torch.optim.Adam's dense
+ * update (reference solver.py:97-99, nn.Embedding without sparse=True) moves every row with momentum, touched or not -- and only the
+ * touched rows after the scatter. */
+int mmda_clamp_adam_rows(float* p, const float* g, float* m, float* v, int rows, int dim, const unsigned char* mask, int want, float lr,
+                         float beta1, float beta2, float eps, float clip, float grad_scale, int step, void* stream);
+int mmda_mark_rows(unsigned char* mask, int rows, const int64_t* ids, int n, void* stream);
 /* clip_grad_value_(clip) + torch.optim.RMSprop with torch's defaults besides lr (alpha 0.99, eps 1e-8, no momentum, not centered):
  * the other entry of the reference's optimizer_dict (config.py:24).  grad_scale as in mmda_clamp_adam. */
 int mmda_clamp_rmsprop(float* p, const float* g, float* square_avg, int64_t n, float lr, float alpha, float eps, float clip,

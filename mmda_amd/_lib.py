@@ -175,6 +175,8 @@ SIGNATURES = {
     "mmda_eval_accumulate": (_I, [_P, _P, _I, _I, _P, _P]),
     "mmda_loss_domain": (_I, [_P, _I, _F, _P, _P, _P]),
     "mmda_clamp_adam": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _I, _P]),
+    "mmda_clamp_adam_rows": (_I, [_P, _P, _P, _P, _I, _I, _P, _I, _F, _F, _F, _F, _F, _F, _I, _P]),
+    "mmda_mark_rows": (_I, [_P, _I, _P, _I, _P]),
     "mmda_clamp": (_I, [_P, _I64, _F, _P]),
     "mmda_clamp_rmsprop": (_I, [_P, _P, _P, _I64, _F, _F, _F, _F, _F, _P]),
     "mmda_misa_create": (_I, [C.POINTER(MisaConfig), C.POINTER(C.c_void_p)]),

@@ -62,7 +62,7 @@ struct mmda_misa {
   int64_t zero_begin = 0, zero_end = 0;      // activation-gradient region that is zeroed per step
   int64_t gpad_begin = 0, gpad_end = 0;      // GRU: four-slot weight gradients (zeroed at set_workspace, re-zeroed by the unpad kernel)
   int64_t z, pmean, prstd, orig, x6, rsum, recon, dom_z, dom_h, dom, qkv, probs, ctx, attn_out, ln1_mean, ln1_rstd, x1, f1, f2,
-      ln2_mean, ln2_rstd, hfused, logits, tcp, scores, labels, losses, diff_work;
+      ln2_mean, ln2_rstd, hfused, logits, tcp, scores, labels, losses, diff_work, touched;
   // K-major (transposed) fp32 copies of the fusion block's weights for its input-gradient GEMMs (made once per step)
   int64_t head_wT, l2_wT, l1_wT, out_wT, in_wT, rec_wT, priv_wT, sh_wT, d1_wT = -1, d2_wT = -1, pwT[3];
   int wT_valid = 0;
@@ -72,6 +72,7 @@ struct mmda_misa {
   // fused train step without a gradient exchange: clamp+Adam of the bucket prefix whose gradients are final beside the layer-1 backward
   // recurrence runs there, on the side stream (set by mmda_misa_train_step around its backward pass)
   int adam_early_on = 0; float ae_lr = 0.f, ae_clip = 0.f; int ae_step = 0; int64_t adam_early_done = 0;
+  int embed_early_done = 0;        // this step's early optimizer pass also covered the embedding rows the batch does not touch
   int wT_pending = 0;              // the K-major fusion-weight copies of this step are still to be made (on the next fork)
   int fusion_fp8 = 0;
   int64_t x1q, x1s, w1q, w1s, f1q, f1s, w2q, w2s;
@@ -275,6 +276,7 @@ int64_t layout(mmda_misa* m, int B, int T, bool commit) {
   o->f1q = k.take((int64_t)6 * B * FFN / 4); o->f1s = k.take((int64_t)6 * B * FFN / 128 + 4);
   o->w2q = k.take((int64_t)hs * FFN / 4); o->w2s = k.take((int64_t)hs * FFN / 128 + 4);
   o->diff_work = k.take(mmda_loss_diff_work_floats(B, hs));
+  o->touched = k.take((c.vocab + 3) / 4);              // one byte per embedding row: occurs in this batch (see mmda_clamp_adam_rows)
   o->head_wT = k.take((int64_t)6 * hs * NC); o->l2_wT = k.take((int64_t)FFN * hs); o->l1_wT = k.take((int64_t)hs * FFN);
   o->out_wT = k.take((int64_t)hs * hs); o->in_wT = k.take((int64_t)hs * 3 * hs); o->rec_wT = k.take((int64_t)3 * hs * hs);
   o->priv_wT = k.take((int64_t)3 * hs * hs); o->sh_wT = k.take((int64_t)hs * hs);
@@ -1333,6 +1335,21 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
     if (!x.rc && B <= SKINNY_MAX_B) x.rc = mmda_add(WS(m->x6), WS(m->x6 + 3 * BH), WS(m->rsum), 3 * BH, ss);
     if (!x.rc && !x.deferred.empty()) x.rc = mmda_gemm_grouped(x.deferred.data(), (int)x.deferred.size(), ss);
     x.deferred.clear();
+    // Experiment, OFF by default (MMDA_ADAM_EMBED_SPLIT=1): clip + Adam of the embedding rows this batch does NOT touch, here, beside
+    // the layer-2 recurrence (the side stream is idle for ~100 us behind the GEMMs above).  Their gradient is zero whatever the rest of
+    // the backward pass does (the bucket was cleared during the forward pass, the scatter at the end adds into the touched rows only),
+    // and torch's dense Adam moves them by their momentum all the same: 6 of the 10.8 M parameters would leave the tail of the step
+    // (-32 us).  Measured at B=32: the 170 MB it streams beside the recurrence slow that kernel's hand-offs by 24 us (0.071 -> 0.095 ms)
+    // and the step ends up 14 us LONGER (0.769 -> 0.783 ms); behind the early optimizer pass beside the layer-1 recurrence instead, the
+    // side stream becomes the longer of the two and the join waits (0.766 -> 0.834 ms).
+    static const int embed_split = getenv("MMDA_ADAM_EMBED_SPLIT") ? atoi(getenv("MMDA_ADAM_EMBED_SPLIT")) : 0;
+    if (!x.rc && m->adam_early_on && embed_split && m->use_side && m->M1 && m->V1 && m->embed + (int64_t)c.vocab * c.d_t == m->flat) {
+      unsigned char* mask = reinterpret_cast<unsigned char*>(WS(m->touched));
+      x.rc = mmda_mark_rows(mask, c.vocab, t_ids, R, ss);
+      if (!x.rc) x.rc = mmda_clamp_adam_rows(PP(m->embed), GG(m->embed), m->M1 + m->embed, m->V1 + m->embed, c.vocab, c.d_t, mask, 0,
+                                             m->ae_lr, 0.9f, 0.999f, 1e-8f, m->ae_clip, 1.0f, m->ae_step, ss);
+      if (!x.rc) m->embed_early_done = 1;
+    }
   }
   if (x.rc) return x.rc;
   // encoders, top layer first
@@ -1560,13 +1577,18 @@ extern "C" int mmda_misa_train_step(mmda_misa* m, const int64_t* t_ids, const fl
   if (rc) return rc;
   static const int adam_split = getenv("MMDA_ADAM_SPLIT") ? atoi(getenv("MMDA_ADAM_SPLIT")) : 1;     // 0: ablation (one launch at the end)
   m->adam_early_on = (do_adam && adam_split) ? 1 : 0; m->ae_lr = lr; m->ae_clip = clip; m->ae_step = step; m->adam_early_done = 0;
+  m->embed_early_done = 0;
   rc = mmda_misa_backward(m, t_ids, v, a, lengths, stream);
   m->adam_early_on = 0;
   if (rc) return rc;
   if (do_adam) {
     // the rest of the bucket (layer-1 recurrent layers, embedding -- or everything, if the backward pass stepped nothing early)
     const int64_t o = m->adam_early_done;
-    rc = mmda_clamp_adam(m->P + o, m->G + o, m->M1 + o, m->V1 + o, m->flat - o, lr, 0.9f, 0.999f, 1e-8f, clip, 1.0f, step, stream);
+    const int64_t end = m->embed_early_done ? m->embed : m->flat;
+    rc = mmda_clamp_adam(m->P + o, m->G + o, m->M1 + o, m->V1 + o, end - o, lr, 0.9f, 0.999f, 1e-8f, clip, 1.0f, step, stream);
+    if (!rc && m->embed_early_done)          // the rows of this batch (their gradient has just been scattered)
+      rc = mmda_clamp_adam_rows(m->P + m->embed, m->G + m->embed, m->M1 + m->embed, m->V1 + m->embed, m->cfg.vocab, m->cfg.d_t,
+                                reinterpret_cast<const unsigned char*>(m->ws + m->touched), 1, lr, 0.9f, 0.999f, 1e-8f, clip, 1.0f, step, stream);
   }
   return rc;
 }

@@ -429,6 +429,22 @@ def clamp_adam(p, g, m, v, lr, step, clip=float("inf"), grad_scale=1.0, betas=(0
                               stream_ptr()), "clamp_adam")
 
 
+def mark_rows(ids, rows):
+    """uint8 mask of `rows` bytes: 1 where the row id occurs in `ids` (int64, device)."""
+    lib = load()
+    mask = torch.empty(rows, dtype=torch.uint8, device=ids.device)
+    check(lib.mmda_mark_rows(ptr(mask), rows, ptr(ids), ids.numel(), stream_ptr()), "mark_rows")
+    return mask
+
+
+def clamp_adam_rows(p, g, m, v, mask, want, lr, step, clip=float("inf"), grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8):
+    """clip + Adam over the rows of the (rows, dim) table p whose mask byte equals `want` (in place)."""
+    lib = load()
+    rows, dim = p.shape
+    check(lib.mmda_clamp_adam_rows(ptr(p), ptr(g), ptr(m), ptr(v), rows, dim, ptr(mask), int(want), lr, betas[0], betas[1], eps, clip,
+                                   grad_scale, step, stream_ptr()), "clamp_adam_rows")
+
+
 def heads_fwd(logits, ncls, threshold=0.35, drop_p=0.0, seed=0, site=0):
     lib = load()
     B = logits.shape[0]

@@ -771,6 +771,27 @@ def test_bce_clamp_at_saturated_scores():
 
 
 # ------------------------------------------------------------------------------------------------ optimizer, dropout
+def test_clamp_adam_rows_in_two_passes_equals_the_dense_update():
+    """Untouched rows first (zero gradient), touched rows after the scatter: bit-identical to one dense clip + Adam pass."""
+    from mmda_amd import ops
+    torch.manual_seed(3)
+    V, D = 997, 300
+    ids = torch.randint(0, V, (160,))
+    ids[0] = V - 1
+    p = torch.randn(V, D); m = torch.randn(V, D) * 1e-2; v = torch.rand(V, D) * 1e-3
+    g = torch.zeros(V, D); g.index_add_(0, ids, torch.randn(160, D) * 3.0)
+    ref = [t.clone().to(dev()) for t in (p, m, v)]
+    ops.clamp_adam(ref[0].view(-1), g.to(dev()).view(-1), ref[1].view(-1), ref[2].view(-1), 1e-3, 4, clip=1.0)
+    got = [t.clone().to(dev()) for t in (p, m, v)]
+    mask = ops.mark_rows(ids.to(dev()), V)
+    assert int(mask.sum()) == len(set(ids.tolist())) and set(mask.nonzero().flatten().tolist()) == set(ids.tolist())
+    gz = torch.zeros(V, D, device=dev())                 # what the gradient bucket holds before the scatter
+    ops.clamp_adam_rows(got[0], gz, got[1], got[2], mask, 0, 1e-3, 4, clip=1.0)
+    ops.clamp_adam_rows(got[0], g.to(dev()), got[1], got[2], mask, 1, 1e-3, 4, clip=1.0)
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+
+
 def test_clamp_adam_matches_torch_adam_three_steps():
     from mmda_amd import ops
     torch.manual_seed(12)
