@@ -3,6 +3,7 @@
 // problem - q,k,v of 6 x hd, a 6x6 score matrix - lives in one 64-lane wavefront's LDS/registers; this is latency
 // work, not a GEMM.  One workgroup (one wave) per (sample, head).
 #include "common.h"
+#include "rowlocal.h"
 
 namespace {
 
@@ -108,7 +109,6 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ 
 // q, k and v row in registers (18 values), a score is one wave reduction, and after the reductions every lane holds the whole
 // 6 x 6 matrix -- softmax, dropout and the context product need no LDS and no barrier.  Same arithmetic order per element and
 // the same dropout indices as the generic kernels above.
-constexpr int S6K = 6;
 
 __global__ __launch_bounds__(64) void attn_fwd_hd64_kernel(const float* __restrict__ qkv, int B, float* ctx, float* probs, float p,
                                                            uint64_t seed, int site, int nhead) {
@@ -156,48 +156,7 @@ __global__ __launch_bounds__(64) void attn_fwd_hd64_kernel(const float* __restri
 __global__ __launch_bounds__(64) void attn_bwd_hd64_kernel(const float* __restrict__ qkv, const float* __restrict__ probs,
                                                            const float* __restrict__ dctx, int B, float* dqkv, float p, uint64_t seed,
                                                            int site, int nhead) {
-  constexpr int S = S6K, hd = 64;
-  const int E = hd * nhead;
-  const int b = blockIdx.x / nhead, h = blockIdx.x % nhead, d = threadIdx.x;
-  float q[S], k[S], v[S], dc[S];
-#pragma unroll
-  for (int s = 0; s < S; ++s) {
-    const float* row = qkv + ((int64_t)s * B + b) * 3 * E + h * hd + d;
-    q[s] = row[0]; k[s] = row[E]; v[s] = row[2 * E];
-    dc[s] = dctx[((int64_t)s * B + b) * E + h * hd + d];
-  }
-  float P[S][S], Pd[S][S], dS[S][S];
-#pragma unroll
-  for (int i = 0; i < S; ++i)
-#pragma unroll
-    for (int j = 0; j < S; ++j) {
-      const int64_t pi = (int64_t)blockIdx.x * S * S + i * S + j;
-      const float mul = drop_mul(p, seed, site, (uint64_t)pi);
-      P[i][j] = probs[pi];
-      Pd[i][j] = P[i][j] * mul;
-      dS[i][j] = wave_sum(dc[i] * v[j]) * mul;                      // dP
-    }
-#pragma unroll
-  for (int i = 0; i < S; ++i) {
-    float dot = 0.f;
-#pragma unroll
-    for (int j = 0; j < S; ++j) dot += dS[i][j] * P[i][j];
-#pragma unroll
-    for (int j = 0; j < S; ++j) dS[i][j] = P[i][j] * (dS[i][j] - dot);
-  }
-  const float scale = 1.0f / sqrtf((float)hd);
-#pragma unroll
-  for (int s = 0; s < S; ++s) {
-    float dq = 0.f, dk = 0.f, dv = 0.f;
-#pragma unroll
-    for (int j = 0; j < S; ++j) {
-      dq += dS[s][j] * k[j];
-      dk += dS[j][s] * q[j];
-      dv += Pd[j][s] * dc[j];
-    }
-    float* row = dqkv + ((int64_t)s * B + b) * 3 * E + h * hd + d;
-    row[0] = dq * scale; row[E] = dk * scale; row[2 * E] = dv;
-  }
+  attn_bwd_hd64_one(qkv, probs, dctx, B, dqkv, p, seed, site, nhead, (int)blockIdx.x, (int)threadIdx.x);      // (rowlocal.h)
 }
 
 }  // namespace

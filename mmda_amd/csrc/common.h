@@ -61,15 +61,32 @@ __device__ __forceinline__ float drop_mul(float p, uint64_t seed, int site, uint
   return u < p ? 0.0f : 1.0f / (1.0f - p);
 }
 
+// Wave-wide sum / max, the same value in every lane.  Inside a row of 16 lanes by DPP (quad swaps, half-row mirror, row mirror: 4
+// VALU instructions, every lane of a row ends with the row's result); the four rows are then read as scalars and combined.  (A
+// __shfl_xor butterfly is six dependent ds_bpermute round trips, ~700 cycles: the 36 dot products of the six-token attention cost 11 us
+// that way.)
+#define MMDA_DPP(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, true))
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v += MMDA_DPP(v, 0xB1);            // quad_perm [1,0,3,2]
+  v += MMDA_DPP(v, 0x4E);            // quad_perm [2,3,0,1]
+  v += MMDA_DPP(v, 0x141);           // row_half_mirror
+  v += MMDA_DPP(v, 0x140);           // row_mirror
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
+  v = fmaxf(v, MMDA_DPP(v, 0xB1));
+  v = fmaxf(v, MMDA_DPP(v, 0x4E));
+  v = fmaxf(v, MMDA_DPP(v, 0x141));
+  v = fmaxf(v, MMDA_DPP(v, 0x140));
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 // block-wide sum for blockDim.x <= 1024 (multiple of 64); `red` is >= 16 floats of LDS. All threads get the result.
 __device__ __forceinline__ float block_sum(float v, float* red) {

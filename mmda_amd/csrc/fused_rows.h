@@ -1,0 +1,41 @@
+// Internal (not part of the C ABI): the row-local stretches of the fusion block's backward pass as ONE launch each.
+// Every operation between the classifier and the utterance vectors acts on the rows of one sample at a time (linear layers, LayerNorms,
+// the six-token attention, sigmoids, dropout) -- only the weight gradients and the losses mix samples, and those run elsewhere.  A
+// workgroup therefore takes the rows of `nb` samples through a whole stretch by itself, its stages separated by workgroup barriers
+// (~1 us each: store drain + L2 round trip) instead of kernel boundaries (5 - 12 us each for these latency-bound sizes).
+#pragma once
+#include "../../include/mmda_hip.h"
+#include <stdint.h>
+
+// stretch C: heads backward -> d_hfused = d_logits W_head -> LayerNorm 2 backward (d_x1, d_f2 + its gamma/beta gradients)
+struct FusedBwdC {
+  int B, hs, ncls, nb;
+  const float* tcp; const float* scores; const float* d_tcp; const float* d_scores; float* d_logits;
+  float p_cls; uint64_t seed; int site_cls;
+  const float* head_w;            // (6 + ncls, 6 hs) row-major
+  float* d_hfused;                // (B, 6 hs)
+  mmda_ln_bwd_args ln2;           // rows = 6 B (token-major), permute_S / permute_B set
+};
+
+// stretch A: LayerNorm 1 backward -> d_ctx = d_attn_out W_out -> attention backward -> d_x6 = (d_x6 + d_qkv W_in + d_recon W_rec) s(1-s)
+//            -> d_orig += d_private W_priv + d_shared W_shared -> the three projection LayerNorms' backward (d_z)
+struct FusedBwdA {
+  int B, hs, nhead, nb;
+  mmda_ln_bwd_args ln1;           // rows = 6 B; d_x = d_x6 (accumulated), d_res = d_attn_out
+  const float* d_attn_out; const float* out_wT; float* d_ctx;
+  const float* qkv; const float* probs; float* d_qkv; float p_tf; uint64_t seed; int site_attn;
+  const float* in_wT;             // (hs, 3 hs): K-major copy of in_proj_weight
+  const float* d_recon;           // (3, B, hs)
+  const float* rec_wT;            // 3 x (hs, hs) K-major
+  const float* x6;                // (6, B, hs) sigmoid outputs
+  float* d_x6;                    // (6, B, hs)
+  const float* priv_wT;           // 3 x (hs, hs) K-major
+  const float* sh_wT;             // (hs, hs) K-major
+  float* d_orig;                  // (3, B, hs)
+  mmda_ln_bwd_args lnp[3];        // rows = B each
+  unsigned long long* dbg;        // diagnostics: cycle counter at each stage boundary of workgroup 0 (NULL in production)
+};
+
+int mmda_fused_bwd_c(const FusedBwdC* a, void* stream);
+int mmda_fused_bwd_a(const FusedBwdA* a, void* stream);
+extern "C" int mmda_debug_set_fused_stamps(void* device_buffer);     // tools/ only (16 x u64)

@@ -1,0 +1,236 @@
+// The row-local stretches of the fusion block's backward pass, one launch each (see fused_rows.h).
+// Workgroup = 512 threads = 8 waves, rows of `nb` samples (nb = 2: twelve token rows fill an MFMA tile; B odd: nb = 1).  GEMM stages use
+// v_mfma_f32_16x16x4_f32 (exact f32; hs = 128: every product is a whole number of 128-deep rounds) with operands global -> registers -> MFMA as in gemm_skinny.hip: wave w owns output columns
+// 16 w .. 16 w + 15 (hs = 128 = 8 waves x 16), walks the whole reduction itself, and applies its epilogue straight from the accumulators.
+// The six problems of d_x6 and the three of d_orig each become ONE accumulator chain per wave: the products that differ per modality
+// run over the same 16-row tile with the rows of the other modalities zeroed.
+#include "common.h"
+#include "rowlocal.h"
+#include "fused_rows.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float f4;
+constexpr int FR_THREADS = 512;
+
+// acc += A_row(lane & 15)[0..K) . Bt_row(lane & 15)[0..K)^T for the 16 x 16 tile (rows: the lanes' A rows, columns: the lanes' Bt rows).
+// arow == nullptr: a zero row.  K % 16 == 0, rows 16-byte aligned.  Rounds of eight 16-deep chunks; the loads of round r + 1 are issued
+// before the MFMAs of round r (two register sets: a stage is a chain of memory latencies, the MFMAs hide behind the next one).
+struct MacRound { f4 a[8], b[8]; };
+// one round = 128 of the reduction: eight 16-deep chunks, a lane's float4 at k = 16 c + 4 (lane >> 4) feeds component s to the s-th MFMA
+__device__ __forceinline__ void mac_load(MacRound& R, const float* __restrict__ arow, const float* __restrict__ brow, int g) {
+  const f4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    R.a[c] = arow ? *reinterpret_cast<const f4*>(arow + 16 * c + 4 * g) : z;
+    R.b[c] = *reinterpret_cast<const f4*>(brow + 16 * c + 4 * g);
+  }
+}
+__device__ __forceinline__ void mac_run(f32x4& acc, const MacRound& R) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(R.a[c][s], R.b[c][s], acc, 0, 0, 0);
+}
+// NR rounds into one accumulator; round r multiplies A row ar[r] (or zeros) with Bt row br[r], both already advanced to the round's k
+template <int NR>
+__device__ __forceinline__ void tile_mac_chain(f32x4& acc, const float* const (&ar)[NR], const float* const (&br)[NR], int lane) {
+  const int g = lane >> 4;
+  MacRound R0, R1;
+  mac_load(R0, ar[0], br[0], g);
+#pragma unroll
+  for (int r = 0; r < NR; r += 2) {
+    if (r + 1 < NR) mac_load(R1, ar[r + 1], br[r + 1], g);
+    mac_run(acc, R0);
+    if (r + 2 < NR) mac_load(R0, ar[r + 2], br[r + 2], g);
+    if (r + 1 < NR) mac_run(acc, R1);
+  }
+}
+
+// stage boundary: this workgroup's global stores are visible to all of its waves
+__device__ __forceinline__ void stage_sync() {
+  __threadfence_block();
+  __syncthreads();
+}
+
+// LayerNorm backward of the rows `row_of(i)`, i < nrows, waves round robin; dgamma / dbeta of the workgroup's rows in ONE atomic per
+// column (LDS reduction over the waves).  n <= 128.
+template <typename RowOf>
+__device__ __forceinline__ void ln_bwd_rows(const mmda_ln_bwd_args& a, int nrows, RowOf row_of, float* red /* 2 x 8 x 128 floats */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float dg[2] = {0.f, 0.f}, db[2] = {0.f, 0.f};
+  for (int i = wave; i < nrows; i += FR_THREADS / 64) ln_bwd_row<2>(a, row_of(i), lane, dg, db);
+  if (a.dgamma == nullptr && a.dbeta == nullptr) return;            // workgroup-uniform
+#pragma unroll
+  for (int q = 0; q < 2; ++q) { red[(0 * 8 + wave) * 128 + q * 64 + lane] = dg[q]; red[(1 * 8 + wave) * 128 + q * 64 + lane] = db[q]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < a.n; i += FR_THREADS) {
+    float gsum = 0.f, bsum = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { gsum += red[(0 * 8 + w) * 128 + i]; bsum += red[(1 * 8 + w) * 128 + i]; }
+    if (a.dgamma) atomicAdd(&a.dgamma[i], gsum);
+    if (a.dbeta) atomicAdd(&a.dbeta[i], bsum);
+  }
+  __syncthreads();                                                   // `red` is free again
+}
+
+__global__ __launch_bounds__(FR_THREADS) void fused_bwd_c_kernel(FusedBwdC P) {
+  __shared__ float red[2 * 8 * 128];
+  const int b0 = (int)blockIdx.x * P.nb;
+  const int nb = min(P.nb, P.B - b0);
+  const int NC = 6 + P.ncls, B = P.B, hs = P.hs;
+  // heads backward: sigmoid' (and the dropout of the class scores) into d_logits
+  for (int e = threadIdx.x; e < nb * NC; e += FR_THREADS) {
+    const int b = b0 + e / NC, c = e % NC;
+    float g = 0.f;
+    if (c < 6) {
+      if (P.d_tcp) { const float t = P.tcp[b * 6 + c]; g = P.d_tcp[b * 6 + c] * t * (1.f - t); }
+    } else {
+      const int k = c - 6;
+      if (P.d_scores) {
+        const float s = P.scores[b * P.ncls + k];
+        g = P.d_scores[b * P.ncls + k] * s * (1.f - s) * drop_mul(P.p_cls, P.seed, P.site_cls, (uint64_t)(b * P.ncls + k));
+      }
+    }
+    P.d_logits[b * NC + c] = g;
+  }
+  stage_sync();
+  // d_hfused (nb, 6 hs) = d_logits (nb, NC) W_head (NC, 6 hs): a dozen terms per element
+  const int W6 = 6 * hs;
+  for (int e = threadIdx.x; e < nb * W6; e += FR_THREADS) {
+    const int b = b0 + e / W6, n = e % W6;
+    float acc = 0.f;
+    for (int c = 0; c < NC; ++c) acc += P.d_logits[b * NC + c] * P.head_w[(int64_t)c * W6 + n];
+    P.d_hfused[(int64_t)b * W6 + n] = acc;
+  }
+  stage_sync();
+  // LayerNorm 2 backward over the token rows (s, b) of these samples
+  ln_bwd_rows(P.ln2, S6K * nb, [&](int i) { return (i / nb) * B + b0 + (i % nb); }, red);
+}
+
+__global__ __launch_bounds__(FR_THREADS) void fused_bwd_a_kernel(FusedBwdA P) {
+  __shared__ float red[2 * 8 * 128];
+  const int b0 = (int)blockIdx.x * P.nb;
+  const int nb = min(P.nb, P.B - b0);
+  const int B = P.B, hs = P.hs;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int64_t BH = (int64_t)B * hs;
+  int stamp_i = 0;
+  auto stamp = [&]() { if (P.dbg && blockIdx.x == 0 && threadIdx.x == 0) P.dbg[stamp_i] = __builtin_readcyclecounter(); ++stamp_i; };
+  stamp();
+  // ---- LayerNorm 1 backward: d_x6 += ..., d_attn_out
+  ln_bwd_rows(P.ln1, S6K * nb, [&](int i) { return (i / nb) * B + b0 + (i % nb); }, red);
+  stage_sync();
+  stamp();
+  // token-row tile: tile row r = j nb + bb  <->  global row j B + b0 + bb
+  const int ntok = S6K * nb;                             // <= 12
+  const bool rok = r16 < ntok;
+  const int tj = rok ? r16 / nb : 0, tb = rok ? r16 % nb : 0;
+  const int64_t trow = (int64_t)tj * B + b0 + tb;        // this lane's A row in the token tiles
+  const int col = wave * 16 + r16;                       // this lane's Bt row (output column): hs = 128 = 8 waves x 16
+  // ---- d_ctx = d_attn_out W_out
+  {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* const ar[1] = {rok ? P.d_attn_out + trow * hs : nullptr};
+    const float* const br[1] = {P.out_wT + (int64_t)col * hs};
+    tile_mac_chain<1>(acc, ar, br, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * g + i;
+      if (r < ntok) P.d_ctx[((int64_t)(r / nb) * B + b0 + (r % nb)) * hs + col] = acc[i];
+    }
+  }
+  stage_sync();
+  stamp();
+  // ---- attention backward, one wave per (sample, head)
+  for (int pr = wave; pr < nb * P.nhead; pr += FR_THREADS / 64)
+    attn_bwd_hd64_one(P.qkv, P.probs, P.d_ctx, B, P.d_qkv, P.p_tf, P.seed, P.site_attn, P.nhead, (b0 + pr / P.nhead) * P.nhead + pr % P.nhead, lane);
+  stage_sync();
+  stamp();
+  // ---- d_x6[j] = (d_x6[j] + d_qkv[j] W_in + d_recon[j % 3] W_rec[j % 3]) * s (1 - s)
+  {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // (rows of the other two modalities multiply zeros in the per-modality products)
+    const float* rec_row = rok ? P.d_recon + ((int64_t)(tj % 3) * B + b0 + tb) * hs : nullptr;
+    const float* qrow = rok ? P.d_qkv + trow * 3 * hs : nullptr;
+    const float* wrow = P.in_wT + (int64_t)col * 3 * hs;
+    const float* const ar[6] = {qrow, qrow ? qrow + 128 : nullptr, qrow ? qrow + 256 : nullptr, (rok && tj % 3 == 0) ? rec_row : nullptr,
+                                (rok && tj % 3 == 1) ? rec_row : nullptr, (rok && tj % 3 == 2) ? rec_row : nullptr};
+    const float* const br[6] = {wrow, wrow + 128, wrow + 256, P.rec_wT + (int64_t)col * hs, P.rec_wT + (int64_t)hs * hs + (int64_t)col * hs,
+                                P.rec_wT + (int64_t)2 * hs * hs + (int64_t)col * hs};
+    tile_mac_chain<6>(acc, ar, br, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * g + i;
+      if (r < ntok) {
+        const int64_t o = ((int64_t)(r / nb) * B + b0 + (r % nb)) * hs + col;
+        const float s = P.x6[o];
+        P.d_x6[o] = (P.d_x6[o] + acc[i]) * (s * (1.f - s));
+      }
+    }
+  }
+  stage_sync();
+  stamp();
+  // ---- d_orig[i] += d_private[i] W_priv[i] + d_shared[i] W_shared; modality-row tile: tile row r = i nb + bb
+  const int nmod = 3 * nb;
+  const bool mok = r16 < nmod;
+  const int mi = mok ? r16 / nb : 0, mb = mok ? r16 % nb : 0;
+  {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* prow = mok ? P.d_x6 + ((int64_t)mi * B + b0 + mb) * hs : nullptr;
+    const float* const ar[4] = {mok ? P.d_x6 + ((int64_t)(3 + mi) * B + b0 + mb) * hs : nullptr, (mok && mi == 0) ? prow : nullptr,
+                                (mok && mi == 1) ? prow : nullptr, (mok && mi == 2) ? prow : nullptr};
+    const float* const br[4] = {P.sh_wT + (int64_t)col * hs, P.priv_wT + (int64_t)col * hs, P.priv_wT + (int64_t)hs * hs + (int64_t)col * hs,
+                                P.priv_wT + (int64_t)2 * hs * hs + (int64_t)col * hs};
+    tile_mac_chain<4>(acc, ar, br, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * g + i;
+      if (r < nmod) {
+        const int64_t o = ((int64_t)(r / nb) * B + b0 + (r % nb)) * hs + col;
+        P.d_orig[o] += acc[i];
+      }
+    }
+  }
+  stage_sync();
+  stamp();
+  // ---- the three projection LayerNorms (with their activation) backward: d_z.  One wave per (modality, sample) row; a wave's
+  // dgamma / dbeta terms go out as its own atomics (two rows per modality and workgroup: nothing to reduce first)
+  for (int i = wave; i < 3 * nb; i += FR_THREADS / 64) {
+    const mmda_ln_bwd_args& a = P.lnp[i / nb];
+    float dg[2] = {0.f, 0.f}, db[2] = {0.f, 0.f};
+    ln_bwd_row<2>(a, b0 + i % nb, lane, dg, db);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int c = q * 64 + lane;
+      if (c < a.n) {
+        if (a.dgamma) atomicAdd(&a.dgamma[c], dg[q]);
+        if (a.dbeta) atomicAdd(&a.dbeta[c], db[q]);
+      }
+    }
+  }
+  (void)BH;
+  stamp();
+}
+
+}  // namespace
+
+int mmda_fused_bwd_c(const FusedBwdC* a, void* stream) {
+  if (!a || a->B <= 0 || a->nb <= 0 || a->hs != 128 || a->ln2.n != 128) return MMDA_EINVAL;
+  hipLaunchKernelGGL(fused_bwd_c_kernel, dim3(ceil_div(a->B, a->nb)), dim3(FR_THREADS), 0, (hipStream_t)stream, *a);
+  MMDA_CHECK_LAUNCH("mmda_fused_bwd_c");
+  return MMDA_OK;
+}
+
+static unsigned long long* g_fr_dbg = nullptr;
+extern "C" int mmda_debug_set_fused_stamps(void* device_buffer) { g_fr_dbg = (unsigned long long*)device_buffer; return MMDA_OK; }
+
+int mmda_fused_bwd_a(const FusedBwdA* a, void* stream) {
+  if (!a || a->B <= 0 || a->nb <= 0 || a->nb > 2 || a->hs != 128 || a->nhead != 2) return MMDA_EINVAL;
+  FusedBwdA P = *a;
+  P.dbg = g_fr_dbg;
+  hipLaunchKernelGGL(fused_bwd_a_kernel, dim3(ceil_div(a->B, a->nb)), dim3(FR_THREADS), 0, (hipStream_t)stream, P);
+  MMDA_CHECK_LAUNCH("mmda_fused_bwd_a");
+  return MMDA_OK;
+}

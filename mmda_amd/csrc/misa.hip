@@ -3,6 +3,7 @@
 // gemm.hip / lstm.hip / norm.hip / attn.hip / losses.hip / optim.hip in dependency order on one stream.  No device
 // memory is owned here; no torch types; no host<->device synchronisation anywhere in a step.
 #include "common.h"
+#include "fused_rows.h"
 #include <map>
 #include <string>
 #include <vector>
@@ -1134,22 +1135,33 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
   if (B <= SKINNY_MAX_B) {
     // ---- few rows: the dX chain on row-skinny GEMMs (13 launches); weight gradients deferred exactly as below
     mmda_skinny_args g[8];
-    x.rc = mmda_heads_bwd(WS(m->tcp), WS(m->scores), WS(m->d_tcp), WS(m->d_scores), B, c.ncls, WS(m->d_logits), p_cls, seed, SITE_CLS,
-                          stream);
     const bool wt = m->wT_valid != 0;                   // K-major weight copies from this step's forward (side stream, joined there)
-    g[0] = wt ? sk_dx(B, NC, 6 * hs, WS(m->d_logits), NC, WS(m->head_wT), WS(m->d_hfused), 6 * hs, 0)
-              : sk_nn(B, NC, 6 * hs, WS(m->d_logits), NC, PP(m->head_w), WS(m->d_hfused), 6 * hs, 0);
-    sk_launch(x, g, 1);
-    lin_dw(x, fmode, B, NC, 6 * hs, WS(m->d_logits), WS(m->hfused), GG(m->head_w), GG(m->head_b));
-    // norm2 + FFN
-    if (!x.rc) {
-      mmda_ln_bwd_args l = {};
-      l.rows = 6 * B; l.n = hs; l.dy = WS(m->d_hfused); l.x = WS(m->x1); l.res = WS(m->f2); l.gamma = PP(m->n2_w);
-      l.mean = WS(m->ln2_mean); l.rstd = WS(m->ln2_rstd); l.d_x = WS(m->d_x1); l.d_res = WS(m->d_f2);
-      l.dgamma = GG(m->n2_w); l.dbeta = GG(m->n2_b); l.drop_p = p_tf; l.drop_seed = seed; l.drop_site = SITE_DROP2;
-      l.permute_S = S6; l.permute_B = B;
-      x.rc = mmda_layernorm_bwd(&l, stream);
+    // The row-local stretches as one launch each (fused_rows.hip): heads' sigmoid' -> d_hfused -> LayerNorm 2, and LayerNorm 1 ->
+    // ... -> the projection LayerNorms.  MMDA_ROW_FUSE=0: the launches they replace (3 and 6).
+    static const int row_fuse_on = getenv("MMDA_ROW_FUSE") ? atoi(getenv("MMDA_ROW_FUSE")) : 1;
+    const bool row_fuse = row_fuse_on && wt && c.use_cmd_sim && hs == 128 && NHEAD == 2;
+    const int fuse_nb = (B % 2) == 0 ? 2 : 1;
+    mmda_ln_bwd_args l2a = {};
+    l2a.rows = 6 * B; l2a.n = hs; l2a.dy = WS(m->d_hfused); l2a.x = WS(m->x1); l2a.res = WS(m->f2); l2a.gamma = PP(m->n2_w);
+    l2a.mean = WS(m->ln2_mean); l2a.rstd = WS(m->ln2_rstd); l2a.d_x = WS(m->d_x1); l2a.d_res = WS(m->d_f2);
+    l2a.dgamma = GG(m->n2_w); l2a.dbeta = GG(m->n2_b); l2a.drop_p = p_tf; l2a.drop_seed = seed; l2a.drop_site = SITE_DROP2;
+    l2a.permute_S = S6; l2a.permute_B = B;
+    if (row_fuse) {
+      FusedBwdC f = {};
+      f.B = B; f.hs = hs; f.ncls = c.ncls; f.nb = fuse_nb;
+      f.tcp = WS(m->tcp); f.scores = WS(m->scores); f.d_tcp = WS(m->d_tcp); f.d_scores = WS(m->d_scores); f.d_logits = WS(m->d_logits);
+      f.p_cls = p_cls; f.seed = seed; f.site_cls = SITE_CLS; f.head_w = PP(m->head_w); f.d_hfused = WS(m->d_hfused); f.ln2 = l2a;
+      x.rc = mmda_fused_bwd_c(&f, stream);
+    } else {
+      x.rc = mmda_heads_bwd(WS(m->tcp), WS(m->scores), WS(m->d_tcp), WS(m->d_scores), B, c.ncls, WS(m->d_logits), p_cls, seed, SITE_CLS,
+                            stream);
+      g[0] = wt ? sk_dx(B, NC, 6 * hs, WS(m->d_logits), NC, WS(m->head_wT), WS(m->d_hfused), 6 * hs, 0)
+                : sk_nn(B, NC, 6 * hs, WS(m->d_logits), NC, PP(m->head_w), WS(m->d_hfused), 6 * hs, 0);
+      sk_launch(x, g, 1);
+      if (!x.rc) x.rc = mmda_layernorm_bwd(&l2a, stream);       // norm2
     }
+    lin_dw(x, fmode, B, NC, 6 * hs, WS(m->d_logits), WS(m->hfused), GG(m->head_w), GG(m->head_b));
+    // FFN
     // d f1 = (d f2 W2) * [f1 > 0] / (1-p): f1 is stored post-relu, post-dropout, so f1 > 0 <=> kept and pre-activation > 0
     g[0] = wt ? sk_dx(6 * B, hs, FFN, WS(m->d_f2), hs, WS(m->l2_wT), WS(m->d_f1), FFN, 0)
               : sk_nn(6 * B, hs, FFN, WS(m->d_f2), hs, PP(m->l2_w), WS(m->d_f1), FFN, 0);
@@ -1160,79 +1172,118 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
               : sk_nn(6 * B, FFN, hs, WS(m->d_f1), FFN, PP(m->l1_w), WS(m->d_x1), hs, 1);
     sk_launch(x, g, 1);
     lin_dw(x, fmode, 6 * B, FFN, hs, WS(m->d_f1), WS(m->x1), GG(m->l1_w), GG(m->l1_b));
-    // norm1 + self-attention
-    if (!x.rc) {
-      mmda_ln_bwd_args l = {};
+    // norm1 + self-attention ... projection LayerNorms
+    if (row_fuse && !x.rc) {
+      FusedBwdA f = {};
+      f.B = B; f.hs = hs; f.nhead = NHEAD; f.nb = fuse_nb;
+      mmda_ln_bwd_args& l = f.ln1;
       l.rows = 6 * B; l.n = hs; l.dy = WS(m->d_x1); l.x = WS(m->x6); l.res = WS(m->attn_out); l.gamma = PP(m->n1_w);
       l.mean = WS(m->ln1_mean); l.rstd = WS(m->ln1_rstd); l.d_x = WS(m->d_x6); l.accumulate_dx = 1; l.d_res = WS(m->d_attn_out);
       l.dgamma = GG(m->n1_w); l.dbeta = GG(m->n1_b); l.drop_p = p_tf; l.drop_seed = seed; l.drop_site = SITE_DROP1;
-      x.rc = mmda_layernorm_bwd(&l, stream);
-    }
-    int n = 0;
-    g[n++] = wt ? sk_dx(6 * B, hs, hs, WS(m->d_attn_out), hs, WS(m->out_wT), WS(m->d_ctx), hs, 0)
-                : sk_nn(6 * B, hs, hs, WS(m->d_attn_out), hs, PP(m->out_w), WS(m->d_ctx), hs, 0);
-    if (!c.use_cmd_sim) g[n++] = wt ? sk_dx(3 * B, 3, hs, WS(m->d_dom), 3, WS(m->d2_wT), WS(m->d_dom_h), hs, 0)
-                                    : sk_nn(3 * B, 3, hs, WS(m->d_dom), 3, PP(m->d2_w), WS(m->d_dom_h), hs, 0);
-    sk_launch(x, g, n);
-    lin_dw(x, fmode, 6 * B, hs, hs, WS(m->d_attn_out), WS(m->ctx), GG(m->out_w), GG(m->out_b));
-    if (!x.rc) x.rc = mmda_attn_bwd(WS(m->qkv), WS(m->probs), WS(m->d_ctx), S6, B, hs, NHEAD, WS(m->d_qkv), p_tf, seed, SITE_ATTN, stream);
-    lin_dw(x, fmode, 6 * B, 3 * hs, hs, WS(m->d_qkv), WS(m->x6), GG(m->in_w), GG(m->in_b));
-    // adversarial branch: discriminator grads, then the REVERSED gradient into the shared codes (functions.py:17-21)
-    if (!c.use_cmd_sim) {
-      lin_dw(x, fmode, 3 * B, 3, hs, WS(m->d_dom), WS(m->dom_h), GG(m->d2_w), GG(m->d2_b));
-      if (!x.rc) {
-        const mmda_act_params ap = act_params(m, training, seed, SITE_RRELU_DISC, true);
-        x.rc = mmda_act_dropout_bwd_p(WS(m->d_dom_h), WS(m->dom_z), WS(m->d_dom_z), 3 * BH, c.act, &ap, p_cls, seed, SITE_DISC, stream);
-      }
-      lin_dw(x, fmode, 3 * B, hs, hs, WS(m->d_dom_z), WS(m->x6 + 3 * BH), GG(m->d1_w), GG(m->d1_b));
-      g[0] = wt ? sk_dx(3 * B, hs, hs, WS(m->d_dom_z), hs, WS(m->d1_wT), WS(m->d_x6 + 3 * BH), hs, 1)
-                : sk_nn(3 * B, hs, hs, WS(m->d_dom_z), hs, PP(m->d1_w), WS(m->d_x6 + 3 * BH), hs, 1);
-      g[0].alpha = -c.reverse_grad_weight;
-      sk_launch(x, g, 1);
-    }
-    // d_x6[token j] = (d_x6 + d_qkv[j] W_in + d_recon[j % 3] W_rec[j % 3]) * s (1 - s): the q/k/v projection's and the
-    // reconstruction's input gradients (the latter flows into BOTH private and shared) and the sigmoid backward, six problems
-    for (int j = 0; j < 6; ++j) {
-      const int i = j % 3;
-      g[j] = wt ? sk_dx(B, 3 * hs, hs, WS(m->d_qkv + (int64_t)j * B * 3 * hs), 3 * hs, WS(m->in_wT), WS(m->d_x6 + j * BH), hs, 1)
-                : sk_nn(B, 3 * hs, hs, WS(m->d_qkv + (int64_t)j * B * 3 * hs), 3 * hs, PP(m->in_w), WS(m->d_x6 + j * BH), hs, 1);
-      g[j].K2 = hs; g[j].A_2nd = WS(m->d_recon + i * BH); g[j].lda_2nd = hs; g[j].ldb_2nd = hs;
-      g[j].B_2nd = wt ? WS(m->rec_wT + (int64_t)i * hs * hs) : PP(m->rec_w + (int64_t)i * hs * hs);
-      g[j].dsig = WS(m->x6 + j * BH); g[j].lddsig = hs;
-    }
-    sk_launch(x, g, 6);
-    {
-      mmda_gemm_args e = {};
-      e.bias_grad = GG(m->rec_b);      // strideBias = hs: one bias gradient per batched problem
-      gemm(x, fmode, 1, 0, hs, hs, B, WS(m->d_recon), hs, WS(m->rsum), hs, GG(m->rec_w), hs, nullptr, nullptr, 1, 0, 3, BH, BH, (int64_t)hs * hs,
-           hs, &e);
-    }
-    // d_orig[i] += d_private[i] W_priv[i] + d_shared[i] W_shared
-    for (int i = 0; i < 3; ++i) {
-      g[i] = wt ? sk_dx(B, hs, hs, WS(m->d_x6 + i * BH), hs, WS(m->priv_wT + (int64_t)i * hs * hs), WS(m->d_orig + i * BH), hs, 1)
-                : sk_nn(B, hs, hs, WS(m->d_x6 + i * BH), hs, PP(m->priv_w + (int64_t)i * hs * hs), WS(m->d_orig + i * BH), hs, 1);
-      g[i].K2 = hs; g[i].A_2nd = WS(m->d_x6 + (3 + i) * BH); g[i].lda_2nd = hs; g[i].B_2nd = wt ? WS(m->sh_wT) : PP(m->sh_w); g[i].ldb_2nd = hs;
-    }
-    sk_launch(x, g, 3);
-    {
-      mmda_gemm_args e = {};
-      e.bias_grad = GG(m->priv_b);
-      gemm(x, fmode, 1, 0, hs, hs, B, WS(m->d_x6), hs, WS(m->orig), hs, GG(m->priv_w), hs, nullptr, nullptr, 1, 0, 3, BH, BH, (int64_t)hs * hs,
-           hs, &e);
-    }
-    lin_dw(x, fmode, 3 * B, hs, hs, WS(m->d_x6 + 3 * BH), WS(m->orig), GG(m->sh_w), GG(m->sh_b));
-    // projections
-    if (!x.rc) {
-      mmda_ln_bwd_args l[3];
+      f.d_attn_out = WS(m->d_attn_out); f.out_wT = WS(m->out_wT); f.d_ctx = WS(m->d_ctx);
+      f.qkv = WS(m->qkv); f.probs = WS(m->probs); f.d_qkv = WS(m->d_qkv); f.p_tf = p_tf; f.seed = seed; f.site_attn = SITE_ATTN;
+      f.in_wT = WS(m->in_wT); f.d_recon = WS(m->d_recon); f.rec_wT = WS(m->rec_wT); f.x6 = WS(m->x6); f.d_x6 = WS(m->d_x6);
+      f.priv_wT = WS(m->priv_wT); f.sh_wT = WS(m->sh_wT); f.d_orig = WS(m->d_orig);
       for (int i = 0; i < 3; ++i) {
         Mod& md = m->mod[i];
-        l[i] = mmda_ln_bwd_args{};
-        l[i].rows = B; l[i].n = hs; l[i].dy = WS(m->d_orig + i * BH); l[i].x = WS(m->z + i * BH); l[i].gamma = PP(md.plw);
-        l[i].mean = WS(m->pmean + i * B); l[i].rstd = WS(m->prstd + i * B); l[i].d_x = WS(m->d_z + i * BH);
-        l[i].dgamma = GG(md.plw); l[i].dbeta = GG(md.plb); l[i].act = c.act;
-        l[i].actp = act_params(m, training, seed, SITE_RRELU + i, true);
+        mmda_ln_bwd_args& lp = f.lnp[i];
+        lp.rows = B; lp.n = hs; lp.dy = WS(m->d_orig + i * BH); lp.x = WS(m->z + i * BH); lp.gamma = PP(md.plw);
+        lp.mean = WS(m->pmean + i * B); lp.rstd = WS(m->prstd + i * B); lp.d_x = WS(m->d_z + i * BH);
+        lp.dgamma = GG(md.plw); lp.dbeta = GG(md.plb); lp.act = c.act;
+        lp.actp = act_params(m, training, seed, SITE_RRELU + i, true);
       }
-      x.rc = mmda_layernorm_bwd_multi(l, 3, stream);
+      x.rc = mmda_fused_bwd_a(&f, stream);
+      // the weight gradients of the stretch (deferred: one grouped launch on the side stream, as below)
+      lin_dw(x, fmode, 6 * B, hs, hs, WS(m->d_attn_out), WS(m->ctx), GG(m->out_w), GG(m->out_b));
+      lin_dw(x, fmode, 6 * B, 3 * hs, hs, WS(m->d_qkv), WS(m->x6), GG(m->in_w), GG(m->in_b));
+      {
+        mmda_gemm_args e = {};
+        e.bias_grad = GG(m->rec_b);      // strideBias = hs: one bias gradient per batched problem
+        gemm(x, fmode, 1, 0, hs, hs, B, WS(m->d_recon), hs, WS(m->rsum), hs, GG(m->rec_w), hs, nullptr, nullptr, 1, 0, 3, BH, BH, (int64_t)hs * hs,
+             hs, &e);
+      }
+      {
+        mmda_gemm_args e = {};
+        e.bias_grad = GG(m->priv_b);
+        gemm(x, fmode, 1, 0, hs, hs, B, WS(m->d_x6), hs, WS(m->orig), hs, GG(m->priv_w), hs, nullptr, nullptr, 1, 0, 3, BH, BH, (int64_t)hs * hs,
+             hs, &e);
+      }
+      lin_dw(x, fmode, 3 * B, hs, hs, WS(m->d_x6 + 3 * BH), WS(m->orig), GG(m->sh_w), GG(m->sh_b));
+    } else {
+      // norm1 + self-attention
+      if (!x.rc) {
+        mmda_ln_bwd_args l = {};
+        l.rows = 6 * B; l.n = hs; l.dy = WS(m->d_x1); l.x = WS(m->x6); l.res = WS(m->attn_out); l.gamma = PP(m->n1_w);
+        l.mean = WS(m->ln1_mean); l.rstd = WS(m->ln1_rstd); l.d_x = WS(m->d_x6); l.accumulate_dx = 1; l.d_res = WS(m->d_attn_out);
+        l.dgamma = GG(m->n1_w); l.dbeta = GG(m->n1_b); l.drop_p = p_tf; l.drop_seed = seed; l.drop_site = SITE_DROP1;
+        x.rc = mmda_layernorm_bwd(&l, stream);
+      }
+      int n = 0;
+      g[n++] = wt ? sk_dx(6 * B, hs, hs, WS(m->d_attn_out), hs, WS(m->out_wT), WS(m->d_ctx), hs, 0)
+                  : sk_nn(6 * B, hs, hs, WS(m->d_attn_out), hs, PP(m->out_w), WS(m->d_ctx), hs, 0);
+      if (!c.use_cmd_sim) g[n++] = wt ? sk_dx(3 * B, 3, hs, WS(m->d_dom), 3, WS(m->d2_wT), WS(m->d_dom_h), hs, 0)
+                                      : sk_nn(3 * B, 3, hs, WS(m->d_dom), 3, PP(m->d2_w), WS(m->d_dom_h), hs, 0);
+      sk_launch(x, g, n);
+      lin_dw(x, fmode, 6 * B, hs, hs, WS(m->d_attn_out), WS(m->ctx), GG(m->out_w), GG(m->out_b));
+      if (!x.rc) x.rc = mmda_attn_bwd(WS(m->qkv), WS(m->probs), WS(m->d_ctx), S6, B, hs, NHEAD, WS(m->d_qkv), p_tf, seed, SITE_ATTN, stream);
+      lin_dw(x, fmode, 6 * B, 3 * hs, hs, WS(m->d_qkv), WS(m->x6), GG(m->in_w), GG(m->in_b));
+      // adversarial branch: discriminator grads, then the REVERSED gradient into the shared codes (functions.py:17-21)
+      if (!c.use_cmd_sim) {
+        lin_dw(x, fmode, 3 * B, 3, hs, WS(m->d_dom), WS(m->dom_h), GG(m->d2_w), GG(m->d2_b));
+        if (!x.rc) {
+          const mmda_act_params ap = act_params(m, training, seed, SITE_RRELU_DISC, true);
+          x.rc = mmda_act_dropout_bwd_p(WS(m->d_dom_h), WS(m->dom_z), WS(m->d_dom_z), 3 * BH, c.act, &ap, p_cls, seed, SITE_DISC, stream);
+        }
+        lin_dw(x, fmode, 3 * B, hs, hs, WS(m->d_dom_z), WS(m->x6 + 3 * BH), GG(m->d1_w), GG(m->d1_b));
+        g[0] = wt ? sk_dx(3 * B, hs, hs, WS(m->d_dom_z), hs, WS(m->d1_wT), WS(m->d_x6 + 3 * BH), hs, 1)
+                  : sk_nn(3 * B, hs, hs, WS(m->d_dom_z), hs, PP(m->d1_w), WS(m->d_x6 + 3 * BH), hs, 1);
+        g[0].alpha = -c.reverse_grad_weight;
+        sk_launch(x, g, 1);
+      }
+      // d_x6[token j] = (d_x6 + d_qkv[j] W_in + d_recon[j % 3] W_rec[j % 3]) * s (1 - s): the q/k/v projection's and the
+      // reconstruction's input gradients (the latter flows into BOTH private and shared) and the sigmoid backward, six problems
+      for (int j = 0; j < 6; ++j) {
+        const int i = j % 3;
+        g[j] = wt ? sk_dx(B, 3 * hs, hs, WS(m->d_qkv + (int64_t)j * B * 3 * hs), 3 * hs, WS(m->in_wT), WS(m->d_x6 + j * BH), hs, 1)
+                  : sk_nn(B, 3 * hs, hs, WS(m->d_qkv + (int64_t)j * B * 3 * hs), 3 * hs, PP(m->in_w), WS(m->d_x6 + j * BH), hs, 1);
+        g[j].K2 = hs; g[j].A_2nd = WS(m->d_recon + i * BH); g[j].lda_2nd = hs; g[j].ldb_2nd = hs;
+        g[j].B_2nd = wt ? WS(m->rec_wT + (int64_t)i * hs * hs) : PP(m->rec_w + (int64_t)i * hs * hs);
+        g[j].dsig = WS(m->x6 + j * BH); g[j].lddsig = hs;
+      }
+      sk_launch(x, g, 6);
+      {
+        mmda_gemm_args e = {};
+        e.bias_grad = GG(m->rec_b);      // strideBias = hs: one bias gradient per batched problem
+        gemm(x, fmode, 1, 0, hs, hs, B, WS(m->d_recon), hs, WS(m->rsum), hs, GG(m->rec_w), hs, nullptr, nullptr, 1, 0, 3, BH, BH, (int64_t)hs * hs,
+             hs, &e);
+      }
+      // d_orig[i] += d_private[i] W_priv[i] + d_shared[i] W_shared
+      for (int i = 0; i < 3; ++i) {
+        g[i] = wt ? sk_dx(B, hs, hs, WS(m->d_x6 + i * BH), hs, WS(m->priv_wT + (int64_t)i * hs * hs), WS(m->d_orig + i * BH), hs, 1)
+                  : sk_nn(B, hs, hs, WS(m->d_x6 + i * BH), hs, PP(m->priv_w + (int64_t)i * hs * hs), WS(m->d_orig + i * BH), hs, 1);
+        g[i].K2 = hs; g[i].A_2nd = WS(m->d_x6 + (3 + i) * BH); g[i].lda_2nd = hs; g[i].B_2nd = wt ? WS(m->sh_wT) : PP(m->sh_w); g[i].ldb_2nd = hs;
+      }
+      sk_launch(x, g, 3);
+      {
+        mmda_gemm_args e = {};
+        e.bias_grad = GG(m->priv_b);
+        gemm(x, fmode, 1, 0, hs, hs, B, WS(m->d_x6), hs, WS(m->orig), hs, GG(m->priv_w), hs, nullptr, nullptr, 1, 0, 3, BH, BH, (int64_t)hs * hs,
+             hs, &e);
+      }
+      lin_dw(x, fmode, 3 * B, hs, hs, WS(m->d_x6 + 3 * BH), WS(m->orig), GG(m->sh_w), GG(m->sh_b));
+      // projections
+      if (!x.rc) {
+        mmda_ln_bwd_args l[3];
+        for (int i = 0; i < 3; ++i) {
+          Mod& md = m->mod[i];
+          l[i] = mmda_ln_bwd_args{};
+          l[i].rows = B; l[i].n = hs; l[i].dy = WS(m->d_orig + i * BH); l[i].x = WS(m->z + i * BH); l[i].gamma = PP(md.plw);
+          l[i].mean = WS(m->pmean + i * B); l[i].rstd = WS(m->prstd + i * B); l[i].d_x = WS(m->d_z + i * BH);
+          l[i].dgamma = GG(md.plw); l[i].dbeta = GG(md.plb); l[i].act = c.act;
+          l[i].actp = act_params(m, training, seed, SITE_RRELU + i, true);
+        }
+        x.rc = mmda_layernorm_bwd_multi(l, 3, stream);
+      }
     }
     for (int i = 0; i < 3; ++i) {
       Mod& md = m->mod[i];

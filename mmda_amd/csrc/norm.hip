@@ -1,17 +1,11 @@
 // Row-wise kernels: LayerNorm forward/backward (wave-per-row shuffle reductions), embedding gather / scatter-add,
 // small elementwise helpers.  All HBM-bound; loads are lane-consecutive (coalesced 256 B per wave instruction).
 #include "common.h"
+#include "rowlocal.h"
 
 namespace {
 
 constexpr int LN_MAXQ = 16;   // up to 16*64 = 1024 columns cached in registers per lane
-
-__device__ __forceinline__ int64_t perm_row(int row, int S, int Bp) {
-  // (s,b) row -> (b,s) row when a permutation is requested
-  if (S <= 0) return row;
-  int s = row / Bp, b = row % Bp;
-  return (int64_t)b * S + s;
-}
 
 constexpr int LN_MAXP = 4;      // problems per launch (the three modalities' LayerNorms go out together)
 struct LnMulti { mmda_ln_args a[LN_MAXP]; int start[LN_MAXP + 1]; int n; };
@@ -81,51 +75,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdMulti L) {
   float dg[NQ], db[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) { dg[q] = 0.f; db[q] = 0.f; }
-  for (int row = blk * 4 + wave; row < a.rows; row += nblk * 4) {
-    const float mean = a.mean[row], rstd = a.rstd[row];
-    const int64_t drow = perm_row(row, a.permute_S, a.permute_B);
-    float xh[NQ], gdy[NQ];
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      int i = lane + 64 * q;
-      xh[q] = 0.f; gdy[q] = 0.f;
-      if (i < n) {
-        int64_t idx = (int64_t)row * n + i;
-        float x = act_fwd_p(a.act, a.x[idx], a.actp, (uint64_t)idx);
-        if (a.res) x += a.res[idx] * drop_mul(a.drop_p, a.drop_seed, a.drop_site, (uint64_t)idx);
-        float dy = a.dy[drow * n + i];
-        xh[q] = (x - mean) * rstd;
-        gdy[q] = dy * a.gamma[i];
-        dg[q] += dy * xh[q];
-        db[q] += dy;
-        s1 += gdy[q];
-        s2 += gdy[q] * xh[q];
-      }
-    }
-    s1 = wave_sum(s1) / n;
-    s2 = wave_sum(s2) / n;
-    float dslope = 0.f;                                  // PReLU: d(slope) = sum of dx_pre * z over the elements with z <= 0
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      int i = lane + 64 * q;
-      if (i < n) {
-        int64_t idx = (int64_t)row * n + i;
-        float dxp = rstd * (gdy[q] - s1 - xh[q] * s2);
-        if (a.d_x) {
-          const float z = a.x[idx];
-          float d = dxp * act_bwd_p(a.act, z, a.actp, (uint64_t)idx);
-          a.d_x[idx] = a.accumulate_dx ? a.d_x[idx] + d : d;
-          if (a.act == MMDA_ACT_PRELU && z <= 0.f) dslope += dxp * z;
-        }
-        if (a.d_res) a.d_res[idx] = dxp * drop_mul(a.drop_p, a.drop_seed, a.drop_site, (uint64_t)idx);
-      }
-    }
-    if (a.act == MMDA_ACT_PRELU && a.d_x && a.actp.dslope) {       // problem-uniform
-      dslope = wave_sum(dslope);
-      if (lane == 0) atomicAdd(a.actp.dslope, dslope);
-    }
-  }
+  for (int row = blk * 4 + wave; row < a.rows; row += nblk * 4) ln_bwd_row<NQ>(a, row, lane, dg, db);      // (rowlocal.h)
   if (!want_pg) return;            // block-uniform: parameter gradients come from mmda_layernorm_param_grads instead
   // reduce the per-wave column partials across the block's 4 waves, then one atomic per column per block
   const int nq = (n + 63) / 64;
