@@ -104,6 +104,12 @@ typedef struct mmda_gemm_bf16_args {
    * (forward: B rows were interleaved by mmda_convert_bf16).  perm_m_H = H: C rows and bias_grad entries are written at
    * orig(m) (weight gradients: A rows are interleaved).  0 = no interleave. */
   int perm_n_H, perm_m_H;
+  /* tn = 1: BOTH operands are M/N-major -- A is bf16 (K, lda) with row k holding A[., k] along m, B is bf16 (K, ldb) likewise:
+   * C[M,N] (+)= alpha * A^T B, the weight-gradient form dW = dG^T X on the tensors as the backward pass leaves them (no transposed
+   * copies: the kernel stages k-rows into LDS and takes its MFMA fragments with the transposing LDS read of gfx950,
+   * ds_read_b64_tr_b16).  lda / ldb multiples of 4 (8-byte rows), bases 4-byte aligned; columns m >= M / n >= N of a row may hold
+   * anything finite (they only reach outputs that are not stored).  bias_grad then is a virtual all-ones COLUMN n == N of B. */
+  int tn;
 } mmda_gemm_bf16_args;
 int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, void* stream);
 /* fp32 (rows, cols) matrix with leading dim ld -> bf16 copies: `plain` (rows, ldp) and/or `transposed` (cols, ldt); either may be

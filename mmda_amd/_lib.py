@@ -35,7 +35,8 @@ class GemmArgs(C.Structure):
 class GemmBf16Args(C.Structure):
     _fields_ = [("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("A", C.c_void_p), ("lda", C.c_int), ("B", C.c_void_p), ("ldb", C.c_int),
                 ("C", C.c_void_p), ("ldc", C.c_int), ("bias", C.c_void_p), ("bias2", C.c_void_p), ("bias_grad", C.c_void_p),
-                ("bias_grad2", C.c_void_p), ("accumulate", C.c_int), ("alpha", C.c_float), ("perm_n_H", C.c_int), ("perm_m_H", C.c_int)]
+                ("bias_grad2", C.c_void_p), ("accumulate", C.c_int), ("alpha", C.c_float), ("perm_n_H", C.c_int), ("perm_m_H", C.c_int),
+                ("tn", C.c_int)]
 
 
 class ConvertJob(C.Structure):

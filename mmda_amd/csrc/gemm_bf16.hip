@@ -18,6 +18,12 @@ namespace {
 
 constexpr int TK = 64;
 constexpr int LDT = TK + 8;                 // bf16 elements per LDS row (144 B: 16-B aligned, conflict-light for ds_read_b128)
+// tn form: the LDS image of an operand tile is [k 0..63][T + pad] (k-rows as they lie in memory); row strides of 40 (T = 64) and 72
+// (T = 128) banks make eight consecutive k-rows of 16 columns tile the 64 banks exactly, which is what one half-wave of a transposing
+// read touches (see tn_frag)
+template <int T> struct TnLd { static constexpr int v = T == 64 ? 80 : 144; };
+template <int T> struct LdsElems { static constexpr int nt = 2 * 2 * T * LDT, tn = 2 * 2 * TK * TnLd<T>::v, v = nt > tn ? nt : tn; };
+typedef short v4s __attribute__((ext_vector_type(4)));
 constexpr int GROUP_MAX = 16;
 
 
@@ -40,12 +46,13 @@ __device__ __forceinline__ u32x4 ld_chunk(const unsigned short* base, int row, i
 // One output tile of T x T (T = 128: 4 waves of 64 x 64; T = 64: 4 waves of 32 x 32), k-tiles of 64, two register stages of
 // global prefetch.  128 x 128 when the output alone fills the chip; 64 x 64 for the long-K / small-output gradient GEMMs,
 // where four times as many workgroups matter more than operand reuse.
-template <int T>
+template <int T, bool TN>
 __device__ __forceinline__ void gemm_bf16_tile(const mmda_gemm_bf16_args& g, int splitk, int bx, int by, int sp, unsigned short* AB) {
   // two LDS buffers of (A block | B block): k-tile kt is computed out of buffer kt & 1 while tile kt + 1 is being stored into the
   // other one -- ONE workgroup barrier per k-tile, and the LDS stores (ds_write_b128 runs at a third of the read rate) sit beside
   // the other waves' MFMAs instead of between two barriers
-  constexpr int BUF = 2 * T * LDT;
+  constexpr int LDK = TnLd<T>::v;             // tn: elements per k-row of an operand's LDS image
+  constexpr int BUF = TN ? 2 * TK * LDK : 2 * T * LDT;
   unsigned short* As = AB;                   // (the epilogue stages the C tile over the first buffer)
   constexpr int W = T / 32;                  // MFMA tiles per wave per dimension
   constexpr int CH = T / 32;                 // 16-B chunks per thread per operand and k-tile (T rows x 8 chunks / 256 threads)
@@ -73,24 +80,40 @@ __device__ __forceinline__ void gemm_bf16_tile(const mmda_gemm_bf16_args& g, int
   // read as zero in hardware, k past the (8-padded) depth is sent there by one select on the OFFSET -- no clamps, no 64-bit address
   // arithmetic and no selects on the loaded data in the k-loop (they were most of the wave's issue slots: the matrix pipe was 20 % busy
   // with the waves 38 % of their time in issue stalls, tools/prof_gemm_pmc.sh).  Host side guarantees (M + T) * lda * 2 < 4 GiB.
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(A), 0, (int)(((int64_t)(M - 1) * g.lda + Kp) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Bm), 0, (int)(((int64_t)(N - 1) * g.ldb + Kp) * 2), 0x00020000);
+  // (tn: the descriptors end with the last k-row, so k >= K reads as zero; columns past the row's width read the next row -- finite
+  //  values that only reach outputs nobody stores -- except past the very end, where they are zero again)
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(A), 0,
+      TN ? (int)((int64_t)K * g.lda * 2) : (int)(((int64_t)(M - 1) * g.lda + Kp) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Bm), 0,
+      TN ? (int)((int64_t)K * g.ldb * 2) : (int)(((int64_t)(N - 1) * g.ldb + Kp) * 2), 0x00020000);
   constexpr unsigned OOB_OFF = 0xFFFFFF00u;
+  constexpr int CPR = T / 8;                 // tn: 16-byte chunks per k-row of a tile
   unsigned offA[CH], offB[CH];
 #pragma unroll
   for (int i = 0; i < CH; ++i) {
     const int c = tid + 256 * i;
-    const int r = c >> 3, k = (c & 7) * 8;
-    offA[i] = (unsigned)(((row0 + r) * g.lda + k) * 2);
-    offB[i] = (unsigned)(((col0 + r) * g.ldb + k) * 2);
+    if (TN) {
+      const int kr = c / CPR, mc = (c % CPR) * 8;
+      offA[i] = (unsigned)((kr * g.lda + row0 + mc) * 2);
+      offB[i] = (unsigned)((kr * g.ldb + col0 + mc) * 2);
+    } else {
+      const int r = c >> 3, k = (c & 7) * 8;
+      offA[i] = (unsigned)(((row0 + r) * g.lda + k) * 2);
+      offB[i] = (unsigned)(((col0 + r) * g.ldb + k) * 2);
+    }
   }
   auto load_tile = [&](u32x4 (&a)[CH], u32x4 (&b)[CH], int k0) {
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       const int c = tid + 256 * i;
-      const bool k_ok = k0 + (c & 7) * 8 < Kp;
-      a[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, k_ok ? offA[i] + (unsigned)k0 * 2u : OOB_OFF, 0, 0);
-      b[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, k_ok ? offB[i] + (unsigned)k0 * 2u : OOB_OFF, 0, 0);
+      if (TN) {
+        a[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, offA[i] + (unsigned)k0 * (unsigned)g.lda * 2u, 0, 0);
+        b[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, offB[i] + (unsigned)k0 * (unsigned)g.ldb * 2u, 0, 0);
+      } else {
+        const bool k_ok = k0 + (c & 7) * 8 < Kp;
+        a[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, k_ok ? offA[i] + (unsigned)k0 * 2u : OOB_OFF, 0, 0);
+        b[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, k_ok ? offB[i] + (unsigned)k0 * 2u : OOB_OFF, 0, 0);
+      }
     }
   };
   // the virtual all-ones row n == N of B (bias gradient) is written straight into the LDS tile that holds column N: it never
@@ -98,7 +121,25 @@ __device__ __forceinline__ void gemm_bf16_tile(const mmda_gemm_bf16_args& g, int
   const bool tile_has_ones = ones_row && col0 <= N && N < col0 + T;       // block-uniform
   auto store_tile = [&](const u32x4 (&a)[CH], const u32x4 (&b)[CH], int k0, int buf) {
     unsigned short* As = AB + buf * BUF;
-    unsigned short* Bs = As + T * LDT;
+    unsigned short* Bs = As + (TN ? TK * LDK : T * LDT);
+    if (TN) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int c = tid + 256 * i;
+        const int kr = c / CPR, mc = (c % CPR) * 8;
+        *reinterpret_cast<u32x4*>(&As[kr * LDK + mc]) = a[i];
+        u32x4 v = b[i];
+        if (tile_has_ones && col0 + mc <= N && N < col0 + mc + 8) {      // the chunk that holds the virtual ones-column n == N
+          const unsigned one = (k0 + kr < K) ? 0x3F80u : 0u;
+          const int e = N - col0 - mc;
+          unsigned w = v[e >> 1];
+          w = (e & 1) ? ((w & 0x0000ffffu) | (one << 16)) : ((w & 0xffff0000u) | one);
+          v[e >> 1] = w;
+        }
+        *reinterpret_cast<u32x4*>(&Bs[kr * LDK + mc]) = v;
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       const int c = tid + 256 * i;
@@ -127,12 +168,31 @@ __device__ __forceinline__ void gemm_bf16_tile(const mmda_gemm_bf16_args& g, int
 #pragma unroll
   for (int u = 0; u < NS; ++u)
     if (kt0 + u < nk) load_tile(ra[u], rb[u], (kt0 + u) * TK);
+  // tn: the fragment of a 16-column block for the 32-deep k-step ks.  ds_read_b64_tr_b16 takes, per 16-lane group, a block of 4 k-rows x
+  // 16 columns -- lane 4q + p of the group gives the address of row q, columns 4p..4p+3 -- and hands lane i column i of the four rows.
+  // Group fq reads k-rows 4 fq + q and 16 + 4 fq + q of the step: its eight k are not consecutive, but A and B fragments use the same
+  // set, and a half-wave's two groups then touch eight CONSECUTIVE k-rows, which the row stride spreads over all 64 banks.
+  auto tn_frag = [&](const unsigned short* Xs, int cbase, int ks) -> bf16x8 {
+    typedef __attribute__((address_space(3))) v4s* lp;
+    const int q = (lane & 15) >> 2, p = lane & 3;
+    const unsigned short* a0 = &Xs[(ks * 32 + 4 * fq + q) * LDK + cbase + 4 * p];
+    const v4s r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)a0);
+    const v4s r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(a0 + 16 * LDK));
+    return bf16x8{r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+  };
   auto compute = [&](int buf) {
     const unsigned short* As = AB + buf * BUF;
-    const unsigned short* Bs = As + T * LDT;
+    const unsigned short* Bs = As + (TN ? TK * LDK : T * LDT);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 a[W], b[W];
+      if (TN) {
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+          a[i] = tn_frag(As, wm * (T / 2) + i * 16, ks);
+          b[i] = tn_frag(Bs, wn * (T / 2) + i * 16, ks);
+        }
+      } else
 #pragma unroll
       for (int i = 0; i < W; ++i) {
         a[i] = *reinterpret_cast<const bf16x8*>(&As[(wm * (T / 2) + i * 16 + fr) * LDT + ks * 32 + fq * 8]);
@@ -279,9 +339,9 @@ __device__ __forceinline__ void gemm_bf16_tile(const mmda_gemm_bf16_args& g, int
 
 // One kernel per tile size: the 64 x 64 form needs half the registers and LDS of the 128 x 128 one, and the long-K gradient
 // GEMMs that use it are bound by per-k-tile latency -- more resident workgroups per CU is what hides it.
-template <int T>
+template <int T, bool TN>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(Bf16Group G) {
-  __shared__ __attribute__((aligned(16))) unsigned short AB[2 * 2 * T * LDT];   // two buffers of (A block | B block); the C tile is staged over the first
+  __shared__ __attribute__((aligned(16))) unsigned short AB[TN ? LdsElems<T>::tn : LdsElems<T>::nt];   // two buffers of (A block | B block); the C tile is staged over the first
   int pi = 0;
 #pragma unroll
   for (int k = 1; k < GROUP_MAX; ++k)
@@ -290,7 +350,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(Bf16Group G) {
   const int splitk = G.splitk[pi];
   const int local = blockIdx.x - G.start[pi];
   const int bx = local % G.tx[pi], by = (local / G.tx[pi]) % G.ty[pi], sp = local / (G.tx[pi] * G.ty[pi]);
-  gemm_bf16_tile<T>(g, splitk, bx, by, sp, AB);
+  gemm_bf16_tile<T, TN>(g, splitk, bx, by, sp, AB);      // (a launch holds problems of one form: the tn form costs the 64-tile kernel 18 registers, i.e. a workgroup per CU)
 }
 
 __global__ __launch_bounds__(256) void convert_kernel(ConvLaunch L) {
@@ -306,6 +366,12 @@ extern "C" int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, vo
   for (int i = 0; i < n; ++i) {
     const mmda_gemm_bf16_args& a = args[i];
     if (!a.A || !a.B || !a.C || a.M < 0 || a.N < 0 || a.K <= 0) return MMDA_EINVAL;
+    if (a.tn) {
+      if ((a.lda & 3) || (a.ldb & 3) || (((uintptr_t)a.A | (uintptr_t)a.B) & 3) || a.lda < a.M || a.ldb < a.N) return MMDA_EINVAL;
+      if (((double)a.K + 64.0) * a.lda * 2.0 >= 4.0e9 || ((double)a.K + 64.0) * a.ldb * 2.0 >= 4.0e9) return MMDA_EINVAL;
+      if (a.perm_n_H < 0 || a.perm_m_H < 0 || (a.perm_n_H && a.N % (4 * a.perm_n_H)) || (a.perm_m_H && a.M % (4 * a.perm_m_H))) return MMDA_EINVAL;
+      continue;
+    }
     if ((a.lda & 7) || (a.ldb & 7) || (((uintptr_t)a.A | (uintptr_t)a.B) & 15)) return MMDA_EINVAL;
     if (a.lda < ((a.K + 7) & ~7) || a.ldb < ((a.K + 7) & ~7)) return MMDA_EINVAL;
     // operands are addressed with 32-bit byte offsets through buffer descriptors (row clamping is done by the descriptor's size)
@@ -318,6 +384,7 @@ extern "C" int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, vo
     const int Ne = a.N + (a.bias_grad ? 1 : 0);
     return ceil_div(Ne, 128) * ceil_div(a.M, 128) >= t128_min ? 128 : 64;
   };
+  for (int form = 0; form < 2; ++form)
   for (int T = 64; T <= 128; T += 64) {
     Bf16Group G;
     G.n = 0;
@@ -326,8 +393,13 @@ extern "C" int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, vo
       if (blocks == 0) { G.n = 0; return MMDA_OK; }
       for (int k = G.n; k <= GROUP_MAX; ++k) G.start[k] = blocks;
       for (int k = G.n; k < GROUP_MAX; ++k) { G.p[k] = G.p[0]; G.tx[k] = G.ty[k] = G.splitk[k] = 1; G.tile[k] = T; }
-      if (T == 128) hipLaunchKernelGGL(gemm_bf16_kernel<128>, dim3(blocks), dim3(256), 0, s, G);
-      else hipLaunchKernelGGL(gemm_bf16_kernel<64>, dim3(blocks), dim3(256), 0, s, G);
+      if (form == 0) {
+        if (T == 128) hipLaunchKernelGGL((gemm_bf16_kernel<128, false>), dim3(blocks), dim3(256), 0, s, G);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<64, false>), dim3(blocks), dim3(256), 0, s, G);
+      } else {
+        if (T == 128) hipLaunchKernelGGL((gemm_bf16_kernel<128, true>), dim3(blocks), dim3(256), 0, s, G);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<64, true>), dim3(blocks), dim3(256), 0, s, G);
+      }
       MMDA_CHECK_LAUNCH("mmda_gemm_bf16_grouped");
       G.n = 0; blocks = 0;
       return MMDA_OK;
@@ -338,7 +410,7 @@ extern "C" int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, vo
     int64_t all_tiles = 0;
     for (int i = 0; i < n; ++i) {
       const mmda_gemm_bf16_args& a = args[i];
-      if (a.M == 0 || a.N == 0 || tile_of(a) != T) continue;
+      if (a.M == 0 || a.N == 0 || tile_of(a) != T || (a.tn ? 1 : 0) != form) continue;
       order.push_back(i);
       all_tiles += (int64_t)ceil_div(a.N + (a.bias_grad ? 1 : 0), T) * ceil_div(a.M, T);
     }

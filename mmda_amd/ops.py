@@ -94,12 +94,15 @@ def gemm_bf16_grouped(problems):
     outs = []
     for g, p in zip(arr, problems):
         A, B = p["A"], p["B"]
-        assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and A.is_contiguous() and B.is_contiguous()
-        M, N, K = A.shape[0], B.shape[0], p["K"]
+        tn = bool(p.get("tn", False))
+        assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and (tn or (A.is_contiguous() and B.is_contiguous()))
+        # tn: A is (K, lda) with M <= lda columns in use, B is (K, ldb): C = A[:K, :M]^T @ B[:K, :N]
+        M, N, K = (p["M"], p["N"], p["K"]) if tn else (A.shape[0], B.shape[0], p["K"])
+        g.tn = int(tn); g.perm_m_H = int(p.get("perm_m_H", 0))
         out = p.get("out")
         if out is None:
             out = torch.zeros((M, N), device=A.device, dtype=torch.float32)
-        g.M = M; g.N = N; g.K = K; g.A = ptr(A); g.lda = A.shape[1]; g.B = ptr(B); g.ldb = B.shape[1]
+        g.M = M; g.N = N; g.K = K; g.A = ptr(A); g.lda = A.stride(0) if tn else A.shape[1]; g.B = ptr(B); g.ldb = B.stride(0) if tn else B.shape[1]
         g.C = ptr(_f(out)); g.ldc = N
         g.bias = ptr(p.get("bias")); g.bias2 = ptr(p.get("bias2"))
         g.bias_grad = ptr(p.get("bias_grad")); g.bias_grad2 = ptr(p.get("bias_grad2"))

@@ -141,6 +141,28 @@ def test_gemm_bf16_grouped_backward_forms_bias_grad_accumulate():
     assert relerr(outs[2], dGb[shift:].t() @ Xb[:R - shift]) < TOL["fp32"]
 
 
+@pytest.mark.parametrize("M,N,K,lda,ldb,a0,b0", [(2400, 300, 1600, 2400, 304, 0, 0), (140, 35, 1550, 280, 80, 140, 40),
+                                                  (1200, 300, 12750, 2400, 608, 1200, 304), (64, 64, 64, 64, 64, 0, 0),
+                                                  (296, 74, 490, 592, 160, 296, 80)])
+def test_gemm_bf16_tn_form_weight_gradient(M, N, K, lda, ldb, a0, b0):
+    """tn form: C = A^T B on (K, M)- and (K, N)-major operands (dW = dG^T X on the tensors as they lie; transposing LDS reads), with
+    the bias gradient as a virtual ones-column, accumulate, column windows that start off the 16-byte grid (the reverse direction's
+    half of dG for a 35-wide LSTM: a0 = 280 bytes; b0: the per-direction bf16 copy of hseq) and split-K -- against an fp32 matmul of the same bf16 values."""
+    from mmda_amd import ops
+    torch.manual_seed(M + N + K)
+    A = (torch.randn(K, lda) * 0.5).to(torch.bfloat16).to(dev())
+    Bm = (torch.randn(K, ldb) * 0.5).to(torch.bfloat16).to(dev())
+    C0 = torch.randn(M, N)
+    bg = torch.zeros(M, device=dev())
+    out, = ops.gemm_bf16_grouped([dict(A=A[:, a0:], B=Bm[:, b0:], M=M, N=N, K=K, tn=True, out=C0.clone().to(dev()), accumulate=True,
+                                       bias_grad=bg)])
+    Af, Bf = A.float().cpu()[:, a0:a0 + M], Bm.float().cpu()[:, b0:b0 + N]
+    want = C0 + Af.t() @ Bf
+    tol = 3e-5 * float(want.abs().max()) * max(1.0, (K / 1600) ** 0.5)
+    assert float((out.cpu() - want).abs().max()) < tol, (M, N, K)
+    assert float((bg.cpu() - Af.sum(0)).abs().max()) < 3e-5 * float(Af.sum(0).abs().max()) * max(1.0, (K / 1600) ** 0.5)
+
+
 def test_gemm_bf16_gate_interleave():
     """The gate-minor layout end to end at GEMM level: W_ih rows interleaved by the conversion, bias read through the
     interleave (forward); dW rows and bias gradients written back through it (backward)."""
