@@ -339,8 +339,11 @@ __device__ __forceinline__ void gemm_bf16_tile(const mmda_gemm_bf16_args& g, int
 
 // One kernel per tile size: the 64 x 64 form needs half the registers and LDS of the 128 x 128 one, and the long-K gradient
 // GEMMs that use it are bound by per-k-tile latency -- more resident workgroups per CU is what hides it.
+// TN = false: nt problems only.  TN = true: either form per problem (a launch that holds tn problems runs every problem on this
+// instance, so that input-gradient and weight-gradient GEMMs of a layer still go out together); held to the register budget of four
+// workgroups per CU like the nt instance.
 template <int T, bool TN>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(Bf16Group G) {
+__global__ __launch_bounds__(256, T == 64 ? 4 : 2) void gemm_bf16_kernel(Bf16Group G) {
   __shared__ __attribute__((aligned(16))) unsigned short AB[TN ? LdsElems<T>::tn : LdsElems<T>::nt];   // two buffers of (A block | B block); the C tile is staged over the first
   int pi = 0;
 #pragma unroll
@@ -350,7 +353,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(Bf16Group G) {
   const int splitk = G.splitk[pi];
   const int local = blockIdx.x - G.start[pi];
   const int bx = local % G.tx[pi], by = (local / G.tx[pi]) % G.ty[pi], sp = local / (G.tx[pi] * G.ty[pi]);
-  gemm_bf16_tile<T, TN>(g, splitk, bx, by, sp, AB);      // (a launch holds problems of one form: the tn form costs the 64-tile kernel 18 registers, i.e. a workgroup per CU)
+  if (TN && g.tn) gemm_bf16_tile<T, true>(g, splitk, bx, by, sp, AB);      // block-uniform
+  else gemm_bf16_tile<T, false>(g, splitk, bx, by, sp, AB);
 }
 
 __global__ __launch_bounds__(256) void convert_kernel(ConvLaunch L) {
@@ -384,8 +388,10 @@ extern "C" int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, vo
     const int Ne = a.N + (a.bias_grad ? 1 : 0);
     return ceil_div(Ne, 128) * ceil_div(a.M, 128) >= t128_min ? 128 : 64;
   };
-  for (int form = 0; form < 2; ++form)
   for (int T = 64; T <= 128; T += 64) {
+    bool any_tn = false;
+    for (int i = 0; i < n; ++i) any_tn = any_tn || (args[i].tn && args[i].M > 0 && args[i].N > 0 && tile_of(args[i]) == T);
+    const int form = any_tn ? 1 : 0;
     Bf16Group G;
     G.n = 0;
     int blocks = 0;
@@ -410,7 +416,7 @@ extern "C" int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, vo
     int64_t all_tiles = 0;
     for (int i = 0; i < n; ++i) {
       const mmda_gemm_bf16_args& a = args[i];
-      if (a.M == 0 || a.N == 0 || tile_of(a) != T || (a.tn ? 1 : 0) != form) continue;
+      if (a.M == 0 || a.N == 0 || tile_of(a) != T) continue;
       order.push_back(i);
       all_tiles += (int64_t)ceil_div(a.N + (a.bias_grad ? 1 : 0), T) * ceil_div(a.M, T);
     }

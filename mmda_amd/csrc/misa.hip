@@ -22,6 +22,7 @@ struct Rnn {           // one bidirectional LSTM layer
   int64_t xb, xbT;                           // layer input (R, ldD) and its transpose (D, ldR)
   int64_t dgb, dgbT;                         // gate gradients (R, ldG) and transpose (8H, ldR)
   int64_t hbT;                               // hseq^T (2H, ldR)
+  int64_t hbp[2]; int ldH;                   // tn weight-gradient GEMMs: hseq of one direction as bf16 (R, ldH), ldH = round_up(H, 8)
   int ldD, ldG;
   // GRU (cfg.rnncell): workspace offsets of the parameters / gradients in the four-slot layout (mmda_gru_pad_job); -1 for LSTM
   int64_t pw_ih = -1, pw_hh[2] = {-1, -1}, pb_ih = -1, pb_hh = -1, gw_ih = -1, gw_hh[2] = {-1, -1}, gb = -1;
@@ -73,6 +74,7 @@ struct mmda_misa {
   // fused train step without a gradient exchange: clamp+Adam of the bucket prefix whose gradients are final beside the layer-1 backward
   // recurrence runs there, on the side stream (set by mmda_misa_train_step around its backward pass)
   int adam_early_on = 0; float ae_lr = 0.f, ae_clip = 0.f; int ae_step = 0; int64_t adam_early_done = 0;
+  int tn_wgrad = 0;                // this step's weight-gradient GEMMs read dG / inputs / hseq as they lie (tn form): no transposed copies
   int embed_early_done = 0;        // this step's early optimizer pass also covered the embedding rows the batch does not touch
   int wT_pending = 0;              // the K-major fusion-weight copies of this step are still to be made (on the next fork)
   int fusion_fp8 = 0;
@@ -238,6 +240,8 @@ int64_t layout(mmda_misa* m, int B, int T, bool commit) {
       r.xb = k.take(R * r.ldD / 2); r.xbT = k.take((int64_t)r.D * ldR / 2);
       r.dgb = k.take(R * r.ldG / 2); r.dgbT = k.take((int64_t)8 * r.H * ldR / 2);
       r.hbT = k.take((int64_t)2 * r.H * ldR / 2);
+      r.ldH = round_up(r.H, 8);
+      for (int d = 0; d < 2; ++d) r.hbp[d] = k.take(R * r.ldH / 2);
     }
     if (c.rnncell == MMDA_CELL_GRU) {
       for (int l = 0; l < 2; ++l) {
@@ -650,13 +654,19 @@ int eager_side_losses(mmda_misa* m, void* stream, bool hseq2_t) {
   void* ss = nullptr;
   int rc = side_fork(m, stream, &ss);
   if (!rc && m->wT_pending) rc = weight_transposes(m, ss);
-  if (!rc && hseq2_t) {            // hseq^T of layer 2 for its dW_hh (every fork puts a marker packet on the main stream: one for both)
-    mmda_convert_job cj[3];
+  if (!rc && hseq2_t) {            // hseq of layer 2 as bf16 for its dW_hh (every fork puts a marker packet on the main stream: one for both)
+    mmda_convert_job cj[6];
+    int nj = 0;
     for (int i = 0; i < 3; ++i) {
-      Mod& md = m->mod[i];
-      cj[i] = mmda_convert_job{WS(md.hseq[1]), 2 * md.H, m->B * m->T, 2 * md.H, nullptr, nullptr, 0, WS(md.rnn[1].hbT), m->ldR};
+      Mod& md = m->mod[i]; Rnn& r = md.rnn[1];
+      if (m->tn_wgrad) {
+        for (int d = 0; d < 2; ++d)
+          cj[nj++] = mmda_convert_job{WS(md.hseq[1]) + d * md.H, 2 * md.H, m->B * m->T, md.H, nullptr, WS(r.hbp[d]), r.ldH, nullptr, 0};
+      } else {
+        cj[nj++] = mmda_convert_job{WS(md.hseq[1]), 2 * md.H, m->B * m->T, 2 * md.H, nullptr, nullptr, 0, WS(r.hbT), m->ldR};
+      }
     }
-    rc = mmda_convert_bf16(cj, 3, ss);
+    rc = mmda_convert_bf16(cj, nj, ss);
   }
   if (!rc) rc = mmda_misa_zero_act_grads(m, ss);
   float* L = WS(m->losses);
@@ -739,6 +749,7 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
       probe[i].xchg = (m->use_cluster && md.xchg >= 0) ? (void*)WS(md.xchg) : nullptr; probe[i].gate_minor = gate_minor;
       probe[i].cell = c.rnncell;
     }
+    if (backward == 2) return mmda_lstm_bwd_emits_dg_bf16(mode, 3, probe, B, T) != 0;      // ... and writes the gate gradients as bf16
     return mmda_lstm_resident_applicable(mode, 3, probe, B, T, backward) != 0;
   };
   // bf16 mode: the input GEMMs read bf16 operand copies (K-major, 16-B rows): W_ih of both layers (plain for the forward,
@@ -762,6 +773,30 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
   // than the smaller main-stream conversions save, so this stays an ablation switch, off by default)
   static const int late_t_on = getenv("MMDA_LATE_T") ? atoi(getenv("MMDA_LATE_T")) : 0;
   const bool late_t = bfg && m->use_side && !inf && late_t_on;
+  // Weight gradients in the tn form of the bf16 GEMM (dW = dG^T X on row-major dG, X, hseq): the transposed copies of the inputs, of
+  // hseq and of the gate gradients are not made at all (B=256: 0.33 ms of conversions per step).  Needs the gate gradients as bf16
+  // from the recurrent kernel (gate-minor resident path).  Up to T*B = 4096 rows: measured (step, ms) B=32 0.759 -> 0.745, B=64 0.928 ->
+  // 0.917, but B=128 1.362 -> 1.391, B=256 2.39 -> 2.55, T=500 4.06 -> 4.08 -- in isolation the tn kernel matches the nt one at K = 1600
+  // and runs 15 - 20 % slower at K = 12800 (twice the LDS read instructions per k-tile), which at large batches outweighs the
+  // conversions it saves.  MMDA_GEMM_TN=0: the transposed-copy (nt) form everywhere; MMDA_GEMM_TN_MAX_ROWS moves the limit.
+  static const int tn_on = getenv("MMDA_GEMM_TN") ? atoi(getenv("MMDA_GEMM_TN")) : 1;
+  static const int tn_max_rows = getenv("MMDA_GEMM_TN_MAX_ROWS") ? atoi(getenv("MMDA_GEMM_TN_MAX_ROWS")) : 4096;
+  const bool tnw = bfg && gm && tn_on && !late_t && (B % 8) == 0 && R <= tn_max_rows && probe_resident(1, 2);
+  m->tn_wgrad = (tnw && !inf) ? 1 : 0;
+  // hseq of layer l as bf16 for its dW_hh: one (R, ldH) copy per direction (tn) or the transpose (nt); returns the number of jobs
+  auto hseq_jobs = [&](int l, mmda_convert_job* cj) -> int {
+    int n = 0;
+    for (int i = 0; i < 3; ++i) {
+      Mod& md = m->mod[i]; Rnn& r = md.rnn[l];
+      if (tnw) {
+        for (int d = 0; d < 2; ++d)
+          cj[n++] = mmda_convert_job{WS(md.hseq[l]) + d * md.H, 2 * md.H, R, md.H, nullptr, WS(r.hbp[d]), r.ldH, nullptr, 0};
+      } else {
+        cj[n++] = mmda_convert_job{WS(md.hseq[l]), 2 * md.H, R, 2 * md.H, nullptr, nullptr, 0, WS(r.hbT), ldR};
+      }
+    }
+    return n;
+  };
   auto first_jobs = [&](bool plain, bool transposed, mmda_convert_job* cj) -> int {
     int n = 0;
     for (int i = 0; i < 3; ++i) {
@@ -772,8 +807,10 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
       }
       Rnn& r0 = m->mod[i].rnn[0];
       const float* src = i == 0 ? PP(m->embed) : xin[i];
-      cj[n++] = mmda_convert_job{src, r0.D, R, r0.D, i == 0 ? t_ids : nullptr, plain ? WS(r0.xb) : nullptr, plain ? r0.ldD : 0,
-                                 transposed ? WS(r0.xbT) : nullptr, transposed ? ldR : 0};
+      const bool xt = transposed && !tnw;
+      if (plain || xt)
+        cj[n++] = mmda_convert_job{src, r0.D, R, r0.D, i == 0 ? t_ids : nullptr, plain ? WS(r0.xb) : nullptr, plain ? r0.ldD : 0,
+                                   xt ? WS(r0.xbT) : nullptr, xt ? ldR : 0};
     }
     return n;
   };
@@ -895,14 +932,15 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
       x.rc = mmda_layernorm_fwd_multi(ln, 3, stream);
       if (bfg && !x.rc) {
         // layer-2 inputs (plain for its forward GEMM, transposed for its dW_ih) and hseq^T of layer 1 (for its dW_hh)
-        mmda_convert_job cj[6];
+        mmda_convert_job cj[9];
+        int nj = 0;
         for (int i = 0; i < 3; ++i) {
-          Mod& md = m->mod[i]; Rnn& r1 = md.rnn[1]; Rnn& r0 = md.rnn[0];
-          const bool tr = !inf && !late_t;
-          cj[i] = mmda_convert_job{WS(md.normed), 2 * md.H, R, 2 * md.H, nullptr, WS(r1.xb), r1.ldD, tr ? WS(r1.xbT) : nullptr, tr ? ldR : 0};
-          cj[3 + i] = mmda_convert_job{WS(md.hseq[0]), 2 * md.H, R, 2 * md.H, nullptr, nullptr, 0, WS(r0.hbT), ldR};
+          Mod& md = m->mod[i]; Rnn& r1 = md.rnn[1];
+          const bool tr = !inf && !late_t && !tnw;
+          cj[nj++] = mmda_convert_job{WS(md.normed), 2 * md.H, R, 2 * md.H, nullptr, WS(r1.xb), r1.ldD, tr ? WS(r1.xbT) : nullptr, tr ? ldR : 0};
         }
-        x.rc = mmda_convert_bf16(cj, (inf || late_t) ? 3 : 6, stream);
+        if (!(inf || late_t)) nj += hseq_jobs(0, cj + nj);
+        x.rc = mmda_convert_bf16(cj, nj, stream);
       }
     } else if (!x.rc && !m->eager_losses && ((bfg && !inf) || m->zero_grad_pending || m->wT_pending)) {
       // side stream, beside the fusion block: the gradient bucket is cleared (train_step) and hseq^T of layer 2 is made for its
@@ -912,12 +950,9 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
       if (!x.rc && m->wT_pending) x.rc = weight_transposes(m, ss);
       if (!x.rc && m->zero_grad_pending && !m->eager_losses) { x.rc = mmda_misa_zero_grad(m, ss); m->zero_grad_pending = 0; }
       if (bfg && !inf && !x.rc) {
-        mmda_convert_job cj[3];
-        for (int i = 0; i < 3; ++i) {
-          Mod& md = m->mod[i];
-          cj[i] = mmda_convert_job{WS(md.hseq[1]), 2 * md.H, R, 2 * md.H, nullptr, nullptr, 0, WS(md.rnn[1].hbT), ldR};
-        }
-        x.rc = mmda_convert_bf16(cj, 3, ss);
+        mmda_convert_job cj[6];
+        const int nj = hseq_jobs(1, cj);
+        x.rc = mmda_convert_bf16(cj, nj, ss);
       }
     }
   }
@@ -1452,8 +1487,10 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
                                 m->ldR};
       if (kdg) { dgj[i].src = WS(r.dgb); dgj[i].ld = r.ldG; dgj[i].src_bf16 = 1; }
     }
-    const bool dg_on_side = bfg && kdg && l == 1 && dw_overlap && m->use_side;
-    if (bfg && !dg_on_side) {
+    const bool tn = bfg && m->tn_wgrad != 0;           // weight gradients straight from dG / inputs / hseq as they lie (no dG^T)
+    if (tn && !kdg) return MMDA_EINVAL;                // (forward() set tn_wgrad only where the recurrent kernel writes bf16 dG)
+    const bool dg_on_side = bfg && kdg && l == 1 && dw_overlap && m->use_side && !tn;
+    if (bfg && !dg_on_side && !tn) {
       x.rc = mmda_convert_bf16(dgj, 3, stream);
       if (x.rc) return x.rc;
     }
@@ -1472,6 +1509,7 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
         mmda_gemm_bf16_args g = {};
         g.M = G8; g.N = r.D; g.K = R; g.A = dgT; g.lda = m->ldR; g.B = WS(r.xbT); g.ldb = m->ldR; g.C = gW_ih(m, r); g.ldc = r.D;
         g.accumulate = 1; g.bias_grad = gB_ih(m, r); g.bias_grad2 = gB_hh(m, r); g.perm_m_H = m->gate_minor ? H : 0;
+        if (tn) { g.tn = 1; g.A = WS(r.dgb); g.lda = r.ldG; g.B = WS(r.xb); g.ldb = r.ldD; }
         wq.push_back(g);
       } else {
         mmda_gemm_args e = {};
@@ -1484,10 +1522,23 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
           mmda_gemm_bf16_args g = {};
           g.M = 4 * H; g.N = H; g.K = (T - 1) * B; g.lda = m->ldR; g.ldb = m->ldR; g.ldc = H; g.accumulate = 1;
           g.perm_m_H = m->gate_minor ? H : 0;
+          if (tn) {
+            // rows of dG / hseq are (t, b): the forward direction pairs rows t B + b of dG with rows (t - 1) B + b of h, the reverse
+            // direction rows t B + b with rows (t + 1) B + b
+            const unsigned short* dg = reinterpret_cast<const unsigned short*>(WS(r.dgb));
+            const unsigned short* h0 = reinterpret_cast<const unsigned short*>(WS(r.hbp[0]));
+            const unsigned short* h1 = reinterpret_cast<const unsigned short*>(WS(r.hbp[1]));
+            g.tn = 1; g.lda = r.ldG; g.ldb = r.ldH;
+            g.A = dg + (int64_t)B * r.ldG; g.B = h0; g.C = gW_hh(m, r, 0);
+            wq.push_back(g);
+            g.A = dg + 4 * H; g.B = h1 + (int64_t)B * r.ldH; g.C = gW_hh(m, r, 1);
+            wq.push_back(g);
+          } else {
           g.A = dgT + B; g.B = hT; g.C = gW_hh(m, r, 0);
           wq.push_back(g);
           g.A = dgT + (int64_t)4 * H * m->ldR; g.B = hT + (int64_t)H * m->ldR + B; g.C = gW_hh(m, r, 1);
           wq.push_back(g);
+          }
         } else {
           const float* hs_ = WS(md.hseq[l]);
           gemm(x, mode, 1, 0, 4 * H, H, (T - 1) * B, dG + (int64_t)B * G8, G8, hs_, 2 * H, gW_hh(m, r, 0), H, nullptr, nullptr, 1);
