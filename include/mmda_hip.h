@@ -214,6 +214,8 @@ typedef struct mmda_ln_args {
   int permute_S, permute_B;                     /* 0,0 = no permutation */
   float eps;
   mmda_act_params actp;                         /* act = MMDA_ACT_PRELU / MMDA_ACT_RRELU only */
+  void* y_bf16; int ld_bf16;                    /* optional second output: y as bf16 (rows, ld_bf16), columns n..ld_bf16-1 zero -- the
+                                                 * K-major operand copy the next layer's input GEMM reads (no conversion launch between) */
 } mmda_ln_args;
 int mmda_layernorm_fwd(const mmda_ln_args* a, void* stream);
 /* backward: dx_pre = LN'(dy); outputs: d_x = dx_pre * act'(x) (written or accumulated), d_res = dx_pre*dropmask,

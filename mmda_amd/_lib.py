@@ -69,7 +69,8 @@ class LnArgs(C.Structure):
     _fields_ = [("rows", C.c_int), ("n", C.c_int), ("x", C.c_void_p), ("res", C.c_void_p), ("gamma", C.c_void_p),
                 ("beta", C.c_void_p), ("y", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("act", C.c_int),
                 ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_site", C.c_int),
-                ("permute_S", C.c_int), ("permute_B", C.c_int), ("eps", C.c_float), ("actp", ActParams)]
+                ("permute_S", C.c_int), ("permute_B", C.c_int), ("eps", C.c_float), ("actp", ActParams),
+                ("y_bf16", C.c_void_p), ("ld_bf16", C.c_int)]
 
 
 class LnBwdArgs(C.Structure):

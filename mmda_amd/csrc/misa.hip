@@ -644,6 +644,27 @@ int weight_transposes(mmda_misa* m, void* ss) {
   return rc;
 }
 
+// bf16 operand copies that only the backward pass reads -- hseq of both layers (per direction for the tn weight-gradient GEMMs,
+// transposed for the nt ones) and, nt only, the transposed layer-2 inputs: made on the side stream beside the fusion block.  <= 15 jobs.
+int backward_only_jobs(mmda_misa* m, mmda_convert_job* cj) {
+  const int R = m->B * m->T;
+  int n = 0;
+  for (int i = 0; i < 3; ++i) {
+    Mod& md = m->mod[i];
+    for (int l = 0; l < 2; ++l) {
+      Rnn& r = md.rnn[l];
+      if (m->tn_wgrad) {
+        for (int d = 0; d < 2; ++d)
+          cj[n++] = mmda_convert_job{WS(md.hseq[l]) + d * md.H, 2 * md.H, R, md.H, nullptr, WS(r.hbp[d]), r.ldH, nullptr, 0};
+      } else {
+        cj[n++] = mmda_convert_job{WS(md.hseq[l]), 2 * md.H, R, 2 * md.H, nullptr, nullptr, 0, WS(r.hbT), m->ldR};
+      }
+    }
+    if (!m->tn_wgrad) cj[n++] = mmda_convert_job{WS(md.normed), 2 * md.H, R, 2 * md.H, nullptr, nullptr, 0, WS(md.rnn[1].xbT), m->ldR};
+  }
+  return n;
+}
+
 // side stream, right after x6 = [private x3, shared x3] exists: clear the loss sums and the loss-seeded activation gradients,
 // then DiffLoss and CMD with their gradients (they read x6 only), then the gradient bucket if train_step left that to forward()
 int eager_side_losses(mmda_misa* m, void* stream, bool hseq2_t) {
@@ -654,18 +675,9 @@ int eager_side_losses(mmda_misa* m, void* stream, bool hseq2_t) {
   void* ss = nullptr;
   int rc = side_fork(m, stream, &ss);
   if (!rc && m->wT_pending) rc = weight_transposes(m, ss);
-  if (!rc && hseq2_t) {            // hseq of layer 2 as bf16 for its dW_hh (every fork puts a marker packet on the main stream: one for both)
-    mmda_convert_job cj[6];
-    int nj = 0;
-    for (int i = 0; i < 3; ++i) {
-      Mod& md = m->mod[i]; Rnn& r = md.rnn[1];
-      if (m->tn_wgrad) {
-        for (int d = 0; d < 2; ++d)
-          cj[nj++] = mmda_convert_job{WS(md.hseq[1]) + d * md.H, 2 * md.H, m->B * m->T, md.H, nullptr, WS(r.hbp[d]), r.ldH, nullptr, 0};
-      } else {
-        cj[nj++] = mmda_convert_job{WS(md.hseq[1]), 2 * md.H, m->B * m->T, 2 * md.H, nullptr, nullptr, 0, WS(r.hbT), m->ldR};
-      }
-    }
+  if (!rc && hseq2_t) {            // the backward pass's operand copies (every fork puts a marker packet on the main stream: one for all)
+    mmda_convert_job cj[16];
+    const int nj = backward_only_jobs(m, cj);
     rc = mmda_convert_bf16(cj, nj, ss);
   }
   if (!rc) rc = mmda_misa_zero_act_grads(m, ss);
@@ -783,20 +795,6 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
   static const int tn_max_rows = getenv("MMDA_GEMM_TN_MAX_ROWS") ? atoi(getenv("MMDA_GEMM_TN_MAX_ROWS")) : 4096;
   const bool tnw = bfg && gm && tn_on && !late_t && (B % 8) == 0 && R <= tn_max_rows && probe_resident(1, 2);
   m->tn_wgrad = (tnw && !inf) ? 1 : 0;
-  // hseq of layer l as bf16 for its dW_hh: one (R, ldH) copy per direction (tn) or the transpose (nt); returns the number of jobs
-  auto hseq_jobs = [&](int l, mmda_convert_job* cj) -> int {
-    int n = 0;
-    for (int i = 0; i < 3; ++i) {
-      Mod& md = m->mod[i]; Rnn& r = md.rnn[l];
-      if (tnw) {
-        for (int d = 0; d < 2; ++d)
-          cj[n++] = mmda_convert_job{WS(md.hseq[l]) + d * md.H, 2 * md.H, R, md.H, nullptr, WS(r.hbp[d]), r.ldH, nullptr, 0};
-      } else {
-        cj[n++] = mmda_convert_job{WS(md.hseq[l]), 2 * md.H, R, 2 * md.H, nullptr, nullptr, 0, WS(r.hbT), ldR};
-      }
-    }
-    return n;
-  };
   auto first_jobs = [&](bool plain, bool transposed, mmda_convert_job* cj) -> int {
     int n = 0;
     for (int i = 0; i < 3; ++i) {
@@ -929,19 +927,11 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
         ln[i].rows = R; ln[i].n = 2 * md.H; ln[i].x = WS(md.hseq[0]); ln[i].gamma = PP(md.ln_w); ln[i].beta = PP(md.ln_b);
         ln[i].y = WS(md.normed); ln[i].mean = WS(md.ln_mean); ln[i].rstd = WS(md.ln_rstd); ln[i].eps = 1e-5f;
       }
+      // (bf16 GEMMs: the LayerNorm also writes its output as the bf16 operand copy layer 2's input GEMM reads; the copies that only
+      //  the backward pass needs -- hseq, transposed inputs -- are made later on the side stream: backward_only_jobs)
+      if (bfg)
+        for (int i = 0; i < 3; ++i) { ln[i].y_bf16 = WS(m->mod[i].rnn[1].xb); ln[i].ld_bf16 = m->mod[i].rnn[1].ldD; }
       x.rc = mmda_layernorm_fwd_multi(ln, 3, stream);
-      if (bfg && !x.rc) {
-        // layer-2 inputs (plain for its forward GEMM, transposed for its dW_ih) and hseq^T of layer 1 (for its dW_hh)
-        mmda_convert_job cj[9];
-        int nj = 0;
-        for (int i = 0; i < 3; ++i) {
-          Mod& md = m->mod[i]; Rnn& r1 = md.rnn[1];
-          const bool tr = !inf && !late_t && !tnw;
-          cj[nj++] = mmda_convert_job{WS(md.normed), 2 * md.H, R, 2 * md.H, nullptr, WS(r1.xb), r1.ldD, tr ? WS(r1.xbT) : nullptr, tr ? ldR : 0};
-        }
-        if (!(inf || late_t)) nj += hseq_jobs(0, cj + nj);
-        x.rc = mmda_convert_bf16(cj, nj, stream);
-      }
     } else if (!x.rc && !m->eager_losses && ((bfg && !inf) || m->zero_grad_pending || m->wT_pending)) {
       // side stream, beside the fusion block: the gradient bucket is cleared (train_step) and hseq^T of layer 2 is made for its
       // dW_hh.  Joined at the end of forward(), so everything the backward pass issues on either stream is ordered behind both.
@@ -949,9 +939,9 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
       x.rc = side_fork(m, stream, &ss);
       if (!x.rc && m->wT_pending) x.rc = weight_transposes(m, ss);
       if (!x.rc && m->zero_grad_pending && !m->eager_losses) { x.rc = mmda_misa_zero_grad(m, ss); m->zero_grad_pending = 0; }
-      if (bfg && !inf && !x.rc) {
-        mmda_convert_job cj[6];
-        const int nj = hseq_jobs(1, cj);
+      if (bfg && !inf && !late_t && !x.rc) {
+        mmda_convert_job cj[16];
+        const int nj = backward_only_jobs(m, cj);
         x.rc = mmda_convert_bf16(cj, nj, ss);
       }
     }

@@ -56,7 +56,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnMulti L) {
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     int i = lane + 64 * q;
-    if (i < n) a.y[orow * n + i] = (v[q] - mean) * rstd * a.gamma[i] + a.beta[i];
+    float y = 0.f;
+    if (i < n) { y = (v[q] - mean) * rstd * a.gamma[i] + a.beta[i]; a.y[orow * n + i] = y; }
+    if (a.y_bf16 && i < a.ld_bf16) reinterpret_cast<unsigned short*>(a.y_bf16)[orow * a.ld_bf16 + i] = f2bf(y);      // (zero in the padding)
   }
 }
 
