@@ -1419,7 +1419,7 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
     // and the step ends up 14 us LONGER (0.769 -> 0.783 ms); behind the early optimizer pass beside the layer-1 recurrence instead, the
     // side stream becomes the longer of the two and the join waits (0.766 -> 0.834 ms).
     static const int embed_split = getenv("MMDA_ADAM_EMBED_SPLIT") ? atoi(getenv("MMDA_ADAM_EMBED_SPLIT")) : 0;
-    if (!x.rc && m->adam_early_on && embed_split && m->use_side && m->M1 && m->V1 && m->embed + (int64_t)c.vocab * c.d_t == m->flat) {
+    if (!x.rc && m->adam_early_on && embed_split == 1 && m->use_side && m->M1 && m->V1 && m->embed + (int64_t)c.vocab * c.d_t == m->flat) {
       unsigned char* mask = reinterpret_cast<unsigned char*>(WS(m->touched));
       x.rc = mmda_mark_rows(mask, c.vocab, t_ids, R, ss);
       if (!x.rc) x.rc = mmda_clamp_adam_rows(PP(m->embed), GG(m->embed), m->M1 + m->embed, m->V1 + m->embed, c.vocab, c.d_t, mask, 0,
@@ -1589,6 +1589,15 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
         if (!x.rc && m->adam_early_on && m->early_floats > 0 && m->M1 && m->V1) {
           x.rc = mmda_clamp_adam(m->P, m->G, m->M1, m->V1, m->early_floats, m->ae_lr, 0.9f, 0.999f, 1e-8f, m->ae_clip, 1.0f, m->ae_step, ss);
           if (!x.rc) m->adam_early_done = m->early_floats;
+          // (MMDA_ADAM_EMBED_SPLIT=2: the untouched embedding rows behind it, i.e. beside the tail GEMMs rather than a recurrence)
+          static const int embed_split2 = getenv("MMDA_ADAM_EMBED_SPLIT") ? atoi(getenv("MMDA_ADAM_EMBED_SPLIT")) : 0;
+          if (!x.rc && embed_split2 == 2 && m->use_side && m->embed + (int64_t)c.vocab * c.d_t == m->flat) {
+            unsigned char* mask = reinterpret_cast<unsigned char*>(WS(m->touched));
+            x.rc = mmda_mark_rows(mask, c.vocab, t_ids, R, ss);
+            if (!x.rc) x.rc = mmda_clamp_adam_rows(PP(m->embed), GG(m->embed), m->M1 + m->embed, m->V1 + m->embed, c.vocab, c.d_t, mask, 0,
+                                                   m->ae_lr, 0.9f, 0.999f, 1e-8f, m->ae_clip, 1.0f, m->ae_step, ss);
+            if (!x.rc) m->embed_early_done = 1;
+          }
         }
       }
     } else if (!x.rc) {
