@@ -1363,6 +1363,15 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
 // waves together have seen every tile's four flags for step s+1, hence after every reader of the step-s image has finished with it.
 // A wave whose poll times out raises the abort word and from then on stops waiting (its results are garbage, the host discards the
 // launch) but keeps arriving at the barriers, so the grid always drains.
+// Steady-state data polling: PSETS copies of a wave's three loads in flight, PGAP x 64 cycles between their first issues (one copy:
+// before the first).  Measured at B=32 (step, ms): one copy 0.740 (0 / 256 / 512 cycles of first delay: equal, 1024: 0.763), two copies
+// issued back to back 0.738, two spaced by 512 / 1024 cycles 0.92 / 0.90, three 1.03, four 1.15 -- every read in flight sits in the
+// consumer CU's memory queue in front of the one that will return the data, so polling harder makes the hand-off slower.
+#ifndef MMDA_PSETS
+#define MMDA_PSETS 1
+#define MMDA_PGAP 0
+#endif
+constexpr int PSETS = MMDA_PSETS, PGAP = MMDA_PGAP;
 constexpr int QUAD_LDS = 2 * 4 * 16 * 16 * 4 * 4;      // bytes: parity x source wave x 16 rows x 16 units x 4 gates, fp32
 
 __device__ __forceinline__ bool flags4_reached(u32x4 f, unsigned need) {
@@ -1516,36 +1525,44 @@ __global__ __launch_bounds__(256, 4) void lstm_fwd_quad_kernel(CLaunch L) {   //
 #pragma unroll
         for (int j = 0; j < 3; ++j) fa[j] = ld16_sc1(xr, par + foff[j]);
       } else {                                           // steady state: the fragments themselves say when they are there
-        u32x4 fb[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) fa[j] = ld16_sc1(xr, par + foff[j]);
-        __builtin_amdgcn_s_sleep(2);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) fb[j] = ld16_sc1(xr, par + foff[j]);
+        // (PSETS copies of the three loads in flight: see the note at PSETS -- one is best)
+        u32x4 fs[PSETS][3];
         auto stale = [&](const u32x4 (&f)[3]) {          // some element of a fragment this lane needs still carries the other tag
           unsigned t = 0;
 #pragma unroll
           for (int j = 0; j < 3; ++j) t |= (((f[j][0] ^ tm) | (f[j][1] ^ tm)) | ((f[j][2] ^ tm) | (f[j][3] ^ tm))) & chk[j];
           return t != 0;
         };
-        if (!dead) {
-          for (unsigned spins = 0;; spins += 2) {
-            if (!__any(stale(fa))) break;
+        if (PSETS == 1 && PGAP > 0) __builtin_amdgcn_s_sleep(PGAP);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) fa[j] = ld16_sc1(xr, par + foff[j]);
-            if (!__any(stale(fb))) {
+        for (int q = 0; q < PSETS; ++q) {
 #pragma unroll
-              for (int j = 0; j < 3; ++j) fa[j] = fb[j];
-              break;
-            }
+          for (int j = 0; j < 3; ++j) fs[q][j] = ld16_sc1(xr, par + foff[j]);
+          if (q + 1 < PSETS) __builtin_amdgcn_s_sleep(PGAP);
+        }
+        bool got = dead;
+        for (unsigned spins = 0; !got; spins += PSETS) {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) fb[j] = ld16_sc1(xr, par + foff[j]);
-            if (spins > SPIN_LIMIT || ((spins & 255u) == 0 && spins && ld_flag(abort_w) != 0)) {
-              dead = true;
-              if (lane == 0) st_flag(abort_w, 1u);
-              break;
+          for (int q = 0; q < PSETS; ++q) {
+            if (!got) {
+              if (!__any(stale(fs[q]))) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) fa[j] = fs[q][j];
+                got = true;
+              } else {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) fs[q][j] = ld16_sc1(xr, par + foff[j]);
+              }
             }
           }
+          if (!got && (spins > SPIN_LIMIT || ((spins & 255u) == 0 && spins && ld_flag(abort_w) != 0))) {
+            dead = true; got = true;
+            if (lane == 0) st_flag(abort_w, 1u);
+          }
+        }
+        if (dead) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) fa[j] = fs[0][j];
         }
       }
       bf16x8 af[3];
@@ -1822,36 +1839,43 @@ __global__ __launch_bounds__(256, 4) void lstm_bwd_quad_kernel(CLaunch L) {   //
 #pragma unroll
         for (int l = 0; l < 3; ++l) fa[l] = ld16_sc1(xr, par + goff[l]);
       } else {
-        u32x4 fb[3];
-#pragma unroll
-        for (int l = 0; l < 3; ++l) fa[l] = ld16_sc1(xr, par + goff[l]);
-        __builtin_amdgcn_s_sleep(2);
-#pragma unroll
-        for (int l = 0; l < 3; ++l) fb[l] = ld16_sc1(xr, par + goff[l]);
+        u32x4 fs[PSETS][3];                              // (see the forward kernel)
         auto stale = [&](const u32x4 (&f)[3]) {
           unsigned t = 0;
 #pragma unroll
           for (int l = 0; l < 3; ++l) t |= (((f[l][0] ^ tm) | (f[l][1] ^ tm)) | ((f[l][2] ^ tm) | (f[l][3] ^ tm))) & chk[l];
           return t != 0;
         };
-        if (!dead) {
-          for (unsigned spins = 0;; spins += 2) {
-            if (!__any(stale(fa))) break;
+        if (PSETS == 1 && PGAP > 0) __builtin_amdgcn_s_sleep(PGAP);
 #pragma unroll
-            for (int l = 0; l < 3; ++l) fa[l] = ld16_sc1(xr, par + goff[l]);
-            if (!__any(stale(fb))) {
+        for (int q = 0; q < PSETS; ++q) {
 #pragma unroll
-              for (int l = 0; l < 3; ++l) fa[l] = fb[l];
-              break;
-            }
+          for (int l = 0; l < 3; ++l) fs[q][l] = ld16_sc1(xr, par + goff[l]);
+          if (q + 1 < PSETS) __builtin_amdgcn_s_sleep(PGAP);
+        }
+        bool got = dead;
+        for (unsigned spins = 0; !got; spins += PSETS) {
 #pragma unroll
-            for (int l = 0; l < 3; ++l) fb[l] = ld16_sc1(xr, par + goff[l]);
-            if (spins > SPIN_LIMIT || ((spins & 255u) == 0 && spins && ld_flag(abort_w) != 0)) {
-              dead = true;
-              if (lane == 0) st_flag(abort_w, 1u);
-              break;
+          for (int q = 0; q < PSETS; ++q) {
+            if (!got) {
+              if (!__any(stale(fs[q]))) {
+#pragma unroll
+                for (int l = 0; l < 3; ++l) fa[l] = fs[q][l];
+                got = true;
+              } else {
+#pragma unroll
+                for (int l = 0; l < 3; ++l) fs[q][l] = ld16_sc1(xr, par + goff[l]);
+              }
             }
           }
+          if (!got && (spins > SPIN_LIMIT || ((spins & 255u) == 0 && spins && ld_flag(abort_w) != 0))) {
+            dead = true; got = true;
+            if (lane == 0) st_flag(abort_w, 1u);
+          }
+        }
+        if (dead) {
+#pragma unroll
+          for (int l = 0; l < 3; ++l) fa[l] = fs[0][l];
         }
       }
       flush(step - 1);
