@@ -409,11 +409,33 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_cluster_kernel(CLaunch L) {
   }
 }
 
-// Pipelined flag poll of the wave-autonomous kernels: lane tau watches the flag of hidden tile tau.  A flag read is a ~1 us
-// round trip to memory; with one read in flight the wait is quantised to that round trip (half of it lost on average), so
-// four reads are kept in flight ~130 cycles apart and the oldest is examined each time round.  Returns false on timeout /
-// abort (bounded spin).
+// Flag poll of the wave-autonomous kernels: lane tau watches the flag of hidden tile tau.  One read in flight: round 1 kept four in
+// flight ~130 cycles apart to cut the quantisation of the wait, but every read in flight queues in the polling CU's memory pipeline in
+// front of the loads that fetch the data (measured below).  Returns false on timeout / abort (bounded spin).
+// (flag reads in flight per polling wave: B=256, all eight groups in one launch, step 2.375 ms with four, 2.354 with two, 2.338 with one)
+#ifndef MMDA_FLAGPOLL
+#define MMDA_FLAGPOLL 1
+#endif
 __device__ __forceinline__ bool poll_tiles(const unsigned char* poll_flag, const unsigned char* abort_w, bool watching, unsigned need) {
+  if (MMDA_FLAGPOLL == 1) {
+    for (unsigned spins = 0;; ++spins) {
+      const unsigned f = ld_flag(poll_flag);
+      if (__all(!watching || (int)(f - need) >= 0)) return true;
+      if (spins > SPIN_LIMIT || ((spins & 255u) == 0 && spins && ld_flag(abort_w) != 0)) return false;
+    }
+  }
+  if (MMDA_FLAGPOLL == 2) {
+    unsigned f0 = ld_flag(poll_flag);
+    __builtin_amdgcn_s_sleep(2);
+    unsigned f1 = ld_flag(poll_flag);
+    for (unsigned spins = 0;; spins += 2) {
+      if (__all(!watching || (int)(f0 - need) >= 0)) return true;
+      f0 = ld_flag(poll_flag);
+      if (__all(!watching || (int)(f1 - need) >= 0)) return true;
+      f1 = ld_flag(poll_flag);
+      if (spins > SPIN_LIMIT || ((spins & 255u) == 0 && spins && ld_flag(abort_w) != 0)) return false;
+    }
+  }
   unsigned f0 = ld_flag(poll_flag);
   __builtin_amdgcn_s_sleep(2);
   unsigned f1 = ld_flag(poll_flag);
