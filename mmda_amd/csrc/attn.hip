@@ -112,45 +112,7 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ 
 
 __global__ __launch_bounds__(64) void attn_fwd_hd64_kernel(const float* __restrict__ qkv, int B, float* ctx, float* probs, float p,
                                                            uint64_t seed, int site, int nhead) {
-  constexpr int S = S6K, hd = 64;
-  const int E = hd * nhead;
-  const int b = blockIdx.x / nhead, h = blockIdx.x % nhead, d = threadIdx.x;
-  float q[S], k[S], v[S];
-#pragma unroll
-  for (int s = 0; s < S; ++s) {
-    const float* row = qkv + ((int64_t)s * B + b) * 3 * E + h * hd + d;
-    q[s] = row[0]; k[s] = row[E]; v[s] = row[2 * E];
-  }
-  const float scale = 1.0f / sqrtf((float)hd);
-  float pr[S][S];
-#pragma unroll
-  for (int i = 0; i < S; ++i)
-#pragma unroll
-    for (int j = 0; j < S; ++j) pr[i][j] = wave_sum(q[i] * k[j]) * scale;
-#pragma unroll
-  for (int i = 0; i < S; ++i) {
-    float m = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < S; ++j) m = fmaxf(m, pr[i][j]);
-    float sum = 0.f;
-#pragma unroll
-    for (int j = 0; j < S; ++j) { pr[i][j] = expf(pr[i][j] - m); sum += pr[i][j]; }
-    const float inv = 1.0f / sum;
-#pragma unroll
-    for (int j = 0; j < S; ++j) {
-      const float pv = pr[i][j] * inv;
-      const int64_t pi = ((int64_t)blockIdx.x * S + i) * S + j;
-      if (d == 0) probs[pi] = pv;                                   // every lane holds the same value
-      pr[i][j] = pv * drop_mul(p, seed, site, (uint64_t)pi);
-    }
-  }
-#pragma unroll
-  for (int s = 0; s < S; ++s) {
-    float acc = 0.f;
-#pragma unroll
-    for (int j = 0; j < S; ++j) acc += pr[s][j] * v[j];
-    ctx[((int64_t)s * B + b) * E + h * hd + d] = acc;
-  }
+  attn_fwd_hd64_one(qkv, B, ctx, probs, p, seed, site, nhead, (int)blockIdx.x, (int)threadIdx.x);      // (rowlocal.h)
 }
 
 __global__ __launch_bounds__(64) void attn_bwd_hd64_kernel(const float* __restrict__ qkv, const float* __restrict__ probs,

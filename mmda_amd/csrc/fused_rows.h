@@ -36,6 +36,26 @@ struct FusedBwdA {
   unsigned long long* dbg;        // diagnostics: cycle counter at each stage boundary of workgroup 0 (NULL in production)
 };
 
+// forward stretch A: recon = (private + shared) W_rec^T + b and qkv = x6 W_in^T + b (both read x6 only) -> six-token attention ->
+//                    attn_out = ctx W_out^T + b -> x1 = LayerNorm 1 (x6 + dropout(attn_out))
+struct FusedFwdA {
+  int B, hs, nhead, nb;
+  const float* x6;                // (6, B, hs)
+  const float* rec_w; const float* rec_b; float* recon;           // 3 x (hs, hs) row-major [out][in], 3 x hs, (3, B, hs)
+  const float* in_w; const float* in_b; float* qkv;               // (3 hs, hs), 3 hs, (6 B, 3 hs)
+  float* ctx; float* probs; float p_tf; uint64_t seed; int site_attn;
+  const float* out_w; const float* out_b; float* attn_out;        // (hs, hs), hs, (6 B, hs)
+  mmda_ln_args ln1;               // rows = 6 B: x = x6, res = attn_out
+};
+// forward stretch C: hfused = LayerNorm 2 (x1 + dropout(f2)) permuted to (B, 6 hs) -> logits = hfused W_head^T + b -> heads
+struct FusedFwdC {
+  int B, hs, ncls, nb;
+  mmda_ln_args ln2;               // rows = 6 B, permute_S / permute_B set, y = hfused
+  const float* hfused; const float* head_w; const float* head_b; float* logits;      // (B, 6 hs), (6 + ncls, 6 hs), 6 + ncls, (B, 6 + ncls)
+  float threshold; float* tcp; float* scores; float* labels; float p_cls; uint64_t seed; int site_cls;
+};
+int mmda_fused_fwd_a(const FusedFwdA* a, void* stream);
+int mmda_fused_fwd_c(const FusedFwdC* a, void* stream);
 int mmda_fused_bwd_c(const FusedBwdC* a, void* stream);
 int mmda_fused_bwd_a(const FusedBwdA* a, void* stream);
 extern "C" int mmda_debug_set_fused_stamps(void* device_buffer);     // tools/ only (16 x u64)

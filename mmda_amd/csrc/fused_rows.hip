@@ -214,7 +214,135 @@ __global__ __launch_bounds__(FR_THREADS) void fused_bwd_a_kernel(FusedBwdA P) {
   stamp();
 }
 
+// ---------------------------------------------------------------------------------------------------------------- forward stretches
+// one round with the A row formed as the sum of two rows (private + shared)
+__device__ __forceinline__ void mac_load2(MacRound& R, const float* __restrict__ arow, const float* __restrict__ arow2,
+                                          const float* __restrict__ brow, int g) {
+  const f4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    R.a[c] = arow ? *reinterpret_cast<const f4*>(arow + 16 * c + 4 * g) + *reinterpret_cast<const f4*>(arow2 + 16 * c + 4 * g) : z;
+    R.b[c] = *reinterpret_cast<const f4*>(brow + 16 * c + 4 * g);
+  }
+}
+
+__global__ __launch_bounds__(FR_THREADS) void fused_fwd_a_kernel(FusedFwdA P) {
+  const int b0 = (int)blockIdx.x * P.nb;
+  const int nb = min(P.nb, P.B - b0);
+  const int B = P.B, hs = P.hs;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int ntok = S6K * nb, nmod = 3 * nb;
+  const bool rok = r16 < ntok;
+  const int tj = rok ? r16 / nb : 0, tb = rok ? r16 % nb : 0;
+  const int64_t trow = (int64_t)tj * B + b0 + tb;
+  const bool mok = r16 < nmod;
+  const int mi = mok ? r16 / nb : 0, mb = mok ? r16 % nb : 0;
+  const int col = wave * 16 + r16;
+  // ---- recon[i] = (x6[i] + x6[3 + i]) W_rec[i]^T + b_rec[i]: modality-row tile, three products into one accumulator
+  {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    MacRound R;
+#pragma unroll
+    for (int i3 = 0; i3 < 3; ++i3) {
+      const bool mine = mok && mi == i3;
+      mac_load2(R, mine ? P.x6 + ((int64_t)mi * B + b0 + mb) * hs : nullptr, P.x6 + ((int64_t)(3 + mi) * B + b0 + mb) * hs,
+                P.rec_w + (int64_t)i3 * hs * hs + (int64_t)col * hs, g);
+      mac_run(acc, R);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * g + i;
+      if (r < nmod) P.recon[((int64_t)(r / nb) * B + b0 + (r % nb)) * hs + col] = acc[i] + P.rec_b[(r / nb) * hs + col];
+    }
+  }
+  // ---- qkv = x6 W_in^T + b_in: token-row tile, 3 hs = 384 output columns = three passes of the eight waves
+#pragma unroll 1
+  for (int pass = 0; pass < 3; ++pass) {
+    const int n = pass * 128 + col;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* const ar[1] = {rok ? P.x6 + trow * hs : nullptr};
+    const float* const br[1] = {P.in_w + (int64_t)n * hs};
+    tile_mac_chain<1>(acc, ar, br, lane);
+    const float bias = P.in_b[n];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * g + i;
+      if (r < ntok) P.qkv[((int64_t)(r / nb) * B + b0 + (r % nb)) * 3 * hs + n] = acc[i] + bias;
+    }
+  }
+  stage_sync();
+  // ---- attention, one wave per (sample, head)
+  for (int pr = wave; pr < nb * P.nhead; pr += FR_THREADS / 64)
+    attn_fwd_hd64_one(P.qkv, B, P.ctx, P.probs, P.p_tf, P.seed, P.site_attn, P.nhead, (b0 + pr / P.nhead) * P.nhead + pr % P.nhead, lane);
+  stage_sync();
+  // ---- attn_out = ctx W_out^T + b_out
+  {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* const ar[1] = {rok ? P.ctx + trow * hs : nullptr};
+    const float* const br[1] = {P.out_w + (int64_t)col * hs};
+    tile_mac_chain<1>(acc, ar, br, lane);
+    const float bias = P.out_b[col];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * g + i;
+      if (r < ntok) P.attn_out[((int64_t)(r / nb) * B + b0 + (r % nb)) * hs + col] = acc[i] + bias;
+    }
+  }
+  stage_sync();
+  // ---- LayerNorm 1 over the token rows
+  for (int i = wave; i < ntok; i += FR_THREADS / 64) ln_fwd_row<2>(P.ln1, (i / nb) * B + b0 + (i % nb), lane);
+}
+
+__global__ __launch_bounds__(FR_THREADS) void fused_fwd_c_kernel(FusedFwdC P) {
+  const int b0 = (int)blockIdx.x * P.nb;
+  const int nb = min(P.nb, P.B - b0);
+  const int B = P.B, hs = P.hs, NC = 6 + P.ncls, W6 = 6 * hs;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // ---- LayerNorm 2 over the token rows, written in the (B, 6 hs) layout the heads read
+  for (int i = wave; i < S6K * nb; i += FR_THREADS / 64) ln_fwd_row<2>(P.ln2, (i / nb) * B + b0 + (i % nb), lane);
+  stage_sync();
+  // ---- logits = hfused W_head^T + b_head: a wave per (sample, output) pair, lanes along the 768-deep reduction; then the heads
+  for (int e = wave; e < nb * NC; e += FR_THREADS / 64) {
+    const int b = b0 + e / NC, c = e % NC;
+    const float* x = P.hfused + (int64_t)b * W6;
+    const float* w = P.head_w + (int64_t)c * W6;
+    float acc = 0.f;
+    for (int k = lane * 4; k < W6; k += 256) {
+      const f4 xv = *reinterpret_cast<const f4*>(x + k), wv = *reinterpret_cast<const f4*>(w + k);
+      acc += xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      const float z = acc + P.head_b[c];
+      P.logits[b * NC + c] = z;
+      if (c < 6) {
+        P.tcp[b * 6 + c] = sigmoidf_(z);
+      } else {
+        const int k = c - 6;
+        const float sc = sigmoidf_(z * drop_mul(P.p_cls, P.seed, P.site_cls, (uint64_t)(b * P.ncls + k)));
+        P.scores[b * P.ncls + k] = sc;
+        P.labels[b * P.ncls + k] = sc > P.threshold ? 1.f : 0.f;
+      }
+    }
+  }
+}
+
 }  // namespace
+
+int mmda_fused_fwd_a(const FusedFwdA* a, void* stream) {
+  if (!a || a->B <= 0 || a->nb <= 0 || a->nb > 2 || a->hs != 128 || a->nhead != 2 || a->ln1.n != 128) return MMDA_EINVAL;
+  hipLaunchKernelGGL(fused_fwd_a_kernel, dim3(ceil_div(a->B, a->nb)), dim3(FR_THREADS), 0, (hipStream_t)stream, *a);
+  MMDA_CHECK_LAUNCH("mmda_fused_fwd_a");
+  return MMDA_OK;
+}
+
+int mmda_fused_fwd_c(const FusedFwdC* a, void* stream) {
+  if (!a || a->B <= 0 || a->nb <= 0 || a->hs != 128 || a->ln2.n != 128) return MMDA_EINVAL;
+  hipLaunchKernelGGL(fused_fwd_c_kernel, dim3(ceil_div(a->B, a->nb)), dim3(FR_THREADS), 0, (hipStream_t)stream, *a);
+  MMDA_CHECK_LAUNCH("mmda_fused_fwd_c");
+  return MMDA_OK;
+}
 
 int mmda_fused_bwd_c(const FusedBwdC* a, void* stream) {
   if (!a || a->B <= 0 || a->nb <= 0 || a->hs != 128 || a->ln2.n != 128) return MMDA_EINVAL;

@@ -675,11 +675,7 @@ int eager_side_losses(mmda_misa* m, void* stream, bool hseq2_t) {
   void* ss = nullptr;
   int rc = side_fork(m, stream, &ss);
   if (!rc && m->wT_pending) rc = weight_transposes(m, ss);
-  if (!rc && hseq2_t) {            // the backward pass's operand copies (every fork puts a marker packet on the main stream: one for all)
-    mmda_convert_job cj[16];
-    const int nj = backward_only_jobs(m, cj);
-    rc = mmda_convert_bf16(cj, nj, ss);
-  }
+  (void)hseq2_t;                   // (the backward pass's operand copies are made by backward() itself: backward_only_jobs)
   if (!rc) rc = mmda_misa_zero_act_grads(m, ss);
   float* L = WS(m->losses);
   if (!rc) rc = mmda_loss_diff(WS(m->x6), BH, B, hs, c.diff_weight, L + 1, WS(m->d_x6), WS(m->diff_work), ss);
@@ -939,11 +935,7 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
       x.rc = side_fork(m, stream, &ss);
       if (!x.rc && m->wT_pending) x.rc = weight_transposes(m, ss);
       if (!x.rc && m->zero_grad_pending && !m->eager_losses) { x.rc = mmda_misa_zero_grad(m, ss); m->zero_grad_pending = 0; }
-      if (bfg && !inf && !late_t && !x.rc) {
-        mmda_convert_job cj[16];
-        const int nj = backward_only_jobs(m, cj);
-        x.rc = mmda_convert_bf16(cj, nj, ss);
-      }
+
     }
   }
   if (x.rc) return x.rc;
@@ -970,32 +962,47 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
     g[3] = sk_nt(3 * B, hs, hs, WS(m->orig), hs, PP(m->sh_w), PP(m->sh_b), WS(m->x6 + 3 * BH), hs, MMDA_ACT_SIGMOID);
     sk_launch(x, g, 4);
     if (!x.rc) x.rc = eager_side_losses(m, stream, bfg && !inf);
-    // reconstruct from private + shared (models.py:254-262), the q/k/v projection of the six tokens (models.py:243) and the
-    // discriminator's first layer all read x6 only
-    int n = 0;
-    for (int i = 0; i < 3; ++i) {
-      g[n] = sk_nt(B, hs, hs, WS(m->x6 + i * BH), hs, PP(m->rec_w + (int64_t)i * hs * hs), PP(m->rec_b + i * hs), WS(m->recon + i * BH), hs);
-      g[n++].A2 = WS(m->x6 + (3 + i) * BH);
-    }
-    g[n++] = sk_nt(6 * B, 3 * hs, hs, WS(m->x6), hs, PP(m->in_w), PP(m->in_b), WS(m->qkv), 3 * hs);
-    if (!c.use_cmd_sim) g[n++] = sk_nt(3 * B, hs, hs, WS(m->x6 + 3 * BH), hs, PP(m->d1_w), PP(m->d1_b), WS(m->dom_z), hs);
-    sk_launch(x, g, n);
-    if (!c.use_cmd_sim && !x.rc)
-      {
-      const mmda_act_params ap = act_params(m, training, seed, SITE_RRELU_DISC, false);
-      x.rc = mmda_act_dropout_fwd_p(WS(m->dom_z), WS(m->dom_h), 3 * BH, c.act, &ap, p_cls, seed, SITE_DISC, stream);
-    }
-    if (!x.rc) x.rc = mmda_attn_fwd(WS(m->qkv), S6, B, hs, NHEAD, WS(m->ctx), WS(m->probs), p_tf, seed, SITE_ATTN, stream);
-    n = 0;
-    g[n++] = sk_nt(6 * B, hs, hs, WS(m->ctx), hs, PP(m->out_w), PP(m->out_b), WS(m->attn_out), hs);
-    if (!c.use_cmd_sim) g[n++] = sk_nt(3 * B, 3, hs, WS(m->dom_h), hs, PP(m->d2_w), PP(m->d2_b), WS(m->dom), 3);
-    sk_launch(x, g, n);
-    if (!x.rc) {
-      mmda_ln_args l1 = {};
-      l1.rows = 6 * B; l1.n = hs; l1.x = WS(m->x6); l1.res = WS(m->attn_out); l1.gamma = PP(m->n1_w); l1.beta = PP(m->n1_b);
-      l1.y = WS(m->x1); l1.mean = WS(m->ln1_mean); l1.rstd = WS(m->ln1_rstd); l1.drop_p = p_tf; l1.drop_seed = seed;
-      l1.drop_site = SITE_DROP1; l1.eps = 1e-5f;
-      x.rc = mmda_layernorm_fwd(&l1, stream);
+    // The row-local stretches as one launch each (fused_rows.hip): recon + qkv -> attention -> out-proj -> LayerNorm 1, and
+    // LayerNorm 2 -> heads.  MMDA_ROW_FUSE=0: the launches they replace (4 and 3).
+    static const int row_fuse_on = getenv("MMDA_ROW_FUSE") ? atoi(getenv("MMDA_ROW_FUSE")) : 1;
+    const bool row_fuse = row_fuse_on && c.use_cmd_sim && hs == 128 && NHEAD == 2;
+    const int fuse_nb = (B % 2) == 0 ? 2 : 1;
+    mmda_ln_args l1 = {};
+    l1.rows = 6 * B; l1.n = hs; l1.x = WS(m->x6); l1.res = WS(m->attn_out); l1.gamma = PP(m->n1_w); l1.beta = PP(m->n1_b);
+    l1.y = WS(m->x1); l1.mean = WS(m->ln1_mean); l1.rstd = WS(m->ln1_rstd); l1.drop_p = p_tf; l1.drop_seed = seed;
+    l1.drop_site = SITE_DROP1; l1.eps = 1e-5f;
+    if (row_fuse) {
+      if (!x.rc) {
+        FusedFwdA f = {};
+        f.B = B; f.hs = hs; f.nhead = NHEAD; f.nb = fuse_nb; f.x6 = WS(m->x6);
+        f.rec_w = PP(m->rec_w); f.rec_b = PP(m->rec_b); f.recon = WS(m->recon);
+        f.in_w = PP(m->in_w); f.in_b = PP(m->in_b); f.qkv = WS(m->qkv);
+        f.ctx = WS(m->ctx); f.probs = WS(m->probs); f.p_tf = p_tf; f.seed = seed; f.site_attn = SITE_ATTN;
+        f.out_w = PP(m->out_w); f.out_b = PP(m->out_b); f.attn_out = WS(m->attn_out); f.ln1 = l1;
+        x.rc = mmda_fused_fwd_a(&f, stream);
+      }
+    } else {
+      // reconstruct from private + shared (models.py:254-262), the q/k/v projection of the six tokens (models.py:243) and the
+      // discriminator's first layer all read x6 only
+      int n = 0;
+      for (int i = 0; i < 3; ++i) {
+        g[n] = sk_nt(B, hs, hs, WS(m->x6 + i * BH), hs, PP(m->rec_w + (int64_t)i * hs * hs), PP(m->rec_b + i * hs), WS(m->recon + i * BH), hs);
+        g[n++].A2 = WS(m->x6 + (3 + i) * BH);
+      }
+      g[n++] = sk_nt(6 * B, 3 * hs, hs, WS(m->x6), hs, PP(m->in_w), PP(m->in_b), WS(m->qkv), 3 * hs);
+      if (!c.use_cmd_sim) g[n++] = sk_nt(3 * B, hs, hs, WS(m->x6 + 3 * BH), hs, PP(m->d1_w), PP(m->d1_b), WS(m->dom_z), hs);
+      sk_launch(x, g, n);
+      if (!c.use_cmd_sim && !x.rc)
+        {
+        const mmda_act_params ap = act_params(m, training, seed, SITE_RRELU_DISC, false);
+        x.rc = mmda_act_dropout_fwd_p(WS(m->dom_z), WS(m->dom_h), 3 * BH, c.act, &ap, p_cls, seed, SITE_DISC, stream);
+      }
+      if (!x.rc) x.rc = mmda_attn_fwd(WS(m->qkv), S6, B, hs, NHEAD, WS(m->ctx), WS(m->probs), p_tf, seed, SITE_ATTN, stream);
+      n = 0;
+      g[n++] = sk_nt(6 * B, hs, hs, WS(m->ctx), hs, PP(m->out_w), PP(m->out_b), WS(m->attn_out), hs);
+      if (!c.use_cmd_sim) g[n++] = sk_nt(3 * B, 3, hs, WS(m->dom_h), hs, PP(m->d2_w), PP(m->d2_b), WS(m->dom), 3);
+      sk_launch(x, g, n);
+      if (!x.rc) x.rc = mmda_layernorm_fwd(&l1, stream);
     }
     if (m->fusion_fp8) {
       if (!x.rc) x.rc = ffn_fp8(m, p_tf, seed, stream);
@@ -1006,18 +1013,27 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
       g[0] = sk_nt(6 * B, hs, FFN, WS(m->f1), FFN, PP(m->l2_w), PP(m->l2_b), WS(m->f2), hs);
       sk_launch(x, g, 1);
     }
-    if (!x.rc) {
-      mmda_ln_args l2 = {};
-      l2.rows = 6 * B; l2.n = hs; l2.x = WS(m->x1); l2.res = WS(m->f2); l2.gamma = PP(m->n2_w); l2.beta = PP(m->n2_b);
-      l2.y = WS(m->hfused); l2.mean = WS(m->ln2_mean); l2.rstd = WS(m->ln2_rstd); l2.drop_p = p_tf; l2.drop_seed = seed;
-      l2.drop_site = SITE_DROP2; l2.permute_S = S6; l2.permute_B = B; l2.eps = 1e-5f;   // emits h = cat(h[0..5], dim=1)
-      x.rc = mmda_layernorm_fwd(&l2, stream);
+    mmda_ln_args l2 = {};
+    l2.rows = 6 * B; l2.n = hs; l2.x = WS(m->x1); l2.res = WS(m->f2); l2.gamma = PP(m->n2_w); l2.beta = PP(m->n2_b);
+    l2.y = WS(m->hfused); l2.mean = WS(m->ln2_mean); l2.rstd = WS(m->ln2_rstd); l2.drop_p = p_tf; l2.drop_seed = seed;
+    l2.drop_site = SITE_DROP2; l2.permute_S = S6; l2.permute_B = B; l2.eps = 1e-5f;   // emits h = cat(h[0..5], dim=1)
+    if (row_fuse) {
+      if (!x.rc) {
+        FusedFwdC f = {};
+        f.B = B; f.hs = hs; f.ncls = c.ncls; f.nb = fuse_nb; f.ln2 = l2;
+        f.hfused = WS(m->hfused); f.head_w = PP(m->head_w); f.head_b = PP(m->head_b); f.logits = WS(m->logits);
+        f.threshold = c.threshold; f.tcp = WS(m->tcp); f.scores = WS(m->scores); f.labels = WS(m->labels);
+        f.p_cls = p_cls; f.seed = seed; f.site_cls = SITE_CLS;
+        x.rc = mmda_fused_fwd_c(&f, stream);
+      }
+    } else {
+      if (!x.rc) x.rc = mmda_layernorm_fwd(&l2, stream);
+      g[0] = sk_nt(B, NC, 6 * hs, WS(m->hfused), 6 * hs, PP(m->head_w), PP(m->head_b), WS(m->logits), NC);
+      sk_launch(x, g, 1);
+      if (!x.rc)
+        x.rc = mmda_heads_fwd(WS(m->logits), B, c.ncls, c.threshold, WS(m->tcp), WS(m->scores), WS(m->labels), p_cls, seed, SITE_CLS,
+                              stream);
     }
-    g[0] = sk_nt(B, NC, 6 * hs, WS(m->hfused), 6 * hs, PP(m->head_w), PP(m->head_b), WS(m->logits), NC);
-    sk_launch(x, g, 1);
-    if (!x.rc)
-      x.rc = mmda_heads_fwd(WS(m->logits), B, c.ncls, c.threshold, WS(m->tcp), WS(m->scores), WS(m->labels), p_cls, seed, SITE_CLS,
-                            stream);
   } else {
     // ---- many rows: the tiled generic kernel
     for (int i = 0; i < 3 && !x.rc; ++i) {
@@ -1411,6 +1427,13 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
     if (!x.rc && B <= SKINNY_MAX_B) x.rc = mmda_add(WS(m->x6), WS(m->x6 + 3 * BH), WS(m->rsum), 3 * BH, ss);
     if (!x.rc && !x.deferred.empty()) x.rc = mmda_gemm_grouped(x.deferred.data(), (int)x.deferred.size(), ss);
     x.deferred.clear();
+    // the bf16 operand copies that only the weight-gradient GEMMs read (hseq of both layers, nt form: transposed layer-2 inputs): here,
+    // where the side stream is idle beside the layer-2 recurrence, instead of in front of the loss kernels of the forward pass
+    if (!x.rc && mode == MMDA_BF16 && m->use_bf16_gemm && T > 0) {
+      mmda_convert_job cj[16];
+      const int nj = backward_only_jobs(m, cj);
+      x.rc = mmda_convert_bf16(cj, nj, ss);
+    }
     // Experiment, OFF by default (MMDA_ADAM_EMBED_SPLIT=1): clip + Adam of the embedding rows this batch does NOT touch, here, beside
     // the layer-2 recurrence (the side stream is idle for ~100 us behind the GEMMs above).  Their gradient is zero whatever the rest of
     // the backward pass does (the bucket was cleared during the forward pass, the scatter at the end adds into the touched rows only),

@@ -23,43 +23,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnMulti L) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = ((int)blockIdx.x - L.start[pi]) * 4 + wave;
   if (row >= a.rows) return;
-  const int n = a.n;
-  float v[NQ];
-  float s = 0.f;
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    int i = lane + 64 * q;
-    float x = 0.f;
-    if (i < n) {
-      int64_t idx = (int64_t)row * n + i;
-      x = act_fwd_p(a.act, a.x[idx], a.actp, (uint64_t)idx);
-      if (a.res) x += a.res[idx] * drop_mul(a.drop_p, a.drop_seed, a.drop_site, (uint64_t)idx);
-    }
-    v[q] = x;
-    s += x;
-  }
-  const float mean = wave_sum(s) / n;
-  float ss = 0.f;
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    int i = lane + 64 * q;
-    float d = (i < n) ? v[q] - mean : 0.f;
-    ss += d * d;
-  }
-  const float var = wave_sum(ss) / n;
-  const float rstd = 1.0f / sqrtf(var + a.eps);
-  if (lane == 0) {
-    if (a.mean) a.mean[row] = mean;
-    if (a.rstd) a.rstd[row] = rstd;
-  }
-  const int64_t orow = perm_row(row, a.permute_S, a.permute_B);
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    int i = lane + 64 * q;
-    float y = 0.f;
-    if (i < n) { y = (v[q] - mean) * rstd * a.gamma[i] + a.beta[i]; a.y[orow * n + i] = y; }
-    if (a.y_bf16 && i < a.ld_bf16) reinterpret_cast<unsigned short*>(a.y_bf16)[orow * a.ld_bf16 + i] = f2bf(y);      // (zero in the padding)
-  }
+  ln_fwd_row<NQ>(a, row, lane);      // (rowlocal.h)
 }
 
 template <int NQ>
