@@ -17,8 +17,11 @@ constexpr int FR_THREADS = 512;
 // arow == nullptr: a zero row.  K % 16 == 0, rows 16-byte aligned.  Rounds of eight 16-deep chunks; the loads of round r + 1 are issued
 // before the MFMAs of round r (two register sets: a stage is a chain of memory latencies, the MFMAs hide behind the next one).
 struct MacRound { f4 a[8], b[8]; };
-// one round = 128 of the reduction: eight 16-deep chunks, a lane's float4 at k = 16 c + 4 (lane >> 4) feeds component s to the s-th MFMA
-__device__ __forceinline__ void mac_load(MacRound& R, const float* __restrict__ arow, const float* __restrict__ brow, int g) {
+// one round = 128 of the reduction: eight 16-deep chunks, a lane's float4 at k = 16 c + 4 (lane >> 4) feeds component s to the s-th MFMA.
+// The A rows of a stage are staged in LDS once per workgroup (stage_rows): all eight waves multiply the same <= 16 rows, and what bounds
+// a stage is the volume of loads one CU can pull through its memory pipeline -- the weights (B), which every wave needs its own
+// columns of, stay global -> registers.  arow == nullptr: a zero row (no read at all).
+__device__ __forceinline__ void mac_load(MacRound& R, const float* arow /* LDS */, const float* __restrict__ brow, int g) {
   const f4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
@@ -32,7 +35,8 @@ __device__ __forceinline__ void mac_run(f32x4& acc, const MacRound& R) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(R.a[c][s], R.b[c][s], acc, 0, 0, 0);
 }
-// NR rounds into one accumulator; round r multiplies A row ar[r] (or zeros) with Bt row br[r], both already advanced to the round's k
+// NR rounds into one accumulator; round r multiplies A row ar[r] (or zeros) with Bt row br[r], both already advanced to the round's k.
+// The loads of round r + 1 are issued before the MFMAs of round r (a third register set, two rounds ahead, measured no faster).
 template <int NR>
 __device__ __forceinline__ void tile_mac_chain(f32x4& acc, const float* const (&ar)[NR], const float* const (&br)[NR], int lane) {
   const int g = lane >> 4;
@@ -50,6 +54,21 @@ __device__ __forceinline__ void tile_mac_chain(f32x4& acc, const float* const (&
 // stage boundary: this workgroup's global stores are visible to all of its waves
 __device__ __forceinline__ void stage_sync() {
   __threadfence_block();
+  __syncthreads();
+}
+
+// LDS image of a stage's A rows: row r at lds + r * (K + 4) floats (the + 4 puts the sixteen rows a b128 read touches on distinct banks).
+// src_of(r): the global row (K floats, 16-byte aligned) or nullptr for a zero row.  Ends with a workgroup barrier.
+constexpr int LDS_A_FLOATS = 12 * (384 + 4) + 18 * (128 + 4);      // the largest stage: twelve d_qkv rows + their d_recon rows
+template <typename SrcOf>
+__device__ __forceinline__ void stage_rows(float* lds, int nrows, int K, SrcOf src_of) {
+  const int per_row = K >> 2;
+  for (int e = threadIdx.x; e < nrows * per_row; e += FR_THREADS) {
+    const int r = e / per_row, c = e % per_row;
+    const float* src = src_of(r);
+    const f4 z = {0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f4*>(lds + r * (K + 4) + 4 * c) = src ? *reinterpret_cast<const f4*>(src + 4 * c) : z;
+  }
   __syncthreads();
 }
 
@@ -110,6 +129,7 @@ __global__ __launch_bounds__(FR_THREADS) void fused_bwd_c_kernel(FusedBwdC P) {
 
 __global__ __launch_bounds__(FR_THREADS) void fused_bwd_a_kernel(FusedBwdA P) {
   __shared__ float red[2 * 8 * 128];
+  __shared__ __attribute__((aligned(16))) float lds_a[LDS_A_FLOATS];
   const int b0 = (int)blockIdx.x * P.nb;
   const int nb = min(P.nb, P.B - b0);
   const int B = P.B, hs = P.hs;
@@ -126,13 +146,13 @@ __global__ __launch_bounds__(FR_THREADS) void fused_bwd_a_kernel(FusedBwdA P) {
   // token-row tile: tile row r = j nb + bb  <->  global row j B + b0 + bb
   const int ntok = S6K * nb;                             // <= 12
   const bool rok = r16 < ntok;
-  const int tj = rok ? r16 / nb : 0, tb = rok ? r16 % nb : 0;
-  const int64_t trow = (int64_t)tj * B + b0 + tb;        // this lane's A row in the token tiles
+  const int tj = rok ? r16 / nb : 0;
   const int col = wave * 16 + r16;                       // this lane's Bt row (output column): hs = 128 = 8 waves x 16
   // ---- d_ctx = d_attn_out W_out
   {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const float* const ar[1] = {rok ? P.d_attn_out + trow * hs : nullptr};
+    stage_rows(lds_a, ntok, hs, [&](int r) { return P.d_attn_out + ((int64_t)(r / nb) * B + b0 + (r % nb)) * hs; });
+    const float* const ar[1] = {rok ? lds_a + r16 * (hs + 4) : nullptr};
     const float* const br[1] = {P.out_wT + (int64_t)col * hs};
     tile_mac_chain<1>(acc, ar, br, lane);
 #pragma unroll
@@ -152,8 +172,12 @@ __global__ __launch_bounds__(FR_THREADS) void fused_bwd_a_kernel(FusedBwdA P) {
   {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     // (rows of the other two modalities multiply zeros in the per-modality products)
-    const float* rec_row = rok ? P.d_recon + ((int64_t)(tj % 3) * B + b0 + tb) * hs : nullptr;
-    const float* qrow = rok ? P.d_qkv + trow * 3 * hs : nullptr;
+    // LDS: rows 0..ntok-1 = d_qkv rows (3 hs deep); behind them, at a stride of hs + 4, the d_recon row of every token row
+    float* lds_r = lds_a + 12 * (3 * hs + 4);
+    stage_rows(lds_a, ntok, 3 * hs, [&](int r) { return P.d_qkv + ((int64_t)(r / nb) * B + b0 + (r % nb)) * 3 * hs; });
+    stage_rows(lds_r, ntok, hs, [&](int r) { return P.d_recon + ((int64_t)((r / nb) % 3) * B + b0 + (r % nb)) * hs; });
+    const float* rec_row = rok ? lds_r + r16 * (hs + 4) : nullptr;
+    const float* qrow = rok ? lds_a + r16 * (3 * hs + 4) : nullptr;
     const float* wrow = P.in_wT + (int64_t)col * 3 * hs;
     const float* const ar[6] = {qrow, qrow ? qrow + 128 : nullptr, qrow ? qrow + 256 : nullptr, (rok && tj % 3 == 0) ? rec_row : nullptr,
                                 (rok && tj % 3 == 1) ? rec_row : nullptr, (rok && tj % 3 == 2) ? rec_row : nullptr};
@@ -175,11 +199,13 @@ __global__ __launch_bounds__(FR_THREADS) void fused_bwd_a_kernel(FusedBwdA P) {
   // ---- d_orig[i] += d_private[i] W_priv[i] + d_shared[i] W_shared; modality-row tile: tile row r = i nb + bb
   const int nmod = 3 * nb;
   const bool mok = r16 < nmod;
-  const int mi = mok ? r16 / nb : 0, mb = mok ? r16 % nb : 0;
+  const int mi = mok ? r16 / nb : 0;
   {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const float* prow = mok ? P.d_x6 + ((int64_t)mi * B + b0 + mb) * hs : nullptr;
-    const float* const ar[4] = {mok ? P.d_x6 + ((int64_t)(3 + mi) * B + b0 + mb) * hs : nullptr, (mok && mi == 0) ? prow : nullptr,
+    // LDS: rows 0..nmod-1 = d_private rows, rows nmod..2 nmod-1 = d_shared rows
+    stage_rows(lds_a, 2 * nmod, hs, [&](int r) { return P.d_x6 + ((int64_t)((r / nmod) * 3 + (r % nmod) / nb) * B + b0 + (r % nb)) * hs; });
+    const float* prow = mok ? lds_a + r16 * (hs + 4) : nullptr;
+    const float* const ar[4] = {mok ? lds_a + (nmod + r16) * (hs + 4) : nullptr, (mok && mi == 0) ? prow : nullptr,
                                 (mok && mi == 1) ? prow : nullptr, (mok && mi == 2) ? prow : nullptr};
     const float* const br[4] = {P.sh_wT + (int64_t)col * hs, P.priv_wT + (int64_t)col * hs, P.priv_wT + (int64_t)hs * hs + (int64_t)col * hs,
                                 P.priv_wT + (int64_t)2 * hs * hs + (int64_t)col * hs};
@@ -216,17 +242,8 @@ __global__ __launch_bounds__(FR_THREADS) void fused_bwd_a_kernel(FusedBwdA P) {
 
 // ---------------------------------------------------------------------------------------------------------------- forward stretches
 // one round with the A row formed as the sum of two rows (private + shared)
-__device__ __forceinline__ void mac_load2(MacRound& R, const float* __restrict__ arow, const float* __restrict__ arow2,
-                                          const float* __restrict__ brow, int g) {
-  const f4 z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    R.a[c] = arow ? *reinterpret_cast<const f4*>(arow + 16 * c + 4 * g) + *reinterpret_cast<const f4*>(arow2 + 16 * c + 4 * g) : z;
-    R.b[c] = *reinterpret_cast<const f4*>(brow + 16 * c + 4 * g);
-  }
-}
-
 __global__ __launch_bounds__(FR_THREADS) void fused_fwd_a_kernel(FusedFwdA P) {
+  __shared__ __attribute__((aligned(16))) float lds_a[LDS_A_FLOATS];
   const int b0 = (int)blockIdx.x * P.nb;
   const int nb = min(P.nb, P.B - b0);
   const int B = P.B, hs = P.hs;
@@ -234,22 +251,24 @@ __global__ __launch_bounds__(FR_THREADS) void fused_fwd_a_kernel(FusedFwdA P) {
   const int r16 = lane & 15, g = lane >> 4;
   const int ntok = S6K * nb, nmod = 3 * nb;
   const bool rok = r16 < ntok;
-  const int tj = rok ? r16 / nb : 0, tb = rok ? r16 % nb : 0;
-  const int64_t trow = (int64_t)tj * B + b0 + tb;
   const bool mok = r16 < nmod;
-  const int mi = mok ? r16 / nb : 0, mb = mok ? r16 % nb : 0;
+  const int mi = mok ? r16 / nb : 0;
   const int col = wave * 16 + r16;
+  // LDS: rows 0..ntok-1 = the x6 token rows; rows 12..12+nmod-1 = private + shared of (modality, sample)
+  stage_rows(lds_a, ntok, hs, [&](int r) { return P.x6 + ((int64_t)(r / nb) * B + b0 + (r % nb)) * hs; });
+  for (int e = threadIdx.x; e < nmod * (hs / 4); e += FR_THREADS) {
+    const int r = e / (hs / 4), c = e % (hs / 4);
+    const f4 a = *reinterpret_cast<const f4*>(lds_a + r * (hs + 4) + 4 * c), b2 = *reinterpret_cast<const f4*>(lds_a + (nmod + r) * (hs + 4) + 4 * c);
+    *reinterpret_cast<f4*>(lds_a + (12 + r) * (hs + 4) + 4 * c) = a + b2;
+  }
+  __syncthreads();
   // ---- recon[i] = (x6[i] + x6[3 + i]) W_rec[i]^T + b_rec[i]: modality-row tile, three products into one accumulator
   {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    MacRound R;
-#pragma unroll
-    for (int i3 = 0; i3 < 3; ++i3) {
-      const bool mine = mok && mi == i3;
-      mac_load2(R, mine ? P.x6 + ((int64_t)mi * B + b0 + mb) * hs : nullptr, P.x6 + ((int64_t)(3 + mi) * B + b0 + mb) * hs,
-                P.rec_w + (int64_t)i3 * hs * hs + (int64_t)col * hs, g);
-      mac_run(acc, R);
-    }
+    const float* srow = mok ? lds_a + (12 + r16) * (hs + 4) : nullptr;
+    const float* const ar[3] = {(mok && mi == 0) ? srow : nullptr, (mok && mi == 1) ? srow : nullptr, (mok && mi == 2) ? srow : nullptr};
+    const float* const br[3] = {P.rec_w + (int64_t)col * hs, P.rec_w + (int64_t)hs * hs + (int64_t)col * hs, P.rec_w + (int64_t)2 * hs * hs + (int64_t)col * hs};
+    tile_mac_chain<3>(acc, ar, br, lane);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = 4 * g + i;
@@ -261,7 +280,7 @@ __global__ __launch_bounds__(FR_THREADS) void fused_fwd_a_kernel(FusedFwdA P) {
   for (int pass = 0; pass < 3; ++pass) {
     const int n = pass * 128 + col;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const float* const ar[1] = {rok ? P.x6 + trow * hs : nullptr};
+    const float* const ar[1] = {rok ? lds_a + r16 * (hs + 4) : nullptr};
     const float* const br[1] = {P.in_w + (int64_t)n * hs};
     tile_mac_chain<1>(acc, ar, br, lane);
     const float bias = P.in_b[n];
@@ -279,7 +298,8 @@ __global__ __launch_bounds__(FR_THREADS) void fused_fwd_a_kernel(FusedFwdA P) {
   // ---- attn_out = ctx W_out^T + b_out
   {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const float* const ar[1] = {rok ? P.ctx + trow * hs : nullptr};
+    stage_rows(lds_a, ntok, hs, [&](int r) { return P.ctx + ((int64_t)(r / nb) * B + b0 + (r % nb)) * hs; });
+    const float* const ar[1] = {rok ? lds_a + r16 * (hs + 4) : nullptr};
     const float* const br[1] = {P.out_w + (int64_t)col * hs};
     tile_mac_chain<1>(acc, ar, br, lane);
     const float bias = P.out_b[col];
