@@ -150,14 +150,20 @@ constexpr unsigned OOB = 0xFFFFFF00u;
 __device__ __forceinline__ float ldf(__amdgpu_buffer_rsrc_t r, unsigned off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
 }
+// (cache policy of the bulk stores -- stash, hseq, gate gradients -- as a build-time knob.  Measured at B=32, step in ms: default
+//  write-back 0.722, nt 0.740, sc1 write-through 0.751, sc0 sc1 0.753: the end-of-kernel write-back of what is still dirty costs less
+//  than write-through traffic beside the hand-offs)
+#ifndef MMDA_STASH_AUX
+#define MMDA_STASH_AUX 0
+#endif
 __device__ __forceinline__ void stf(__amdgpu_buffer_rsrc_t r, unsigned off, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, MMDA_STASH_AUX);
 }
 __device__ __forceinline__ f32x4 ldf4(__amdgpu_buffer_rsrc_t r, unsigned off) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
 }
 __device__ __forceinline__ void stf4(__amdgpu_buffer_rsrc_t r, unsigned off, f32x4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, MMDA_STASH_AUX);
 }
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -1215,7 +1221,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
         if (f32_dg) stf4(rg, o, f32x4{dgv[r][0], dgv[r][1], dgv[r][2], dgv[r][3]});
         if (has_dg16) {                                // the same four values rounded to bf16: 8 bytes at half the byte offset
           const u32x2 pk = {pack_bf16x2(dgv[r][0], dgv[r][1]), pack_bf16x2(dgv[r][2], dgv[r][3])};
-          __builtin_amdgcn_raw_buffer_store_b64(pk, rg16, inb[r] ? (og[r] + (unsigned)t * sg) >> 1 : OOB, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(pk, rg16, inb[r] ? (og[r] + (unsigned)t * sg) >> 1 : OOB, 0, MMDA_STASH_AUX);
         }
       } else {
 #pragma unroll
@@ -1829,7 +1835,7 @@ __global__ __launch_bounds__(256, 4) void lstm_bwd_quad_kernel(CLaunch L) {   //
     if (f32_dg) stf4(rg, o, f32x4{dgv[0], dgv[1], dgv[2], dgv[3]});
     if (has_dg16) {
       const u32x2 pk = {pack_bf16x2(dgv[0], dgv[1]), pack_bf16x2(dgv[2], dgv[3])};
-      __builtin_amdgcn_raw_buffer_store_b64(pk, rg16, inb ? (og + (unsigned)t * sg) >> 1 : OOB, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b64(pk, rg16, inb ? (og + (unsigned)t * sg) >> 1 : OOB, 0, MMDA_STASH_AUX);
     }
   };
   bool fast = false;
