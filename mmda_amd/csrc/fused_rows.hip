@@ -1,5 +1,6 @@
 // The row-local stretches of the fusion block's backward pass, one launch each (see fused_rows.h).
-// Workgroup = 512 threads = 8 waves, rows of `nb` samples (nb = 2: twelve token rows fill an MFMA tile; B odd: nb = 1).  GEMM stages use
+// Workgroup = 512 threads = 8 waves, rows of `nb` samples (1 by default: the MFMA tile is then 6 of 16 rows full, but what a stage waits
+// for is its weights, and twice the workgroups halve the LayerNorm / attention rounds; 2 = twelve token rows per tile).  GEMM stages use
 // v_mfma_f32_16x16x4_f32 (exact f32; hs = 128: every product is a whole number of 128-deep rounds) with operands global -> registers -> MFMA as in gemm_skinny.hip: wave w owns output columns
 // 16 w .. 16 w + 15 (hs = 128 = 8 waves x 16), walks the whole reduction itself, and applies its epilogue straight from the accumulators.
 // The six problems of d_x6 and the three of d_orig each become ONE accumulator chain per wave: the products that differ per modality

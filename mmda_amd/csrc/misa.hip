@@ -966,7 +966,8 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
     // LayerNorm 2 -> heads.  MMDA_ROW_FUSE=0: the launches they replace (4 and 3).
     static const int row_fuse_on = getenv("MMDA_ROW_FUSE") ? atoi(getenv("MMDA_ROW_FUSE")) : 1;
     const bool row_fuse = row_fuse_on && c.use_cmd_sim && hs == 128 && NHEAD == 2;
-    const int fuse_nb = (B % 2) == 0 ? 2 : 1;
+    static const int fuse_nb_env = getenv("MMDA_ROW_FUSE_NB") ? atoi(getenv("MMDA_ROW_FUSE_NB")) : 1;      // samples per workgroup (B=32: 0.722 ms with 2, 0.712 with 1; B=256 equal)
+    const int fuse_nb = ((B % 2) == 0 && fuse_nb_env == 2) ? 2 : 1;
     mmda_ln_args l1 = {};
     l1.rows = 6 * B; l1.n = hs; l1.x = WS(m->x6); l1.res = WS(m->attn_out); l1.gamma = PP(m->n1_w); l1.beta = PP(m->n1_b);
     l1.y = WS(m->x1); l1.mean = WS(m->ln1_mean); l1.rstd = WS(m->ln1_rstd); l1.drop_p = p_tf; l1.drop_seed = seed;
@@ -1181,7 +1182,8 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
     // ... -> the projection LayerNorms.  MMDA_ROW_FUSE=0: the launches they replace (3 and 6).
     static const int row_fuse_on = getenv("MMDA_ROW_FUSE") ? atoi(getenv("MMDA_ROW_FUSE")) : 1;
     const bool row_fuse = row_fuse_on && wt && c.use_cmd_sim && hs == 128 && NHEAD == 2;
-    const int fuse_nb = (B % 2) == 0 ? 2 : 1;
+    static const int fuse_nb_env = getenv("MMDA_ROW_FUSE_NB") ? atoi(getenv("MMDA_ROW_FUSE_NB")) : 1;      // samples per workgroup (B=32: 0.722 ms with 2, 0.712 with 1; B=256 equal)
+    const int fuse_nb = ((B % 2) == 0 && fuse_nb_env == 2) ? 2 : 1;
     mmda_ln_bwd_args l2a = {};
     l2a.rows = 6 * B; l2a.n = hs; l2a.dy = WS(m->d_hfused); l2a.x = WS(m->x1); l2a.res = WS(m->f2); l2a.gamma = PP(m->n2_w);
     l2a.mean = WS(m->ln2_mean); l2a.rstd = WS(m->ln2_rstd); l2a.d_x = WS(m->d_x1); l2a.d_res = WS(m->d_f2);
