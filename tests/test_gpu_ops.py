@@ -492,7 +492,9 @@ def _lstm_case(T, B, H, D, ragged, seed):
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16", "bf16-resident", "bf16-resident-gateminor"])
 @pytest.mark.parametrize("T,B,H,ragged", [(9, 5, 6, True), (12, 16, 35, True), (7, 20, 74, True), (10, 32, 300, False),
-                                          (6, 3, 300, True), (5, 17, 128, True), (8, 70, 300, True)])
+                                          (6, 3, 300, True), (5, 17, 128, True), (8, 70, 300, True),
+                                          # sequences shorter than the hand-off's flag-announced prologue (three steps) and just past it
+                                          (1, 8, 300, False), (2, 8, 300, True), (3, 8, 74, True), (4, 8, 300, True)])
 def test_lstm_fwd_bwd_vs_nn_lstm(mode, T, B, H, ragged):
     """Three implementations of the recurrence behind one entry point: exact f32-MFMA streaming kernel, bf16 streaming kernel,
     and the bf16 kernel with W_hh resident in LDS across a cluster of workgroups (per-step h / dG all-gather)."""
