@@ -22,6 +22,7 @@ struct FusedBwdC {
 struct FusedBwdA {
   int B, hs, nhead, nb;
   mmda_ln_bwd_args ln1;           // rows = 6 B; d_x = d_x6 (accumulated), d_res = d_attn_out
+  const float* ffn_parts; int n_parts; float* d_x1;                       // optional: d_x1 += sum of the partials (slice order), first
   const float* d_attn_out; const float* out_wT; float* d_ctx;
   const float* qkv; const float* probs; float* d_qkv; float p_tf; uint64_t seed; int site_attn;
   const float* in_wT;             // (hs, 3 hs): K-major copy of in_proj_weight
@@ -51,9 +52,32 @@ struct FusedFwdA {
 struct FusedFwdC {
   int B, hs, ncls, nb;
   mmda_ln_args ln2;               // rows = 6 B, permute_S / permute_B set, y = hfused
+  const float* ffn_parts; int n_parts; const float* b2; float* f2;      // optional: f2 = sum of the partials (slice order) + b2, first
   const float* hfused; const float* head_w; const float* head_b; float* logits;      // (B, 6 hs), (6 + ncls, 6 hs), 6 + ncls, (B, 6 + ncls)
   float threshold; float* tcp; float* scores; float* labels; float p_cls; uint64_t seed; int site_cls;
 };
+// The feed-forward pair of the transformer layer (linear1 hs -> F with relu + dropout, linear2 F -> hs) as ONE launch per direction,
+// split over the HIDDEN units: workgroup (row block, slice j) takes S of the F hidden units of 192 rows through both products -- it needs
+// S rows of W1 and S columns of W2 only, so the 2 MB of weights are spread over F / S workgroups instead of streaming through every one
+// -- and leaves a partial (rows, hs) product of the second GEMM in parts[j]; the consumer (the fused stretch behind it) adds the F / S
+// partials in slice order.
+struct FusedFfnFwd {
+  int M, hs, F, S;                // rows (6 B), 128, 2048, hidden units per workgroup
+  const float* x1; const float* w1; const float* b1; float* f1;   // (M, hs), (F, hs), F, (M, F): f1 = dropout(relu(x1 W1^T + b1))
+  float p; uint64_t seed; int site;                                // dropout on f1, element index m * F + n
+  const float* w2;                // (hs, F)
+  float* parts;                   // (F / S, M, hs): partial f2 (no bias)
+};
+struct FusedFfnBwd {
+  int M, hs, F, S;
+  const float* d_f2; const float* f1; float gate_scale;           // (M, hs), (M, F): d_f1 = (d_f2 W2) * [f1 > 0] * gate_scale
+  const float* l2_wT;             // (F, hs): K-major copy of W2
+  float* d_f1;                    // (M, F)
+  const float* l1_wT;             // (hs, F): K-major copy of W1
+  float* parts;                   // (F / S, M, hs): partial d_x1 = d_f1 W1
+};
+int mmda_fused_ffn_fwd(const FusedFfnFwd* a, void* stream);
+int mmda_fused_ffn_bwd(const FusedFfnBwd* a, void* stream);
 int mmda_fused_fwd_a(const FusedFwdA* a, void* stream);
 int mmda_fused_fwd_c(const FusedFwdC* a, void* stream);
 int mmda_fused_bwd_c(const FusedBwdC* a, void* stream);

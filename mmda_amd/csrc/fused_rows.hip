@@ -52,6 +52,21 @@ __device__ __forceinline__ void tile_mac_chain(f32x4& acc, const float* const (&
   }
 }
 
+// sum of n values `stride` floats apart, added in index order; sixteen loads in flight at a time (one at a time is n memory latencies)
+__device__ __forceinline__ float sum_parts(const float* __restrict__ p, int n, int64_t stride) {
+  float acc = 0.f;
+  int q = 0;
+  for (; q + 16 <= n; q += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = p[(q + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc += v[u];
+  }
+  for (; q < n; ++q) acc += p[q * stride];
+  return acc;
+}
+
 // stage boundary: this workgroup's global stores are visible to all of its waves
 __device__ __forceinline__ void stage_sync() {
   __threadfence_block();
@@ -140,6 +155,16 @@ __global__ __launch_bounds__(FR_THREADS) void fused_bwd_a_kernel(FusedBwdA P) {
   int stamp_i = 0;
   auto stamp = [&]() { if (P.dbg && blockIdx.x == 0 && threadIdx.x == 0) P.dbg[stamp_i] = __builtin_readcyclecounter(); ++stamp_i; };
   stamp();
+  // ---- d_x1 += sum of the feed-forward backward partials (slice order), for the token rows of these samples
+  if (P.ffn_parts) {
+    const int64_t MH = (int64_t)S6K * B * hs;
+    for (int e = threadIdx.x; e < S6K * nb * hs; e += FR_THREADS) {
+      const int i = e / hs, n = e % hs;
+      const int64_t o = ((int64_t)(i / nb) * B + b0 + (i % nb)) * hs + n;
+      P.d_x1[o] += sum_parts(P.ffn_parts + o, P.n_parts, MH);
+    }
+    stage_sync();
+  }
   // ---- LayerNorm 1 backward: d_x6 += ..., d_attn_out
   ln_bwd_rows(P.ln1, S6K * nb, [&](int i) { return (i / nb) * B + b0 + (i % nb); }, red);
   stage_sync();
@@ -320,6 +345,16 @@ __global__ __launch_bounds__(FR_THREADS) void fused_fwd_c_kernel(FusedFwdC P) {
   const int nb = min(P.nb, P.B - b0);
   const int B = P.B, hs = P.hs, NC = 6 + P.ncls, W6 = 6 * hs;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // ---- f2 = sum of the feed-forward partials (slice order) + b2, for the token rows of these samples
+  if (P.ffn_parts) {
+    const int64_t MH = (int64_t)S6K * B * hs;
+    for (int e = threadIdx.x; e < S6K * nb * hs; e += FR_THREADS) {
+      const int i = e / hs, n = e % hs;
+      const int64_t o = ((int64_t)(i / nb) * B + b0 + (i % nb)) * hs + n;
+      P.f2[o] = sum_parts(P.ffn_parts + o, P.n_parts, MH) + P.b2[n];
+    }
+    stage_sync();
+  }
   // ---- LayerNorm 2 over the token rows, written in the (B, 6 hs) layout the heads read
   for (int i = wave; i < S6K * nb; i += FR_THREADS / 64) ln_fwd_row<2>(P.ln2, (i / nb) * B + b0 + (i % nb), lane);
   stage_sync();
@@ -349,7 +384,140 @@ __global__ __launch_bounds__(FR_THREADS) void fused_fwd_c_kernel(FusedFwdC P) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- feed-forward pair
+// See FusedFfnFwd.  Workgroup = (row block of FFN_RB rows, hidden slice of S = 32 units), 8 waves.
+//   product 1 (K = hs = 128): 12 row tiles x 2 column tiles; wave w keeps the weight fragments of column tile w >> 2 in registers and
+//     walks row tiles (w & 3), + 4, + 8 with A from the LDS image of the row block
+//   product 2 (K = S): 12 row tiles x 8 column tiles; wave w keeps the fragments of output columns 16 w.. and walks all row tiles with A
+//     from the LDS image of product 1's result
+constexpr int FFN_RB = 192, FFN_S = 32;
+constexpr int FFN_LDS_X = FFN_RB * (128 + 4), FFN_LDS_H = FFN_RB * (FFN_S + 4);
+
+struct FfnGeom { int rb0, nrows, j; };
+
+// the two products on LDS images: xs (rows, hs + 4) -> hs_ (rows, S + 4) via epi1(row, unit, value) -> partial via store2(row, col, value)
+template <typename Epi1, typename Store2>
+__device__ __forceinline__ void ffn_two_products(const float* xs, float* hs_, const float* __restrict__ b1rows /* S rows x 128, K-major */,
+                                                 int ldb1, const float* __restrict__ b2rows /* 128 rows x S, K-major */, int ldb2,
+                                                 Epi1 epi1, Store2 store2) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  {
+    // product 1: this wave's column tile ct, weights of its 16 units for the whole K = 128 in registers
+    const int ct = wave >> 2;
+    f4 bw[8];
+    const float* brow = b1rows + (int64_t)(ct * 16 + r16) * ldb1;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) bw[c] = *reinterpret_cast<const f4*>(brow + 16 * c + 4 * g);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int rt = (wave & 3) + 4 * q;
+      const float* arow = xs + (rt * 16 + r16) * (128 + 4);
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const f4 a = *reinterpret_cast<const f4*>(arow + 16 * c + 4 * g);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bw[c][s], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = rt * 16 + 4 * g + i, unit = ct * 16 + r16;
+        hs_[row * (FFN_S + 4) + unit] = epi1(row, unit, acc[i]);
+      }
+    }
+  }
+  __syncthreads();
+  {
+    // product 2: output columns 16 wave .. + 15, K = S = 32 (two chunks)
+    f4 bw[2];
+    const float* brow = b2rows + (int64_t)(wave * 16 + r16) * ldb2;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) bw[c] = *reinterpret_cast<const f4*>(brow + 16 * c + 4 * g);
+#pragma unroll 4
+    for (int rt = 0; rt < FFN_RB / 16; ++rt) {
+      const float* arow = hs_ + (rt * 16 + r16) * (FFN_S + 4);
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const f4 a = *reinterpret_cast<const f4*>(arow + 16 * c + 4 * g);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bw[c][s], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) store2(rt * 16 + 4 * g + i, wave * 16 + r16, acc[i]);
+    }
+  }
+}
+
+// rows [rb0, rb0 + nrows) of a (M, 128) matrix into the LDS image (rows past M as zeros)
+__device__ __forceinline__ void ffn_stage_x(float* xs, const float* __restrict__ X, int rb0, int M) {
+  for (int e = threadIdx.x; e < FFN_RB * 32; e += FR_THREADS) {
+    const int r = e >> 5, c = e & 31;
+    const f4 z = {0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f4*>(xs + r * (128 + 4) + 4 * c) = (rb0 + r < M) ? *reinterpret_cast<const f4*>(X + (int64_t)(rb0 + r) * 128 + 4 * c) : z;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(FR_THREADS) void fused_ffn_fwd_kernel(FusedFfnFwd P) {
+  extern __shared__ __attribute__((aligned(16))) float ffn_lds[];
+  float* xs = ffn_lds; float* hs_ = ffn_lds + FFN_LDS_X;
+  const int nsl = P.F / FFN_S;
+  const int j = (int)blockIdx.x % nsl, rb0 = ((int)blockIdx.x / nsl) * FFN_RB;
+  ffn_stage_x(xs, P.x1, rb0, P.M);
+  float* part = P.parts + (int64_t)j * P.M * P.hs;
+  ffn_two_products(xs, hs_, P.w1 + (int64_t)j * FFN_S * P.hs, P.hs, P.w2 + (int64_t)j * FFN_S, P.F,
+    [&](int row, int unit, float v) {
+      const int m = rb0 + row, n = j * FFN_S + unit;
+      v += P.b1[n];
+      v = fmaxf(v, 0.f);
+      if (P.p > 0.f) v *= drop_mul(P.p, P.seed, P.site, (uint64_t)m * P.F + n);
+      if (m < P.M) P.f1[(int64_t)m * P.F + n] = v; else v = 0.f;
+      return v;
+    },
+    [&](int row, int col, float v) { if (rb0 + row < P.M) part[(int64_t)(rb0 + row) * P.hs + col] = v; });
+}
+
+__global__ __launch_bounds__(FR_THREADS) void fused_ffn_bwd_kernel(FusedFfnBwd P) {
+  extern __shared__ __attribute__((aligned(16))) float ffn_lds[];
+  float* xs = ffn_lds; float* hs_ = ffn_lds + FFN_LDS_X;
+  const int nsl = P.F / FFN_S;
+  const int j = (int)blockIdx.x % nsl, rb0 = ((int)blockIdx.x / nsl) * FFN_RB;
+  ffn_stage_x(xs, P.d_f2, rb0, P.M);
+  float* part = P.parts + (int64_t)j * P.M * P.hs;
+  ffn_two_products(xs, hs_, P.l2_wT + (int64_t)j * FFN_S * P.hs, P.hs, P.l1_wT + (int64_t)j * FFN_S, P.F,
+    [&](int row, int unit, float v) {
+      const int m = rb0 + row, n = j * FFN_S + unit;
+      if (m >= P.M) return 0.f;
+      v *= (P.f1[(int64_t)m * P.F + n] > 0.f) ? P.gate_scale : 0.f;      // f1 is stored post-relu, post-dropout
+      P.d_f1[(int64_t)m * P.F + n] = v;
+      return v;
+    },
+    [&](int row, int col, float v) { if (rb0 + row < P.M) part[(int64_t)(rb0 + row) * P.hs + col] = v; });
+}
+
 }  // namespace
+
+int mmda_fused_ffn_fwd(const FusedFfnFwd* a, void* stream) {
+  if (!a || a->M <= 0 || a->hs != 128 || a->S != FFN_S || a->F <= 0 || (a->F % FFN_S)) return MMDA_EINVAL;
+  const int lds = (FFN_LDS_X + FFN_LDS_H) * 4;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fused_ffn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+  hipLaunchKernelGGL(fused_ffn_fwd_kernel, dim3((a->F / FFN_S) * ceil_div(a->M, FFN_RB)), dim3(FR_THREADS), lds, (hipStream_t)stream, *a);
+  MMDA_CHECK_LAUNCH("mmda_fused_ffn_fwd");
+  return MMDA_OK;
+}
+
+int mmda_fused_ffn_bwd(const FusedFfnBwd* a, void* stream) {
+  if (!a || a->M <= 0 || a->hs != 128 || a->S != FFN_S || a->F <= 0 || (a->F % FFN_S)) return MMDA_EINVAL;
+  const int lds = (FFN_LDS_X + FFN_LDS_H) * 4;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fused_ffn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+  hipLaunchKernelGGL(fused_ffn_bwd_kernel, dim3((a->F / FFN_S) * ceil_div(a->M, FFN_RB)), dim3(FR_THREADS), lds, (hipStream_t)stream, *a);
+  MMDA_CHECK_LAUNCH("mmda_fused_ffn_bwd");
+  return MMDA_OK;
+}
 
 int mmda_fused_fwd_a(const FusedFwdA* a, void* stream) {
   if (!a || a->B <= 0 || a->nb <= 0 || a->nb > 2 || a->hs != 128 || a->nhead != 2 || a->ln1.n != 128) return MMDA_EINVAL;

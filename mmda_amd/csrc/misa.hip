@@ -64,7 +64,7 @@ struct mmda_misa {
   int64_t zero_begin = 0, zero_end = 0;      // activation-gradient region that is zeroed per step
   int64_t gpad_begin = 0, gpad_end = 0;      // GRU: four-slot weight gradients (zeroed at set_workspace, re-zeroed by the unpad kernel)
   int64_t z, pmean, prstd, orig, x6, rsum, recon, dom_z, dom_h, dom, qkv, probs, ctx, attn_out, ln1_mean, ln1_rstd, x1, f1, f2,
-      ln2_mean, ln2_rstd, hfused, logits, tcp, scores, labels, losses, diff_work, touched;
+      ln2_mean, ln2_rstd, hfused, logits, tcp, scores, labels, losses, diff_work, touched, ffn_parts;
   // K-major (transposed) fp32 copies of the fusion block's weights for its input-gradient GEMMs (made once per step)
   int64_t head_wT, l2_wT, l1_wT, out_wT, in_wT, rec_wT, priv_wT, sh_wT, d1_wT = -1, d2_wT = -1, pwT[3];
   int wT_valid = 0;
@@ -281,6 +281,7 @@ int64_t layout(mmda_misa* m, int B, int T, bool commit) {
   o->f1q = k.take((int64_t)6 * B * FFN / 4); o->f1s = k.take((int64_t)6 * B * FFN / 128 + 4);
   o->w2q = k.take((int64_t)hs * FFN / 4); o->w2s = k.take((int64_t)hs * FFN / 128 + 4);
   o->diff_work = k.take(mmda_loss_diff_work_floats(B, hs));
+  o->ffn_parts = k.take((int64_t)(FFN / 32) * 6 * BH);      // partial products of the hidden-sliced feed-forward kernels (fused_rows.hip)
   o->touched = k.take((c.vocab + 3) / 4);              // one byte per embedding row: occurs in this batch (see mmda_clamp_adam_rows)
   o->head_wT = k.take((int64_t)6 * hs * NC); o->l2_wT = k.take((int64_t)FFN * hs); o->l1_wT = k.take((int64_t)hs * FFN);
   o->out_wT = k.take((int64_t)hs * hs); o->in_wT = k.take((int64_t)hs * 3 * hs); o->rec_wT = k.take((int64_t)3 * hs * hs);
@@ -1005,8 +1006,18 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
       sk_launch(x, g, n);
       if (!x.rc) x.rc = mmda_layernorm_fwd(&l1, stream);
     }
+    // feed-forward pair: one launch split over the hidden units (fused_rows.hip), its partial products summed by the stretch behind it
+    static const int ffn_fuse_on = getenv("MMDA_FFN_FUSE") ? atoi(getenv("MMDA_FFN_FUSE")) : 1;
+    const bool ffn_fuse = row_fuse && ffn_fuse_on && !m->fusion_fp8 && (FFN % 32) == 0;
     if (m->fusion_fp8) {
       if (!x.rc) x.rc = ffn_fp8(m, p_tf, seed, stream);
+    } else if (ffn_fuse) {
+      if (!x.rc) {
+        FusedFfnFwd f = {};
+        f.M = 6 * B; f.hs = hs; f.F = FFN; f.S = 32; f.x1 = WS(m->x1); f.w1 = PP(m->l1_w); f.b1 = PP(m->l1_b); f.f1 = WS(m->f1);
+        f.p = p_tf; f.seed = seed; f.site = SITE_FFN; f.w2 = PP(m->l2_w); f.parts = WS(m->ffn_parts);
+        x.rc = mmda_fused_ffn_fwd(&f, stream);
+      }
     } else {
       g[0] = sk_nt(6 * B, FFN, hs, WS(m->x1), hs, PP(m->l1_w), PP(m->l1_b), WS(m->f1), FFN, MMDA_ACT_RELU);
       g[0].drop_p = p_tf; g[0].drop_seed = seed; g[0].drop_site = SITE_FFN;
@@ -1022,6 +1033,7 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
       if (!x.rc) {
         FusedFwdC f = {};
         f.B = B; f.hs = hs; f.ncls = c.ncls; f.nb = fuse_nb; f.ln2 = l2;
+        if (ffn_fuse) { f.ffn_parts = WS(m->ffn_parts); f.n_parts = FFN / 32; f.b2 = PP(m->l2_b); f.f2 = WS(m->f2); }
         f.hfused = WS(m->hfused); f.head_w = PP(m->head_w); f.head_b = PP(m->head_b); f.logits = WS(m->logits);
         f.threshold = c.threshold; f.tcp = WS(m->tcp); f.scores = WS(m->scores); f.labels = WS(m->labels);
         f.p_cls = p_cls; f.seed = seed; f.site_cls = SITE_CLS;
@@ -1206,19 +1218,32 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
     lin_dw(x, fmode, B, NC, 6 * hs, WS(m->d_logits), WS(m->hfused), GG(m->head_w), GG(m->head_b));
     // FFN
     // d f1 = (d f2 W2) * [f1 > 0] / (1-p): f1 is stored post-relu, post-dropout, so f1 > 0 <=> kept and pre-activation > 0
-    g[0] = wt ? sk_dx(6 * B, hs, FFN, WS(m->d_f2), hs, WS(m->l2_wT), WS(m->d_f1), FFN, 0)
-              : sk_nn(6 * B, hs, FFN, WS(m->d_f2), hs, PP(m->l2_w), WS(m->d_f1), FFN, 0);
-    g[0].gate = WS(m->f1); g[0].ldgate = FFN; g[0].gate_scale = p_tf > 0.f ? 1.f / (1.f - p_tf) : 1.f;
-    sk_launch(x, g, 1);
+    static const int ffn_fuse_on = getenv("MMDA_FFN_FUSE") ? atoi(getenv("MMDA_FFN_FUSE")) : 1;
+    const bool ffn_fuse = row_fuse && ffn_fuse_on && (FFN % 32) == 0;
+    if (ffn_fuse) {
+      if (!x.rc) {
+        FusedFfnBwd f = {};
+        f.M = 6 * B; f.hs = hs; f.F = FFN; f.S = 32; f.d_f2 = WS(m->d_f2); f.f1 = WS(m->f1);
+        f.gate_scale = p_tf > 0.f ? 1.f / (1.f - p_tf) : 1.f; f.l2_wT = WS(m->l2_wT); f.d_f1 = WS(m->d_f1); f.l1_wT = WS(m->l1_wT);
+        f.parts = WS(m->ffn_parts);
+        x.rc = mmda_fused_ffn_bwd(&f, stream);
+      }
+    } else {
+      g[0] = wt ? sk_dx(6 * B, hs, FFN, WS(m->d_f2), hs, WS(m->l2_wT), WS(m->d_f1), FFN, 0)
+                : sk_nn(6 * B, hs, FFN, WS(m->d_f2), hs, PP(m->l2_w), WS(m->d_f1), FFN, 0);
+      g[0].gate = WS(m->f1); g[0].ldgate = FFN; g[0].gate_scale = p_tf > 0.f ? 1.f / (1.f - p_tf) : 1.f;
+      sk_launch(x, g, 1);
+      g[0] = wt ? sk_dx(6 * B, FFN, hs, WS(m->d_f1), FFN, WS(m->l1_wT), WS(m->d_x1), hs, 1)
+                : sk_nn(6 * B, FFN, hs, WS(m->d_f1), FFN, PP(m->l1_w), WS(m->d_x1), hs, 1);
+      sk_launch(x, g, 1);
+    }
     lin_dw(x, fmode, 6 * B, hs, FFN, WS(m->d_f2), WS(m->f1), GG(m->l2_w), GG(m->l2_b));
-    g[0] = wt ? sk_dx(6 * B, FFN, hs, WS(m->d_f1), FFN, WS(m->l1_wT), WS(m->d_x1), hs, 1)
-              : sk_nn(6 * B, FFN, hs, WS(m->d_f1), FFN, PP(m->l1_w), WS(m->d_x1), hs, 1);
-    sk_launch(x, g, 1);
     lin_dw(x, fmode, 6 * B, FFN, hs, WS(m->d_f1), WS(m->x1), GG(m->l1_w), GG(m->l1_b));
     // norm1 + self-attention ... projection LayerNorms
     if (row_fuse && !x.rc) {
       FusedBwdA f = {};
       f.B = B; f.hs = hs; f.nhead = NHEAD; f.nb = fuse_nb;
+      if (ffn_fuse) { f.ffn_parts = WS(m->ffn_parts); f.n_parts = FFN / 32; f.d_x1 = WS(m->d_x1); }
       mmda_ln_bwd_args& l = f.ln1;
       l.rows = 6 * B; l.n = hs; l.dy = WS(m->d_x1); l.x = WS(m->x6); l.res = WS(m->attn_out); l.gamma = PP(m->n1_w);
       l.mean = WS(m->ln1_mean); l.rstd = WS(m->ln1_rstd); l.d_x = WS(m->d_x6); l.accumulate_dx = 1; l.d_res = WS(m->d_attn_out);
