@@ -386,11 +386,11 @@ __global__ __launch_bounds__(FR_THREADS) void fused_fwd_c_kernel(FusedFwdC P) {
 
 // ---------------------------------------------------------------------------------------------------------------- feed-forward pair
 // See FusedFfnFwd.  Workgroup = (row block of FFN_RB rows, hidden slice of S = 32 units), 8 waves.
-//   product 1 (K = hs = 128): 12 row tiles x 2 column tiles; wave w keeps the weight fragments of column tile w >> 2 in registers and
-//     walks row tiles (w & 3), + 4, + 8 with A from the LDS image of the row block
-//   product 2 (K = S): 12 row tiles x 8 column tiles; wave w keeps the fragments of output columns 16 w.. and walks all row tiles with A
+//   product 1 (K = hs = 128): FFN_RB / 16 row tiles x 2 column tiles; wave w keeps the weight fragments of column tile w >> 2 in registers
+//     and walks row tiles (w & 3), + 4, ... with A from the LDS image of the row block
+//   product 2 (K = S): FFN_RB / 16 row tiles x 8 column tiles; wave w keeps the fragments of output columns 16 w.. and walks all row tiles with A
 //     from the LDS image of product 1's result
-constexpr int FFN_RB = 192, FFN_S = 32;
+constexpr int FFN_RB = 48, FFN_S = 32;       // rows per workgroup (launch time at B=32: 21 us with 192, 12.7 with 96 or 48; B=256 step 2.227 / 2.210 / 2.200 ms)
 constexpr int FFN_LDS_X = FFN_RB * (128 + 4), FFN_LDS_H = FFN_RB * (FFN_S + 4);
 
 struct FfnGeom { int rb0, nrows, j; };
@@ -410,8 +410,9 @@ __device__ __forceinline__ void ffn_two_products(const float* xs, float* hs_, co
 #pragma unroll
     for (int c = 0; c < 8; ++c) bw[c] = *reinterpret_cast<const f4*>(brow + 16 * c + 4 * g);
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < (FFN_RB / 16 + 3) / 4; ++q) {
       const int rt = (wave & 3) + 4 * q;
+      if (rt >= FFN_RB / 16) break;                      // wave-uniform
       const float* arow = xs + (rt * 16 + r16) * (128 + 4);
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -434,7 +435,7 @@ __device__ __forceinline__ void ffn_two_products(const float* xs, float* hs_, co
     const float* brow = b2rows + (int64_t)(wave * 16 + r16) * ldb2;
 #pragma unroll
     for (int c = 0; c < 2; ++c) bw[c] = *reinterpret_cast<const f4*>(brow + 16 * c + 4 * g);
-#pragma unroll 4
+#pragma unroll
     for (int rt = 0; rt < FFN_RB / 16; ++rt) {
       const float* arow = hs_ + (rt * 16 + r16) * (FFN_S + 4);
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -452,10 +453,18 @@ __device__ __forceinline__ void ffn_two_products(const float* xs, float* hs_, co
 
 // rows [rb0, rb0 + nrows) of a (M, 128) matrix into the LDS image (rows past M as zeros)
 __device__ __forceinline__ void ffn_stage_x(float* xs, const float* __restrict__ X, int rb0, int M) {
-  for (int e = threadIdx.x; e < FFN_RB * 32; e += FR_THREADS) {
-    const int r = e >> 5, c = e & 31;
+  constexpr int PER = FFN_RB * 32 / FR_THREADS;         // float4 per thread, all loads issued before the first LDS store
+  f4 v[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int e = threadIdx.x + u * FR_THREADS, r = e >> 5, c = e & 31;
+    v[u] = *reinterpret_cast<const f4*>(X + (int64_t)min(rb0 + r, M - 1) * 128 + 4 * c);
+  }
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int e = threadIdx.x + u * FR_THREADS, r = e >> 5, c = e & 31;
     const f4 z = {0.f, 0.f, 0.f, 0.f};
-    *reinterpret_cast<f4*>(xs + r * (128 + 4) + 4 * c) = (rb0 + r < M) ? *reinterpret_cast<const f4*>(X + (int64_t)(rb0 + r) * 128 + 4 * c) : z;
+    *reinterpret_cast<f4*>(xs + r * (128 + 4) + 4 * c) = (rb0 + r < M) ? v[u] : z;
   }
   __syncthreads();
 }
