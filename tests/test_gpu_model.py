@@ -622,3 +622,42 @@ def test_rrelu_training_mode_draws_slopes_and_replays_them_in_backward():
         assert abs(fd - float(g[i, j])) <= 5e-2 * abs(float(g[i, j])) + 1e-4, (fd, float(g[i, j]))
     finally:
         mm.FUSION_DROPOUT = mm_fd
+
+
+@pytest.mark.parametrize("switches", [{"MMDA_ROW_FUSE": "0"}, {"MMDA_FFN_FUSE": "0"}, {"MMDA_GEMM_TN": "0"}, {"MMDA_LSTM_NO_QUAD": "1"},
+                                      {"MMDA_ROW_FUSE": "0", "MMDA_GEMM_TN": "0", "MMDA_LSTM_NO_QUAD": "1"}],
+                         ids=["stand_alone_fusion_launches", "skinny_feed_forward", "nt_weight_gradients", "one_wave_per_tile", "all_round1_forms"])
+def test_ablation_switches_take_the_replaced_launches_and_agree(switches):
+    """Every fused / re-formed path of round 2 keeps the launches it replaced behind a switch (they are also what the configurations
+    outside its preconditions run: the adversarial branch, large batches, fp8 feed-forward).  One bf16 training step (no optimizer) in
+    a fresh process under each switch: the whole gradient bucket and the losses agree with the default path to summation-order noise."""
+    import os, subprocess, sys, tempfile
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from oracle import misa_oracle as orc
+from mmda_amd import make_config, MISA
+cfg = orc.default_config(vocab_size=120, dropout=0.0)
+c = make_config(precision="bf16", device="cuda:0", **vars(cfg))
+m = MISA(c); m.load_state_dict(orc.synth_params(cfg, 4)); m.to("cuda:0")
+b = orc.synth_batch(cfg, 32, 14, 21, ragged=True)
+m.train_step(b["t"].cuda(), b["v"].cuda(), b["a"].cuda(), b["l"], b["emo"].cuda(), lr=0.0, clip=1.0, do_adam=False, training=False)
+torch.cuda.synchronize()
+assert not m.cluster_aborted()
+G = m.flat_buckets()[1].cpu().numpy()
+L = m.read_losses()
+np.savez(sys.argv[1], G=G, L=np.array([float(L[k]) for k in ("cls", "diff", "sim", "recon", "total")]))
+''' % (ROOT, os.path.join(ROOT, "tests"))
+    outs = []
+    with tempfile.TemporaryDirectory() as d:
+        for i, env in enumerate(({}, switches)):
+            f = os.path.join(d, f"o{i}.npz")
+            r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+            z = np.load(f)
+            outs.append((z["G"], z["L"]))
+    (G0, L0), (G1, L1) = outs
+    assert np.isfinite(G1).all() and np.abs(G0).max() > 0
+    assert np.linalg.norm(G1 - G0) <= 2e-3 * np.linalg.norm(G0), np.linalg.norm(G1 - G0) / np.linalg.norm(G0)
+    assert np.abs(L1 - L0).max() <= 1e-4 * np.abs(L0).max()
