@@ -74,7 +74,7 @@ struct mmda_misa {
   // fused train step without a gradient exchange: clamp+Adam of the bucket prefix whose gradients are final beside the layer-1 backward
   // recurrence runs there, on the side stream (set by mmda_misa_train_step around its backward pass)
   int adam_early_on = 0; float ae_lr = 0.f, ae_clip = 0.f; int ae_step = 0; int64_t adam_early_done = 0;
-  int tn_wgrad = 0;                // this step's weight-gradient GEMMs read dG / inputs / hseq as they lie (tn form): no transposed copies
+  int tn_wgrad = 0;                // bit l: layer l + 1's weight-gradient GEMMs read dG / inputs / hseq as they lie (tn form): no transposed copies
   int embed_early_done = 0;        // this step's early optimizer pass also covered the embedding rows the batch does not touch
   int wT_pending = 0;              // the K-major fusion-weight copies of this step are still to be made (on the next fork)
   int fusion_fp8 = 0;
@@ -654,14 +654,14 @@ int backward_only_jobs(mmda_misa* m, mmda_convert_job* cj) {
     Mod& md = m->mod[i];
     for (int l = 0; l < 2; ++l) {
       Rnn& r = md.rnn[l];
-      if (m->tn_wgrad) {
+      if ((m->tn_wgrad >> l) & 1) {
         for (int d = 0; d < 2; ++d)
           cj[n++] = mmda_convert_job{WS(md.hseq[l]) + d * md.H, 2 * md.H, R, md.H, nullptr, WS(r.hbp[d]), r.ldH, nullptr, 0};
       } else {
         cj[n++] = mmda_convert_job{WS(md.hseq[l]), 2 * md.H, R, 2 * md.H, nullptr, nullptr, 0, WS(r.hbT), m->ldR};
       }
     }
-    if (!m->tn_wgrad) cj[n++] = mmda_convert_job{WS(md.normed), 2 * md.H, R, 2 * md.H, nullptr, nullptr, 0, WS(md.rnn[1].xbT), m->ldR};
+    if (!(m->tn_wgrad & 2)) cj[n++] = mmda_convert_job{WS(md.normed), 2 * md.H, R, 2 * md.H, nullptr, nullptr, 0, WS(md.rnn[1].xbT), m->ldR};
   }
   return n;
 }
@@ -790,8 +790,13 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
   // conversions it saves.  MMDA_GEMM_TN=0: the transposed-copy (nt) form everywhere; MMDA_GEMM_TN_MAX_ROWS moves the limit.
   static const int tn_on = getenv("MMDA_GEMM_TN") ? atoi(getenv("MMDA_GEMM_TN")) : 1;
   static const int tn_max_rows = getenv("MMDA_GEMM_TN_MAX_ROWS") ? atoi(getenv("MMDA_GEMM_TN_MAX_ROWS")) : 4096;
-  const bool tnw = bfg && gm && tn_on && !late_t && (B % 8) == 0 && R <= tn_max_rows && probe_resident(1, 2);
-  m->tn_wgrad = (tnw && !inf) ? 1 : 0;
+  // (Layer 1 alone in the tn form beyond that limit -- its transposed gate-gradient copy, 0.2 ms at B=256, is the one that cannot hide
+  // beside a recurrence -- measured slower too: B=128 1.285 -> 1.315 ms, B=256 2.20 -> 2.29, T=500 3.92 -> 3.96.  MMDA_GEMM_TN_L1=1.)
+  static const int tn_l1 = getenv("MMDA_GEMM_TN_L1") ? atoi(getenv("MMDA_GEMM_TN_L1")) : 0;
+  const bool tn_any = bfg && gm && tn_on && !late_t && (B % 8) == 0 && probe_resident(1, 2);
+  const bool tnw = tn_any && R <= tn_max_rows;
+  const bool tn_ok = tnw || (tn_any && tn_l1);           // layer 1 in the tn form
+  m->tn_wgrad = (tn_ok && !inf) ? (tnw ? 3 : 1) : 0;
   auto first_jobs = [&](bool plain, bool transposed, mmda_convert_job* cj) -> int {
     int n = 0;
     for (int i = 0; i < 3; ++i) {
@@ -802,7 +807,7 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
       }
       Rnn& r0 = m->mod[i].rnn[0];
       const float* src = i == 0 ? PP(m->embed) : xin[i];
-      const bool xt = transposed && !tnw;
+      const bool xt = transposed && !tn_ok;              // layer-1 inputs transposed: only the nt form of layer 1's dW_ih reads them
       if (plain || xt)
         cj[n++] = mmda_convert_job{src, r0.D, R, r0.D, i == 0 ? t_ids : nullptr, plain ? WS(r0.xb) : nullptr, plain ? r0.ldD : 0,
                                    xt ? WS(r0.xbT) : nullptr, xt ? ldR : 0};
@@ -1527,7 +1532,7 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
                                 m->ldR};
       if (kdg) { dgj[i].src = WS(r.dgb); dgj[i].ld = r.ldG; dgj[i].src_bf16 = 1; }
     }
-    const bool tn = bfg && m->tn_wgrad != 0;           // weight gradients straight from dG / inputs / hseq as they lie (no dG^T)
+    const bool tn = bfg && ((m->tn_wgrad >> l) & 1);   // weight gradients straight from dG / inputs / hseq as they lie (no dG^T)
     if (tn && !kdg) return MMDA_EINVAL;                // (forward() set tn_wgrad only where the recurrent kernel writes bf16 dG)
     const bool dg_on_side = bfg && kdg && l == 1 && dw_overlap && m->use_side && !tn;
     if (bfg && !dg_on_side && !tn) {
