@@ -589,6 +589,7 @@ __global__ __launch_bounds__(1024) void cmd_stream_kernel(const float* __restric
   for (int t = 0; t < 3; ++t) {
     float s = 0.f;
     if (t < pl.nt && c_ok)
+#pragma unroll 8
       for (int r = rg; r < B; r += 8) s += x[(int64_t)t * stride + (int64_t)r * D + cc];
     P1[(rg * 3 + t) * 128 + c] = s;
   }
@@ -605,6 +606,7 @@ __global__ __launch_bounds__(1024) void cmd_stream_kernel(const float* __restric
   for (int t = 0; t < 3; ++t) {
     float q2 = 0.f, q3 = 0.f, q4 = 0.f, q5 = 0.f;
     if (t < pl.nt && c_ok)
+#pragma unroll 8
       for (int r = rg; r < B; r += 8) {
         const float d = x[(int64_t)t * stride + (int64_t)r * D + cc] - mom[t][0];
         const float d2 = d * d;
@@ -672,6 +674,7 @@ __global__ __launch_bounds__(1024) void cmd_stream_kernel(const float* __restric
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
     if (!(t < pl.nt && c_ok)) continue;
+#pragma unroll 8
     for (int r = rg; r < B; r += 8) {
       const int64_t o = (int64_t)t * stride + (int64_t)r * D + c;
       const float d = x[o] - mom[t][0];
