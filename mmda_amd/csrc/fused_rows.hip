@@ -18,16 +18,30 @@ constexpr int FR_THREADS = 512;
 // arow == nullptr: a zero row.  K % 16 == 0, rows 16-byte aligned.  Rounds of eight 16-deep chunks; the loads of round r + 1 are issued
 // before the MFMAs of round r (two register sets: a stage is a chain of memory latencies, the MFMAs hide behind the next one).
 struct MacRound { f4 a[8], b[8]; };
-// one round = 128 of the reduction: eight 16-deep chunks, a lane's float4 at k = 16 c + 4 (lane >> 4) feeds component s to the s-th MFMA.
-// The A rows of a stage are staged in LDS once per workgroup (stage_rows): all eight waves multiply the same <= 16 rows, and what bounds
-// a stage is the volume of loads one CU can pull through its memory pipeline -- the weights (B), which every wave needs its own
-// columns of, stay global -> registers.  arow == nullptr: a zero row (no read at all).
-__device__ __forceinline__ void mac_load(MacRound& R, const float* arow /* LDS */, const float* __restrict__ brow, int g) {
+// One round = 128 of the reduction for a 16 x 16 tile: A rows from the workgroup's LDS image (stage_rows), the wave's 16 weight rows
+// from global THROUGH a wave-private LDS block.  Read straight into the fragment layout, the 16 rows of a wave are sixteen 64-byte
+// requests per load instruction, and the rate at which a CU's memory pipeline takes requests (not bytes) is what paces a stage; read as
+// the lines lie -- lane l takes 16 bytes at offset 16 l of two whole 512-byte row segments per instruction -- they are eight 128-byte
+// requests, and the fragments come out of LDS (rows 132 floats apart: the sixteen rows of a b128 read on distinct banks).
+constexpr int WL_LD = 128 + 4;
+struct WRows { f4 g[8]; };
+// issue the loads of one round: `bblk` = first of the wave's 16 weight rows at the round's k, `ldb` = floats between rows
+__device__ __forceinline__ void wrows_load(WRows& W, const float* __restrict__ bblk, int ldb, int lane) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) W.g[j] = *reinterpret_cast<const f4*>(bblk + (int64_t)(2 * j + (lane >> 5)) * ldb + 4 * (lane & 31));
+}
+__device__ __forceinline__ void wrows_to_lds(const WRows& W, float* wl, int lane) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) *reinterpret_cast<f4*>(wl + (2 * j + (lane >> 5)) * WL_LD + 4 * (lane & 31)) = W.g[j];
+}
+// a lane's float4 at k = 16 c + 4 (lane >> 4) of its row feeds component s to the (c, s)-th MFMA (a permutation of k that A and B share)
+__device__ __forceinline__ void mac_frags(MacRound& R, const float* arow /* LDS or nullptr = zero row */, const float* wl, int lane) {
+  const int r16 = lane & 15, g = lane >> 4;
   const f4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     R.a[c] = arow ? *reinterpret_cast<const f4*>(arow + 16 * c + 4 * g) : z;
-    R.b[c] = *reinterpret_cast<const f4*>(brow + 16 * c + 4 * g);
+    R.b[c] = *reinterpret_cast<const f4*>(wl + r16 * WL_LD + 16 * c + 4 * g);
   }
 }
 __device__ __forceinline__ void mac_run(f32x4& acc, const MacRound& R) {
@@ -36,19 +50,20 @@ __device__ __forceinline__ void mac_run(f32x4& acc, const MacRound& R) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(R.a[c][s], R.b[c][s], acc, 0, 0, 0);
 }
-// NR rounds into one accumulator; round r multiplies A row ar[r] (or zeros) with Bt row br[r], both already advanced to the round's k.
-// The loads of round r + 1 are issued before the MFMAs of round r (a third register set, two rounds ahead, measured no faster).
+// NR rounds into one accumulator; round r multiplies A row ar[r] (LDS; nullptr = zeros) with the wave's 16 weight rows at bblk[r] (row
+// stride ldb[r]).  The global loads of round r + 1 are in flight while round r's fragments are read and multiplied.
 template <int NR>
-__device__ __forceinline__ void tile_mac_chain(f32x4& acc, const float* const (&ar)[NR], const float* const (&br)[NR], int lane) {
-  const int g = lane >> 4;
-  MacRound R0, R1;
-  mac_load(R0, ar[0], br[0], g);
+__device__ __forceinline__ void tile_mac_chain(f32x4& acc, const float* const (&ar)[NR], const float* const (&bblk)[NR], const int (&ldb)[NR],
+                                               int lane, float* wl /* this wave's 16 x WL_LD floats of LDS */) {
+  WRows W;
+  MacRound R;
+  wrows_load(W, bblk[0], ldb[0], lane);
 #pragma unroll
-  for (int r = 0; r < NR; r += 2) {
-    if (r + 1 < NR) mac_load(R1, ar[r + 1], br[r + 1], g);
-    mac_run(acc, R0);
-    if (r + 2 < NR) mac_load(R0, ar[r + 2], br[r + 2], g);
-    if (r + 1 < NR) mac_run(acc, R1);
+  for (int r = 0; r < NR; ++r) {
+    wrows_to_lds(W, wl, lane);                           // (the previous round's fragment reads are in registers: program order in LDS)
+    if (r + 1 < NR) wrows_load(W, bblk[r + 1], ldb[r + 1], lane);
+    mac_frags(R, ar[r], wl, lane);
+    mac_run(acc, R);
   }
 }
 
@@ -146,6 +161,7 @@ __global__ __launch_bounds__(FR_THREADS) void fused_bwd_c_kernel(FusedBwdC P) {
 __global__ __launch_bounds__(FR_THREADS) void fused_bwd_a_kernel(FusedBwdA P) {
   __shared__ float red[2 * 8 * 128];
   __shared__ __attribute__((aligned(16))) float lds_a[LDS_A_FLOATS];
+  __shared__ __attribute__((aligned(16))) float lds_w[8 * 16 * WL_LD];
   const int b0 = (int)blockIdx.x * P.nb;
   const int nb = min(P.nb, P.B - b0);
   const int B = P.B, hs = P.hs;
@@ -179,8 +195,9 @@ __global__ __launch_bounds__(FR_THREADS) void fused_bwd_a_kernel(FusedBwdA P) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     stage_rows(lds_a, ntok, hs, [&](int r) { return P.d_attn_out + ((int64_t)(r / nb) * B + b0 + (r % nb)) * hs; });
     const float* const ar[1] = {rok ? lds_a + r16 * (hs + 4) : nullptr};
-    const float* const br[1] = {P.out_wT + (int64_t)col * hs};
-    tile_mac_chain<1>(acc, ar, br, lane);
+    const float* const bb[1] = {P.out_wT + (int64_t)wave * 16 * hs};
+    const int ld[1] = {hs};
+    tile_mac_chain<1>(acc, ar, bb, ld, lane, lds_w + wave * 16 * WL_LD);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = 4 * g + i;
@@ -204,12 +221,13 @@ __global__ __launch_bounds__(FR_THREADS) void fused_bwd_a_kernel(FusedBwdA P) {
     stage_rows(lds_r, ntok, hs, [&](int r) { return P.d_recon + ((int64_t)((r / nb) % 3) * B + b0 + (r % nb)) * hs; });
     const float* rec_row = rok ? lds_r + r16 * (hs + 4) : nullptr;
     const float* qrow = rok ? lds_a + r16 * (3 * hs + 4) : nullptr;
-    const float* wrow = P.in_wT + (int64_t)col * 3 * hs;
+    const float* wrow = P.in_wT + (int64_t)wave * 16 * 3 * hs;
     const float* const ar[6] = {qrow, qrow ? qrow + 128 : nullptr, qrow ? qrow + 256 : nullptr, (rok && tj % 3 == 0) ? rec_row : nullptr,
                                 (rok && tj % 3 == 1) ? rec_row : nullptr, (rok && tj % 3 == 2) ? rec_row : nullptr};
-    const float* const br[6] = {wrow, wrow + 128, wrow + 256, P.rec_wT + (int64_t)col * hs, P.rec_wT + (int64_t)hs * hs + (int64_t)col * hs,
-                                P.rec_wT + (int64_t)2 * hs * hs + (int64_t)col * hs};
-    tile_mac_chain<6>(acc, ar, br, lane);
+    const float* recw = P.rec_wT + (int64_t)wave * 16 * hs;
+    const float* const bb[6] = {wrow, wrow + 128, wrow + 256, recw, recw + (int64_t)hs * hs, recw + (int64_t)2 * hs * hs};
+    const int ld[6] = {3 * hs, 3 * hs, 3 * hs, hs, hs, hs};
+    tile_mac_chain<6>(acc, ar, bb, ld, lane, lds_w + wave * 16 * WL_LD);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = 4 * g + i;
@@ -233,9 +251,10 @@ __global__ __launch_bounds__(FR_THREADS) void fused_bwd_a_kernel(FusedBwdA P) {
     const float* prow = mok ? lds_a + r16 * (hs + 4) : nullptr;
     const float* const ar[4] = {mok ? lds_a + (nmod + r16) * (hs + 4) : nullptr, (mok && mi == 0) ? prow : nullptr,
                                 (mok && mi == 1) ? prow : nullptr, (mok && mi == 2) ? prow : nullptr};
-    const float* const br[4] = {P.sh_wT + (int64_t)col * hs, P.priv_wT + (int64_t)col * hs, P.priv_wT + (int64_t)hs * hs + (int64_t)col * hs,
-                                P.priv_wT + (int64_t)2 * hs * hs + (int64_t)col * hs};
-    tile_mac_chain<4>(acc, ar, br, lane);
+    const float* pw = P.priv_wT + (int64_t)wave * 16 * hs;
+    const float* const bb[4] = {P.sh_wT + (int64_t)wave * 16 * hs, pw, pw + (int64_t)hs * hs, pw + (int64_t)2 * hs * hs};
+    const int ld[4] = {hs, hs, hs, hs};
+    tile_mac_chain<4>(acc, ar, bb, ld, lane, lds_w + wave * 16 * WL_LD);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = 4 * g + i;
@@ -270,6 +289,7 @@ __global__ __launch_bounds__(FR_THREADS) void fused_bwd_a_kernel(FusedBwdA P) {
 // one round with the A row formed as the sum of two rows (private + shared)
 __global__ __launch_bounds__(FR_THREADS) void fused_fwd_a_kernel(FusedFwdA P) {
   __shared__ __attribute__((aligned(16))) float lds_a[LDS_A_FLOATS];
+  __shared__ __attribute__((aligned(16))) float lds_w[8 * 16 * WL_LD];
   const int b0 = (int)blockIdx.x * P.nb;
   const int nb = min(P.nb, P.B - b0);
   const int B = P.B, hs = P.hs;
@@ -293,8 +313,10 @@ __global__ __launch_bounds__(FR_THREADS) void fused_fwd_a_kernel(FusedFwdA P) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const float* srow = mok ? lds_a + (12 + r16) * (hs + 4) : nullptr;
     const float* const ar[3] = {(mok && mi == 0) ? srow : nullptr, (mok && mi == 1) ? srow : nullptr, (mok && mi == 2) ? srow : nullptr};
-    const float* const br[3] = {P.rec_w + (int64_t)col * hs, P.rec_w + (int64_t)hs * hs + (int64_t)col * hs, P.rec_w + (int64_t)2 * hs * hs + (int64_t)col * hs};
-    tile_mac_chain<3>(acc, ar, br, lane);
+    const float* rw = P.rec_w + (int64_t)wave * 16 * hs;
+    const float* const bb[3] = {rw, rw + (int64_t)hs * hs, rw + (int64_t)2 * hs * hs};
+    const int ld[3] = {hs, hs, hs};
+    tile_mac_chain<3>(acc, ar, bb, ld, lane, lds_w + wave * 16 * WL_LD);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = 4 * g + i;
@@ -307,8 +329,9 @@ __global__ __launch_bounds__(FR_THREADS) void fused_fwd_a_kernel(FusedFwdA P) {
     const int n = pass * 128 + col;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const float* const ar[1] = {rok ? lds_a + r16 * (hs + 4) : nullptr};
-    const float* const br[1] = {P.in_w + (int64_t)n * hs};
-    tile_mac_chain<1>(acc, ar, br, lane);
+    const float* const bb[1] = {P.in_w + (int64_t)(pass * 128 + wave * 16) * hs};
+    const int ld[1] = {hs};
+    tile_mac_chain<1>(acc, ar, bb, ld, lane, lds_w + wave * 16 * WL_LD);
     const float bias = P.in_b[n];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -326,8 +349,9 @@ __global__ __launch_bounds__(FR_THREADS) void fused_fwd_a_kernel(FusedFwdA P) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     stage_rows(lds_a, ntok, hs, [&](int r) { return P.ctx + ((int64_t)(r / nb) * B + b0 + (r % nb)) * hs; });
     const float* const ar[1] = {rok ? lds_a + r16 * (hs + 4) : nullptr};
-    const float* const br[1] = {P.out_w + (int64_t)col * hs};
-    tile_mac_chain<1>(acc, ar, br, lane);
+    const float* const bb[1] = {P.out_w + (int64_t)wave * 16 * hs};
+    const int ld[1] = {hs};
+    tile_mac_chain<1>(acc, ar, bb, ld, lane, lds_w + wave * 16 * WL_LD);
     const float bias = P.out_b[col];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
