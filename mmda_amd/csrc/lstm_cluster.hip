@@ -1599,7 +1599,6 @@ __global__ __launch_bounds__(256, 4) void lstm_fwd_quad_kernel(CLaunch L) {   //
         const unsigned cl = chk[j] ? tm : 0u;
         af[j] = __builtin_bit_cast(bf16x8, u32x4{fa[j][0] ^ cl, fa[j][1] ^ cl, fa[j][2] ^ cl, fa[j][3] ^ cl});
       }
-      flush(step - 1, Pp);
       f32x4 acc[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1653,6 +1652,10 @@ __global__ __launch_bounds__(256, 4) void lstm_fwd_quad_kernel(CLaunch L) {   //
         if (lane == 0) { if (fst) st_flag_plain(my_flag, epoch); else st_flag(my_flag, epoch); }
       }
     }
+    // the stash of THIS step and the pre-activations of step + 2 (into the buffer this step used), behind the publish: the wave has
+    // nothing to do until its neighbours' h arrives
+    flush(step, P);
+    (void)Pp;
   };
   {
     typedef std::integral_constant<bool, true> TrueT;
@@ -1677,7 +1680,6 @@ __global__ __launch_bounds__(256, 4) void lstm_fwd_quad_kernel(CLaunch L) {   //
       }
       if (step < T) { do_step(step, pre[1], pre[0], FalseT{}, FmThrough{}); ++step; }
     }
-    if (T > 0) flush(T - 1, (T - 1) & 1 ? pre[1] : pre[0]);
   }
   // final hidden state straight into the utterance layout [h1_fwd, h2_fwd, h1_bwd, h2_bwd] (models.py:203)
   if (inb) D.utt[(int64_t)b * 4 * H + (dir * 2 + D.layer) * H + col] = h_reg;
