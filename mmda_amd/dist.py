@@ -38,6 +38,11 @@ class DataParallelSync:
         # every rank holds a batch of the same (B, T) on every step (benchmarks): the row counts need not be exchanged first
         self.equal_shapes = bool(equal_shapes)
         self._comm = None
+        # Optional optimizer hook for the early prefix: `early_step(n_floats, stream)` is called on the communication stream right behind
+        # the early all-reduce (the prefix's gradients are then final and summed), and `early_stepped` tells the caller how many leading
+        # floats of the bucket have been stepped already.  Set per step by the model's fused path; None = no early step.
+        self.early_step = None
+        self.early_stepped = 0
 
     def broadcast_parameters(self, model):
         """Rank 0's weights everywhere (one broadcast of the flat bucket when the model has one)."""
@@ -128,6 +133,7 @@ class DataParallelSync:
         recurrent layers; the native step records an event behind it) is all-reduced as soon as that event fires -- the recurrence
         leaves more than half of the CUs idle -- and the remainder (layer 1; the embedding gradient in its dense or its (ids, rows)
         form) behind the step's last kernel.  The calling stream waits for the communication stream before the optimizer runs."""
+        self.early_stepped = 0
         if self.world == 1:
             return 1.0
         n = flat_grads.numel()
@@ -149,6 +155,11 @@ class DataParallelSync:
             model.wait_early_grads(self._comm)
             with torch.cuda.stream(self._comm):
                 self._all_reduce(flat_grads[:early])
+                if self.early_step is not None:
+                    # clip + Adam of the prefix while the rest of the backward pass is still running on the main stream (nothing issued
+                    # after the early event reads these fp32 parameters; the single-GPU fused step does the same on its side stream)
+                    self.early_step(early, self._comm)
+                    self.early_stepped = early
         self._comm.wait_stream(cur)                   # the rest is final once everything issued so far is through
         with torch.cuda.stream(self._comm):
             self._all_reduce_chunked(flat_grads[early:end])

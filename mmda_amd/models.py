@@ -459,11 +459,35 @@ class MISA(nn.Module):
         elif do_adam and grad_sync is not None:
             # (bucket, dense_floats, model) or a plain (bucket, dense_floats) callable: decided from its signature, once -- never by
             # retrying after a TypeError, which could come from inside the exchange after a collective was already issued
-            if _takes_model(grad_sync):
-                scale = grad_sync(self._G, self._dense_floats, self)
+            # A DataParallelSync (mmda_amd/dist.py) steps the early-reduced prefix of the bucket on its communication stream, beside the
+            # rest of the backward pass; the remainder is stepped here, behind the exchange.
+            owner = getattr(grad_sync, "__self__", None)
+            hook = owner is not None and hasattr(owner, "early_step") and hasattr(owner, "early_stepped") and hasattr(owner, "world")
+            if hook:
+                gs = 1.0 / float(owner.world)
+                step_no = max(self._step, 1)
+
+                def _early(n_floats, stream, _gs=gs, _k=step_no):
+                    _lib.check(self._lib.mmda_clamp_adam(self._P.data_ptr(), self._G.data_ptr(), self._M.data_ptr(), self._V.data_ptr(),
+                                                         int(n_floats), lr, 0.9, 0.999, 1e-8, clip, _gs, _k, stream.cuda_stream), "adam(early)")
+                owner.early_step = _early
+            try:
+                if _takes_model(grad_sync):
+                    scale = grad_sync(self._G, self._dense_floats, self)
+                else:
+                    scale = grad_sync(self._G, self._dense_floats)
+            finally:
+                if hook:
+                    owner.early_step = None
+            done = int(owner.early_stepped) if hook else 0
+            if done > 0:
+                n = self._P.numel() - done
+                o = done * 4
+                _lib.check(self._lib.mmda_clamp_adam(self._P.data_ptr() + o, self._G.data_ptr() + o, self._M.data_ptr() + o,
+                                                     self._V.data_ptr() + o, n, lr, 0.9, 0.999, 1e-8, clip, float(scale), max(self._step, 1), s),
+                           "adam(rest)")
             else:
-                scale = grad_sync(self._G, self._dense_floats)
-            _lib.check(self._lib.mmda_misa_adam_step(self._h, lr, clip, float(scale), self._step, s), "adam_step")
+                _lib.check(self._lib.mmda_misa_adam_step(self._h, lr, clip, float(scale), self._step, s), "adam_step")
 
     # ------------------------------------------------------------------ early part of the gradient bucket (data parallel)
     def early_grad_floats(self) -> int:

@@ -41,6 +41,8 @@ def _worker(rank, world, port, q, sparse=False):
         dp.broadcast_parameters(m)
         m.train_step(d["t"], d["v"], d["a"], d["l"], d["emo"], lr=1e-3, clip=1.0, training=False, grad_sync=dp.sync)
         torch.cuda.synchronize()
+        # the early-reduced prefix of the bucket was also STEPPED early, on the communication stream (mmda_amd/dist.py)
+        assert 0 < dp.early_stepped < m.flat_buckets()[0].numel() and dp.early_step is None
         sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
         q.put((rank, sd))
     finally:
