@@ -1700,6 +1700,21 @@ __global__ __launch_bounds__(256, 4) void lstm_fwd_quad_kernel(CLaunch L) {   //
 // by 2^-32 on its way to the matrix cores (a power of two: exact), so that every published bf16 partial is below 2 in magnitude
 // and its bit 14 is free for the epoch tag; the gatherer multiplies the fp32 sum by 2^32.  (Gradients beyond 2^33 -- or NaN -- read
 // as a tag that never matches or matches early: the first times out into the abort word, both belong to a diverged run.)
+// value of lane (l ^ 32) / (l ^ 16) / (l ^ 8).  v_permlane32_swap(x, x) returns (x[l], x[l + 32]) in the lower and (x[l - 32], x[l]) in the
+// upper half of the wave; v_permlane16_swap likewise per pair of 16-lane rows; row_ror:8 rotates a row of 16 by 8.
+typedef unsigned u2x __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float lane_xor32(float v, bool upper) {
+  const u2x r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+  return __builtin_bit_cast(float, upper ? r[0] : r[1]);
+}
+__device__ __forceinline__ float lane_xor16(float v, bool odd_row) {
+  const u2x r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+  return __builtin_bit_cast(float, odd_row ? r[0] : r[1]);
+}
+__device__ __forceinline__ float lane_xor8(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128 /* row_ror:8 */, 0xf, 0xf, true));
+}
+
 template <int CELL, int HDH, int D16>
 __global__ __launch_bounds__(256, 4) void lstm_bwd_quad_kernel(CLaunch L) {   // (<= 128 registers: four workgroups share a CU at large batches)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1922,22 +1937,24 @@ __global__ __launch_bounds__(256, 4) void lstm_bwd_quad_kernel(CLaunch L) {   //
           a[2 * q + 1] += __builtin_bit_cast(float, x & 0xffff0000u);
         }
       }
-      // reduce-scatter over the producer slots: bit 5 picks the unit, bits 4 and 3 the row
+      // reduce-scatter over the producer slots: bit 5 picks the unit, bits 4 and 3 the row.  The partner's value comes by
+      // v_permlane32_swap / v_permlane16_swap / a DPP row rotation (VALU, a few cycles each; three dependent ds_bpermute round trips
+      // were ~0.15 us of every step: tools/micro/permlane_swap.hip pins the swap semantics)
       float k4[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float keep = b5 ? a[4 + i] : a[i], send = b5 ? a[i] : a[4 + i];
-        k4[i] = keep + __shfl_xor(send, 32);
+        k4[i] = keep + lane_xor32(send, b5);
       }
       float k2[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const float keep = b4 ? k4[2 + i] : k4[i], send = b4 ? k4[i] : k4[2 + i];
-        k2[i] = keep + __shfl_xor(send, 16);
+        k2[i] = keep + lane_xor16(send, b4);
       }
       {
         const float keep = b3 ? k2[1] : k2[0], send = b3 ? k2[0] : k2[1];
-        dh_rec = (keep + __shfl_xor(send, 8)) * up;
+        dh_rec = (keep + lane_xor8(send)) * up;
       }
     }
     // gate gradients of the lane's element: linear in dh / dc with the factors derive() prepared
