@@ -2295,8 +2295,14 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
                                                             : lstm_fwd_wave_kernel<10, true, MMDA_CELL_LSTM, false, 0>)                         \
                                               : lstm_fwd_wave_kernel<10, false, MMDA_CELL_LSTM, false>)                                           \
                               : (L.gate_minor ? lstm_fwd_cluster_kernel<10, true> : lstm_fwd_cluster_kernel<10, false>);                 \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                            (int)lds_launch) != hipSuccess) { (void)hipGetLastError(); }                         \
+    /* (the attribute is set once per kernel function and size, not per launch) */                               \
+    static std::vector<std::pair<const void*, size_t>> attr_done;                                                \
+    const std::pair<const void*, size_t> akey{reinterpret_cast<const void*>(kfn), lds_launch};                   \
+    if (std::find(attr_done.begin(), attr_done.end(), akey) == attr_done.end()) {                                \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                              (int)lds_launch) != hipSuccess) { (void)hipGetLastError(); }                       \
+      attr_done.push_back(akey);                                                                                 \
+    }                                                                                                            \
     hipLaunchKernelGGL(kfn, grid, block, lds_launch, s, L);                                                      \
   } while (0)
     LAUNCH_C();
