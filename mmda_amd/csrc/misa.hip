@@ -675,13 +675,18 @@ int eager_side_losses(mmda_misa* m, void* stream, bool hseq2_t) {
   const int64_t BH = (int64_t)B * hs;
   void* ss = nullptr;
   int rc = side_fork(m, stream, &ss);
-  if (!rc && m->wT_pending) rc = weight_transposes(m, ss);
+  // (large batches: the loss chain on the side stream is the longer one by far -- the weight transposes go to the main stream)
+  if (!rc && m->wT_pending) rc = weight_transposes(m, B >= 128 ? stream : ss);
   (void)hseq2_t;                   // (the backward pass's operand copies are made by backward() itself: backward_only_jobs)
   if (!rc) rc = mmda_misa_zero_act_grads(m, ss);
   float* L = WS(m->losses);
   if (!rc) rc = mmda_loss_diff(WS(m->x6), BH, B, hs, c.diff_weight, L + 1, WS(m->d_x6), WS(m->diff_work), ss);
   if (!rc && c.use_cmd_sim) rc = mmda_loss_cmd(WS(m->x6 + 3 * BH), BH, B, hs, c.sim_weight, L + 2, WS(m->d_x6 + 3 * BH), ss);
-  if (!rc && m->zero_grad_pending) { rc = mmda_misa_zero_grad(m, ss); m->zero_grad_pending = 0; }
+  // The gradient bucket (43 MB, 11 us) is cleared on the MAIN stream behind the fork: since the row-local stretches were fused the
+  // side stream's loss chain (72 us at B=32), not the main stream's fusion block (55 us), is what the join at the end of forward() waits
+  // for.  (Nothing on either stream touches the bucket before the backward pass; MMDA_ZERO_GRAD_SIDE=1: the old place.)
+  static const int zg_side = getenv("MMDA_ZERO_GRAD_SIDE") ? atoi(getenv("MMDA_ZERO_GRAD_SIDE")) : 0;
+  if (!rc && m->zero_grad_pending) { rc = mmda_misa_zero_grad(m, zg_side ? ss : stream); m->zero_grad_pending = 0; }
   m->eager_done = 1;
   return rc;
 }
