@@ -1399,6 +1399,10 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
 #define MMDA_PSETS 1
 #define MMDA_PGAP 0
 #endif
+// ... and 64 cycles of s_sleep between a stale answer and the next question (B=32 step 0.676 -> 0.668 ms; 128 / 256 cycles: 0.676 / 0.692)
+#ifndef MMDA_POLL_SLEEP
+#define MMDA_POLL_SLEEP 1
+#endif
 constexpr int PSETS = MMDA_PSETS, PGAP = MMDA_PGAP;
 constexpr int QUAD_LDS = 2 * 4 * 16 * 16 * 4 * 4;      // bytes: parity x source wave x 16 rows x 16 units x 4 gates, fp32
 
@@ -1578,6 +1582,7 @@ __global__ __launch_bounds__(256, 4) void lstm_fwd_quad_kernel(CLaunch L) {   //
                 for (int j = 0; j < 3; ++j) fa[j] = fs[q][j];
                 got = true;
               } else {
+                __builtin_amdgcn_s_sleep(MMDA_POLL_SLEEP);          // a short pause before asking again (see PSETS)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) fs[q][j] = ld16_sc1(xr, par + foff[j]);
               }
@@ -1908,6 +1913,7 @@ __global__ __launch_bounds__(256, 4) void lstm_bwd_quad_kernel(CLaunch L) {   //
                 for (int l = 0; l < 3; ++l) fa[l] = fs[q][l];
                 got = true;
               } else {
+                __builtin_amdgcn_s_sleep(MMDA_POLL_SLEEP);          // a short pause before asking again (see PSETS)
 #pragma unroll
                 for (int l = 0; l < 3; ++l) fs[q][l] = ld16_sc1(xr, par + goff[l]);
               }
