@@ -1559,11 +1559,17 @@ __global__ __launch_bounds__(256, 4) void lstm_fwd_quad_kernel(CLaunch L) {   //
       } else {                                           // steady state: the fragments themselves say when they are there
         // (PSETS copies of the three loads in flight: see the note at PSETS -- one is best)
         u32x4 fs[PSETS][3];
-        auto stale = [&](const u32x4 (&f)[3]) {          // some element of a fragment this lane needs still carries the other tag
+        // the fragments with the expected tag XORed off (what the MFMAs take); an element that still carries the other tag keeps a tag
+        // bit -- `stale` -- and a nonexistent tile reads as zero and stays zero (cl = 0)
+        auto untag = [&](u32x4 (&x)[3], const u32x4 (&f)[3]) {
           unsigned t = 0;
 #pragma unroll
-          for (int j = 0; j < 3; ++j) t |= (((f[j][0] ^ tm) | (f[j][1] ^ tm)) | ((f[j][2] ^ tm) | (f[j][3] ^ tm))) & chk[j];
-          return t != 0;
+          for (int j = 0; j < 3; ++j) {
+            const unsigned cl = chk[j] ? tm : 0u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { x[j][i] = f[j][i] ^ cl; t |= x[j][i]; }
+          }
+          return (t & TAGS) != 0;
         };
         if (PSETS == 1 && PGAP > 0) __builtin_amdgcn_s_sleep(PGAP);
 #pragma unroll
@@ -1572,14 +1578,12 @@ __global__ __launch_bounds__(256, 4) void lstm_fwd_quad_kernel(CLaunch L) {   //
           for (int j = 0; j < 3; ++j) fs[q][j] = ld16_sc1(xr, par + foff[j]);
           if (q + 1 < PSETS) __builtin_amdgcn_s_sleep(PGAP);
         }
-        bool got = dead;
+        bool got = false;
         for (unsigned spins = 0; !got; spins += PSETS) {
 #pragma unroll
           for (int q = 0; q < PSETS; ++q) {
             if (!got) {
-              if (!__any(stale(fs[q]))) {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) fa[j] = fs[q][j];
+              if (!__any(untag(fa, fs[q])) || dead) {
                 got = true;
               } else {
                 __builtin_amdgcn_s_sleep(MMDA_POLL_SLEEP);          // a short pause before asking again (see PSETS)
@@ -1593,17 +1597,18 @@ __global__ __launch_bounds__(256, 4) void lstm_fwd_quad_kernel(CLaunch L) {   //
             if (lane == 0) st_flag(abort_w, 1u);
           }
         }
-        if (dead) {
+      }
+      if (FM == 0) {                                     // (flag steps: tags off here)
 #pragma unroll
-          for (int j = 0; j < 3; ++j) fa[j] = fs[0][j];
+        for (int j = 0; j < 3; ++j) {
+          const unsigned cl = chk[j] ? tm : 0u;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) fa[j][i] ^= cl;
         }
       }
       bf16x8 af[3];
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {                      // tags off (nonexistent tiles read as zero and stay zero)
-        const unsigned cl = chk[j] ? tm : 0u;
-        af[j] = __builtin_bit_cast(bf16x8, u32x4{fa[j][0] ^ cl, fa[j][1] ^ cl, fa[j][2] ^ cl, fa[j][3] ^ cl});
-      }
+      for (int j = 0; j < 3; ++j) af[j] = __builtin_bit_cast(bf16x8, fa[j]);
       f32x4 acc[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1890,11 +1895,15 @@ __global__ __launch_bounds__(256, 4) void lstm_bwd_quad_kernel(CLaunch L) {   //
         for (int l = 0; l < 3; ++l) fa[l] = ld16_sc1(xr, par + goff[l]);
       } else {
         u32x4 fs[PSETS][3];                              // (see the forward kernel)
-        auto stale = [&](const u32x4 (&f)[3]) {
+        auto untag = [&](u32x4 (&x)[3], const u32x4 (&f)[3]) {
           unsigned t = 0;
 #pragma unroll
-          for (int l = 0; l < 3; ++l) t |= (((f[l][0] ^ tm) | (f[l][1] ^ tm)) | ((f[l][2] ^ tm) | (f[l][3] ^ tm))) & chk[l];
-          return t != 0;
+          for (int l = 0; l < 3; ++l) {
+            const unsigned cl = chk[l] ? tm : 0u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { x[l][i] = f[l][i] ^ cl; t |= x[l][i]; }
+          }
+          return (t & TAGS) != 0;
         };
         if (PSETS == 1 && PGAP > 0) __builtin_amdgcn_s_sleep(PGAP);
 #pragma unroll
@@ -1903,14 +1912,12 @@ __global__ __launch_bounds__(256, 4) void lstm_bwd_quad_kernel(CLaunch L) {   //
           for (int l = 0; l < 3; ++l) fs[q][l] = ld16_sc1(xr, par + goff[l]);
           if (q + 1 < PSETS) __builtin_amdgcn_s_sleep(PGAP);
         }
-        bool got = dead;
+        bool got = false;
         for (unsigned spins = 0; !got; spins += PSETS) {
 #pragma unroll
           for (int q = 0; q < PSETS; ++q) {
             if (!got) {
-              if (!__any(stale(fs[q]))) {
-#pragma unroll
-                for (int l = 0; l < 3; ++l) fa[l] = fs[q][l];
+              if (!__any(untag(fa, fs[q])) || dead) {
                 got = true;
               } else {
                 __builtin_amdgcn_s_sleep(MMDA_POLL_SLEEP);          // a short pause before asking again (see PSETS)
@@ -1924,9 +1931,13 @@ __global__ __launch_bounds__(256, 4) void lstm_bwd_quad_kernel(CLaunch L) {   //
             if (lane == 0) st_flag(abort_w, 1u);
           }
         }
-        if (dead) {
+      }
+      if (FM == 0) {                                     // (flag steps: tags off here)
 #pragma unroll
-          for (int l = 0; l < 3; ++l) fa[l] = fs[0][l];
+        for (int l = 0; l < 3; ++l) {
+          const unsigned cl = chk[l] ? tm : 0u;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) fa[l][i] ^= cl;
         }
       }
       flush(step - 1);
@@ -1935,10 +1946,9 @@ __global__ __launch_bounds__(256, 4) void lstm_bwd_quad_kernel(CLaunch L) {   //
       float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int l = 0; l < 3; ++l) {
-        const unsigned cl = chk[l] ? tm : 0u;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const unsigned x = fa[l][q] ^ cl;
+          const unsigned x = fa[l][q];                   // (tags already off)
           a[2 * q] += __builtin_bit_cast(float, x << 16);
           a[2 * q + 1] += __builtin_bit_cast(float, x & 0xffff0000u);
         }
