@@ -4,8 +4,10 @@
 One "step" = one full reference loop iteration (solver.py:139-186: zero_grad, forward, six losses, backward,
 clip_grad_value_, Adam; dropout ON) on one synthetic MOSEI-shaped batch per GPU that is already resident in HBM.
 N=1 workload = BASELINE.json configs[1]: B=32, T=50, (d_t,d_v,d_a)=(300,35,74), hidden 128, V=20000, bf16 MFMA operands
-with fp32 accumulate.  N>1: one process per GPU (torchrun), the same per-GPU batch on every rank (weak scaling), one RCCL
-all-reduce of the flat gradient bucket per step.  Rank 0 prints ONE JSON line.
+with fp32 accumulate.  N>1: one process per GPU -- started by torchrun (RANK / WORLD_SIZE in the environment) or, when called
+bare as `python bench.py --gpus N`, by this script itself (launch_ranks: N fresh children, the parent never touches a GPU) --, the
+same per-GPU batch shape on every rank (weak scaling; default B=32/GPU so the curve continues the N=1 point, `--batch 256` is
+BASELINE configs[2]), gradient exchange over RCCL per step.  Rank 0 prints ONE JSON line.
 
 Extra legs on the same line (rank 0, N=1 only for cpu_baseline):
   roofline     - the dominant kernel (the biLSTM recurrence), timed with HIP events on its own stream inside the timed region
@@ -24,6 +26,39 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without torchrun: start one child process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
+    its environment, rendezvous on 127.0.0.1) and relay rank 0's JSON line.  Returns the largest exit code of the ranks.  A rank
+    that dies takes the others down (they would wait in a collective for ever)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", str(port)))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # rank 0 prints the line on this process's stdout; whatever the other ranks print goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            rc = max(rc, abs(code))
+            if code != 0:
+                for q in alive:
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -40,6 +75,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streaming-recurrence", action="store_true", help="bf16: stream W_hh from L2 per step instead of LDS-resident")
     ap.add_argument("--cpu-steps", type=int, default=0, help="0 = pick a count that takes ~10-30 s")
+    ap.add_argument("--launch-check", action="store_true", help="every rank prints its rendezvous environment and exits (no GPU call): tests the launcher")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -47,8 +83,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if args.gpus > 1 and world == 1 and "WORLD_SIZE" in os.environ:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE=1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # called as `python bench.py --gpus N` without a launcher: this process becomes the launcher.  It has not touched the GPU
+        # (importing torch does not) and never will; the ranks are fresh child processes.
+        raise SystemExit(launch_ranks(args.gpus))
+    if args.launch_check:
+        print(json.dumps({"rank": rank, "local_rank": local_rank, "world": world, "master": os.environ.get("MASTER_ADDR"),
+                          "port": os.environ.get("MASTER_PORT")}), file=sys.stdout if rank == 0 else sys.stderr)
+        return
     # rehearsal switches (not for measurements): MMDA_BENCH_BACKEND=gloo + MMDA_BENCH_ONE_DEVICE=1 run the N > 1 code path with
     # every rank on cuda:0 (RCCL refuses two ranks on one device), gradients staged through the host
     backend = os.environ.get("MMDA_BENCH_BACKEND", "nccl")
@@ -97,8 +141,9 @@ def main():
     lib = model._lib
     if rank == 0 and not os.environ.get("MMDA_BENCH_NO_KERNEL_TIMING"):
         # HIP events around the four recurrent launches of every 8th timed step (25 samples at the default 200 steps): the eight
-        # event records cost ~35 us per step, which the metric should not carry on every step
-        stride = 8 if args.steps >= 64 else 1
+        # event records cost ~35 us per step, which the metric should not carry on every step.  A short run (the driver's 20 steps)
+        # samples five of its steps, never every one.
+        stride = 8 if args.steps >= 64 else max(1, (args.steps + 4) // 5)
         _lib.check(lib.mmda_misa_timing_stride(model._h, stride), "timing_stride")
         _lib.check(lib.mmda_misa_timing_begin(model._h, (args.steps + stride - 1) // stride), "timing_begin")
     barrier()
@@ -212,7 +257,8 @@ def main():
         out["cpu_baseline"] = {"value": round(args.batch * nsteps / secs, 2), "unit": "samples/s", "cores": torch.get_num_threads(),
                                "kind": "port",
                                "sample": f"{nsteps} training steps of the same B={args.batch},T={args.seq_len} batch "
-                                         f"(oracle.ModuleBaseline: nn.LSTM/nn.TransformerEncoderLayer/torch.optim.Adam fp32)"}
+                                         f"(oracle.ModuleBaseline: nn.LSTM/nn.TransformerEncoderLayer/torch.optim.Adam fp32, "
+                                         f"pinned to the reference-generated fixtures by tests/test_oracle_golden.py)"}
         out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
     print(json.dumps(out))
     if world > 1:

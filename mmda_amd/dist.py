@@ -21,7 +21,8 @@ import torch.distributed as dist
 
 
 class DataParallelSync:
-    def __init__(self, group=None, bucket_mb: float = 0.0, sparse_embedding=None, overlap: bool = True, equal_shapes: bool = False):
+    def __init__(self, group=None, bucket_mb: float = 0.0, sparse_embedding=None, overlap: bool = True, equal_shapes: bool = False,
+                 force_collectives: bool = False):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
@@ -37,6 +38,9 @@ class DataParallelSync:
         self.overlap = bool(overlap)          # reduce the early-finished prefix of the bucket beside the rest of the backward pass
         # every rank holds a batch of the same (B, T) on every step (benchmarks): the row counts need not be exchanged first
         self.equal_shapes = bool(equal_shapes)
+        # test hook: a ONE-rank group still walks the whole exchange (communication stream, early event wait, early clip + Adam,
+        # all-reduces, both all-gathers, segment sum) instead of returning at once -- the way to run the RCCL branch on a box with one GPU
+        self.force_collectives = bool(force_collectives)
         self._comm = None
         # Optional optimizer hook for the early prefix: `early_step(n_floats, stream)` is called on the communication stream right behind
         # the early all-reduce (the prefix's gradients are then final and summed), and `early_stepped` tells the caller how many leading
@@ -56,6 +60,25 @@ class DataParallelSync:
                 t.copy_(h)
             else:
                 dist.broadcast(t, src=0, group=self.group)
+
+    def agree(self, value: float, src: int = 0) -> float:
+        """Rank `src`'s value on every rank (a decision every rank must take alike -- e.g. "is this epoch the best so far" -- may not
+        depend on a float each rank computed for itself)."""
+        if self.world == 1:
+            return float(value)
+        nccl = dist.get_backend(self.group) == "nccl"
+        t = torch.tensor([float(value)], dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()) if nccl else "cpu")
+        dist.broadcast(t, src=src, group=self.group)
+        return float(t.item())
+
+    def any_rank(self, flag: bool) -> bool:
+        """True on every rank if `flag` is true on any rank (one small MAX all-reduce)."""
+        if self.world == 1:
+            return bool(flag)
+        nccl = dist.get_backend(self.group) == "nccl"
+        t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()) if nccl else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return bool(t.item() > 0)
 
     def _all_reduce(self, t: torch.Tensor, async_op: bool = False):
         """all-reduce(sum) in place.  With the gloo backend (CPU tests, or a 2-rank rehearsal on one GPU) device tensors are
@@ -134,7 +157,7 @@ class DataParallelSync:
         leaves more than half of the CUs idle -- and the remainder (layer 1; the embedding gradient in its dense or its (ids, rows)
         form) behind the step's last kernel.  The calling stream waits for the communication stream before the optimizer runs."""
         self.early_stepped = 0
-        if self.world == 1:
+        if self.world == 1 and not self.force_collectives:
             return 1.0
         n = flat_grads.numel()
         sparse = self._use_sparse(flat_grads, dense_floats, model)

@@ -122,6 +122,17 @@ class Solver(object):
         if hasattr(self.model, "check_cluster"):
             self.model.check_cluster(where)
 
+    def _check_cluster_all_ranks(self, where):
+        """Data parallel: every rank reads its own status, the ranks agree (one MAX all-reduce) and ALL of them raise -- a rank
+        that raised alone would leave its peers waiting in the next collective."""
+        if self.dp is None:
+            return self._check_cluster(where)
+        bad = bool(self.model.cluster_aborted()) if hasattr(self.model, "cluster_aborted") else False
+        if self.dp.any_rank(bad):
+            from . import _lib
+            raise _lib.MMDAError(f"a resident-weights recurrence timed out waiting for its workgroup cluster on "
+                                 f"{'this rank' if bad else 'another rank'} ({where}): results since then are invalid")
+
     def train(self):
         cfg = self.train_config
         best_valid_loss = float("inf")
@@ -135,16 +146,20 @@ class Solver(object):
             print("-" * 100)
             print("Epochs: {}, Valid loss: {}, Valid acc: {}".format(e, valid_loss, valid_acc))
             print("-" * 100)
-            if valid_loss <= best_valid_loss:
-                best_valid_loss, best_epoch = valid_loss, e
+            # Data parallel: whether this epoch is the best one is decided ONCE, from rank 0's dev loss (a sharded dev loader, or one
+            # ULP of difference between ranks, must not send one rank into the checkpoint barrier and another into the next epoch's
+            # all-reduce), and the cluster check in front of the save is collective, so an error is raised on every rank.
+            decided = self.dp.agree(valid_loss) if self.dp is not None else valid_loss
+            if decided <= best_valid_loss:
+                best_valid_loss, best_epoch = decided, e
                 print("Found new best model on dev set!")
+                self._check_cluster_all_ranks("before saving the checkpoint")  # never save weights a failed exchange produced
                 if self.dp is None or self.dp.rank == 0:
                     os.makedirs("checkpoints", exist_ok=True)
-                    self._check_cluster("before saving the checkpoint")        # never save weights a failed exchange produced
                     torch.save(self.model.state_dict(), f"checkpoints/model_{cfg.name}.std")
                     torch.save(self.optimizer.state_dict(), f"checkpoints/optim_{cfg.name}.std")     # solver.py:220
-                if self.dp is not None:
-                    torch.distributed.barrier()           # nobody reads the checkpoint before rank 0 has written it
+            if self.dp is not None:
+                torch.distributed.barrier()               # every epoch, on every rank: nobody reads the checkpoint before rank 0 has written it
             history.append(dict(epoch=e, train=tr, valid_loss=valid_loss, valid_acc=valid_acc))
         test_loss, acc, _, _ = self.eval(mode="test", to_print=best_epoch >= 0)
         print("=" * 50)

@@ -465,7 +465,45 @@ def train_step(P: Params, opt: AdamState, cfg, batch):
 class ModuleBaseline(nn.Module):
     """Stock-module CPU baseline (nn.LSTM / nn.TransformerEncoderLayer / torch.optim.Adam) with
     dropout ON, i.e. the shape of work the reference's CPU training loop performs per step.
-    Used only by bench.py's cpu_baseline leg ("kind": "port")."""
+    Used only by bench.py's cpu_baseline leg ("kind": "port").  Pinned: with the reference's parameters
+    loaded (`load_reference_params`) and dropout off (`eval()`), its losses and gradients equal the
+    reference-generated golden fixtures (tests/test_oracle_golden.py::test_module_baseline_*)."""
+
+    _MODS = "tva"
+
+    def reference_name_map(self):
+        """{reference state_dict key (models.py:47-161): this module's parameter name}."""
+        m = {"embed.weight": "embed.weight", "shared.shared_1.weight": "shared.0.weight", "shared.shared_1.bias": "shared.0.bias",
+             "sp_discriminator.sp_discriminator_layer_1.weight": "sp.weight", "sp_discriminator.sp_discriminator_layer_1.bias": "sp.bias",
+             "confidence.confidence_layer_1.weight": "confidence.0.weight", "confidence.confidence_layer_1.bias": "confidence.0.bias",
+             "classifier.classifier_layer.weight": "classifier.0.weight", "classifier.classifier_layer.bias": "classifier.0.bias"}
+        for i, c in enumerate(self._MODS):
+            for layer, mine in ((1, "rnn1"), (2, "rnn2")):
+                for sfx in ("", "_reverse"):
+                    for w in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"):
+                        m[f"{c}rnn{layer}.{w}{sfx}"] = f"{mine}.{i}.{w}{sfx}"
+            for w in ("weight", "bias"):
+                m[f"{c}layer_norm.{w}"] = f"ln.{i}.{w}"
+                m[f"project_{c}.project_{c}.{w}"] = f"proj.{i}.0.{w}"
+                m[f"project_{c}.project_{c}_layer_norm.{w}"] = f"proj.{i}.2.{w}"
+                m[f"private_{c}.private_{c}_{3 if c == 'a' else 1}.{w}"] = f"private.{i}.0.{w}"
+                m[f"recon_{c}.recon_{c}_1.{w}"] = f"recon.{i}.{w}"
+        for k in ("self_attn.in_proj_weight", "self_attn.in_proj_bias", "self_attn.out_proj.weight", "self_attn.out_proj.bias",
+                  "linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias", "norm1.weight", "norm1.bias",
+                  "norm2.weight", "norm2.bias"):
+            m[f"transformer_encoder.layers.0.{k}"] = f"fuse.layers.0.{k}"
+        return m
+
+    def load_reference_params(self, P: Params):
+        """Copies a reference-keyed parameter dict (synth_params / a reference checkpoint) into the stock modules."""
+        mine = dict(self.named_parameters())
+        nm = self.reference_name_map()
+        assert sorted(nm.values()) == sorted(mine), "name map does not cover the module"
+        with torch.no_grad():
+            for ref, own in nm.items():
+                assert mine[own].shape == P[ref].shape, (ref, own)
+                mine[own].copy_(P[ref])
+        return self
 
     def __init__(self, cfg):
         super().__init__()
@@ -483,6 +521,7 @@ class ModuleBaseline(nn.Module):
         self.shared = nn.Sequential(nn.Linear(hs, hs), nn.Sigmoid())
         self.recon = nn.ModuleList([nn.Linear(hs, hs) for _ in range(3)])
         self.sp = nn.Linear(hs, 4)
+        assert cfg.activation == "leakyrelu" and cfg.use_cmd_sim, "ModuleBaseline is the headline configuration only"
         self.fuse = nn.TransformerEncoder(nn.TransformerEncoderLayer(d_model=hs, nhead=NHEAD), num_layers=1,
                                           enable_nested_tensor=False)
         self.confidence = nn.Sequential(nn.Linear(6 * hs, 6), nn.Sigmoid())

@@ -126,3 +126,56 @@ def test_sparse_embedding_exchange_world2_ragged_shards():
         assert p.exitcode == 0
     for r in res:
         assert all(r[1:]), r
+
+
+def _agree_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dp = DataParallelSync()
+        # each rank computed "its" dev loss; the decision must come out the same everywhere (rank 0's value)
+        mine = 0.5 + 1e-7 * rank
+        q.put((rank, dp.agree(mine), dp.any_rank(rank == 1), dp.any_rank(False)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_collective_decisions_world2():
+    """Solver.train()'s best-epoch decision and its cluster check are collective (mmda_amd/solver.py): rank 0's loss everywhere, an
+    error flag raised by any rank seen by all."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_agree_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] == 0.5
+    assert res[0][2] is True and res[1][2] is True
+    assert res[0][3] is False and res[1][3] is False
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` without torchrun (how the driver calls it): the script starts N fresh rank processes with the
+    rendezvous environment set; rank 0's output is the launcher's stdout.  --launch-check stops every rank before its first GPU call."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--launch-check"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    out = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+    err = [json.loads(x) for x in r.stderr.splitlines() if x.startswith("{")]
+    assert len(out) == 1 and out[0]["rank"] == 0 and out[0]["world"] == 3 and out[0]["master"] == "127.0.0.1"
+    assert sorted(e["rank"] for e in err) == [1, 2] and all(e["port"] == out[0]["port"] for e in err)
+    # under a launcher (WORLD_SIZE set) it must NOT spawn again
+    env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env2,
+                        capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0 and len([x for x in r2.stdout.splitlines() if x.startswith("{")]) == 1 and not r2.stderr.strip().startswith("{")

@@ -102,3 +102,40 @@ def test_loop_lstm_matches_packed_lstm():
                                  getattr(rnn, "bias_ih_l0" + sfx), getattr(rnn, "bias_hh_l0" + sfx), reverse=bool(d))
         torch.testing.assert_close(o, pad[:, :, d * H:(d + 1) * H], rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(h, hn[d], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["real_b8_t12_ragged", "real_b32_t50_full"])
+def test_module_baseline_matches_reference_fixtures(name):
+    """bench.py's cpu_baseline times oracle.ModuleBaseline (stock nn.LSTM / nn.TransformerEncoderLayer modules).
+    It is a checked port: with the reference's parameters and dropout off, its outputs, six losses and every gradient equal what
+    the reference's own models.MISA produced (the golden fixtures)."""
+    z, meta, cfg = load_case(name)
+    assert cfg.rnncell == "lstm" and cfg.use_cmd_sim and not cfg.use_confidNet
+    P = orc.synth_params(cfg, meta["seed"])
+    m = orc.ModuleBaseline(cfg).load_reference_params(P)
+    m.eval()                                                    # dropout off, like the generator (gen_golden.py)
+    batch = batch_of(z)
+    o = m(batch["t"], batch["v"], batch["a"], batch["l"])
+    L = orc.all_losses(o, batch["emo"], cfg)
+    L.total.backward()
+    np.testing.assert_allclose(o.scores.detach().numpy(), z["out::scores"], rtol=RTOL, atol=ATOL)
+    for s in SIDE:
+        np.testing.assert_allclose(getattr(o, s).detach().numpy(), z["out::" + s], rtol=RTOL, atol=ATOL, err_msg=s)
+    for k in ("cls", "diff", "recon", "sim", "conf", "total"):
+        np.testing.assert_allclose(getattr(L, k).item(), float(z["loss::" + k]), rtol=1e-5, atol=1e-6, err_msg=k)
+    mine = dict(m.named_parameters())
+    none = set(meta["none_grads"])
+    for ref, own in m.reference_name_map().items():
+        g = mine[own].grad
+        if ref in none:
+            assert g is None or float(g.abs().max()) == 0.0, ref
+            continue
+        assert g is not None, ref
+        gn = g.numpy()
+        if ref.endswith("self_attn.in_proj_bias"):
+            continue                                            # the key-bias slice is rounding noise (softmax shift invariance)
+        exp = z["grad::" + ref] if meta["full_tensors"] else z["gsample::" + ref]
+        got = gn if meta["full_tensors"] else gn.ravel()[sample_idx(gn.size)]
+        assert np.abs(got - exp).max() <= 5e-5 * max(np.abs(exp).max(), 1e-6) + 1e-7, ref
+        scale = max(float(z["gnorm::" + ref]), 1e-12)
+        assert abs(np.sqrt((gn.astype(np.float64) ** 2).sum()) - scale) <= 1e-4 * scale + 1e-9, ref
