@@ -54,6 +54,12 @@ typedef struct mmda_act_params {
 
 const char* mmda_last_error(void);
 int mmda_abi_version(void);
+/* The GEMM entry points split long reductions over K and combine the slices DETERMINISTICALLY: every slice writes its partial tile
+ * into a slab, a reduce launch on the same stream sums the slabs in slice order (no float atomics: two identical calls give
+ * identical bits; reference train.py:46-51 asks for reproducible runs).  The slabs live in a scratch buffer the library keeps per
+ * stream -- the one exception to "the caller owns every buffer": it is grown on demand (hipMalloc, i.e. during warm-up) and
+ * released by this call (or at process exit).  Call it only when no GEMM of this library is in flight. */
+int mmda_scratch_release(void);
 
 /* ---------------------------------------------------------------------------------------------- GEMM
  * C[b] = epilogue( opA(A[b] (+A2[b])) * opB(B[b]) + bias[b] + bias2[b] (+ C[b] if accumulate) )

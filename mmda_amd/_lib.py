@@ -120,6 +120,7 @@ _P, _I, _I64, _F, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 SIGNATURES = {
     "mmda_last_error": (C.c_char_p, []),
     "mmda_abi_version": (_I, []),
+    "mmda_scratch_release": (_I, []),
     "mmda_gemm": (_I, [C.POINTER(GemmArgs), _P]),
     "mmda_gemm_grouped": (_I, [C.POINTER(GemmArgs), _I, _P]),
     "mmda_gemm_bf16_grouped": (_I, [C.POINTER(GemmBf16Args), _I, _P]),

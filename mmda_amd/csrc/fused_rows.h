@@ -15,6 +15,7 @@ struct FusedBwdC {
   const float* head_w;            // (6 + ncls, 6 hs) row-major
   float* d_hfused;                // (B, 6 hs)
   mmda_ln_bwd_args ln2;           // rows = 6 B (token-major), permute_S / permute_B set
+  float* pg_parts;                // (B, 5, 2, hs): per-sample partial gamma / beta gradients of the block's five LayerNorms (slot 0: ln2)
 };
 
 // stretch A: LayerNorm 1 backward -> d_ctx = d_attn_out W_out -> attention backward -> d_x6 = (d_x6 + d_qkv W_in + d_recon W_rec) s(1-s)
@@ -34,6 +35,7 @@ struct FusedBwdA {
   const float* sh_wT;             // (hs, hs) K-major
   float* d_orig;                  // (3, B, hs)
   mmda_ln_bwd_args lnp[3];        // rows = B each
+  float* pg_parts;                // (B, 5, 2, hs): slot 1: ln1, slots 2..4: the projection LayerNorms
   unsigned long long* dbg;        // diagnostics: cycle counter at each stage boundary of workgroup 0 (NULL in production)
 };
 
@@ -82,4 +84,9 @@ int mmda_fused_fwd_a(const FusedFwdA* a, void* stream);
 int mmda_fused_fwd_c(const FusedFwdC* a, void* stream);
 int mmda_fused_bwd_c(const FusedBwdC* a, void* stream);
 int mmda_fused_bwd_a(const FusedBwdA* a, void* stream);
+// The LayerNorm parameter gradients of the two backward stretches, deterministic: the stretches leave per-sample partial sums in
+// pg_parts (B, 5, 2, hs) -- slots ln2, ln1, proj_t, proj_v, proj_a -- and this launch adds them, in sample order, into dgamma[k] /
+// dbeta[k] (no float atomics: identical bits on every run).  Runs wherever the weight-gradient GEMMs of the block run (side stream).
+constexpr int FUSED_PG_SLOTS = 5;
+int mmda_fused_pg_finish(const float* pg_parts, int B, int hs, float* const* dgamma, float* const* dbeta, void* stream);
 extern "C" int mmda_debug_set_fused_stamps(void* device_buffer);     // tools/ only (16 x u64)

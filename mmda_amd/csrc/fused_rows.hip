@@ -103,25 +103,34 @@ __device__ __forceinline__ void stage_rows(float* lds, int nrows, int K, SrcOf s
   __syncthreads();
 }
 
-// LayerNorm backward of the rows `row_of(i)`, i < nrows, waves round robin; dgamma / dbeta of the workgroup's rows in ONE atomic per
-// column (LDS reduction over the waves).  n <= 128.
+// LayerNorm backward of the rows `row_of(i)`, i < nrows, waves round robin; dgamma / dbeta of the workgroup's rows summed over its
+// waves in LDS (fixed order) and left as ONE partial row each in `part` (2 x 128 floats: gamma, beta) -- mmda_fused_pg_finish adds the
+// partials of all workgroups in order.  n <= 128.
 template <typename RowOf>
-__device__ __forceinline__ void ln_bwd_rows(const mmda_ln_bwd_args& a, int nrows, RowOf row_of, float* red /* 2 x 8 x 128 floats */) {
+__device__ __forceinline__ void ln_bwd_rows(const mmda_ln_bwd_args& a, int nrows, RowOf row_of, float* red /* 2 x 8 x 128 floats */,
+                                            float* part) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float dg[2] = {0.f, 0.f}, db[2] = {0.f, 0.f};
   for (int i = wave; i < nrows; i += FR_THREADS / 64) ln_bwd_row<2>(a, row_of(i), lane, dg, db);
-  if (a.dgamma == nullptr && a.dbeta == nullptr) return;            // workgroup-uniform
+  if (part == nullptr) return;                                        // workgroup-uniform
 #pragma unroll
   for (int q = 0; q < 2; ++q) { red[(0 * 8 + wave) * 128 + q * 64 + lane] = dg[q]; red[(1 * 8 + wave) * 128 + q * 64 + lane] = db[q]; }
   __syncthreads();
-  for (int i = threadIdx.x; i < a.n; i += FR_THREADS) {
+  for (int i = threadIdx.x; i < 128; i += FR_THREADS) {
     float gsum = 0.f, bsum = 0.f;
 #pragma unroll
     for (int w = 0; w < 8; ++w) { gsum += red[(0 * 8 + w) * 128 + i]; bsum += red[(1 * 8 + w) * 128 + i]; }
-    if (a.dgamma) atomicAdd(&a.dgamma[i], gsum);
-    if (a.dbeta) atomicAdd(&a.dbeta[i], bsum);
+    part[i] = i < a.n ? gsum : 0.f;
+    part[128 + i] = i < a.n ? bsum : 0.f;
   }
   __syncthreads();                                                   // `red` is free again
+}
+// slot k of sample b in pg_parts (B, 5, 2, 128)
+__device__ __forceinline__ float* pg_slot(float* parts, int b, int k) { return parts ? parts + ((int64_t)b * FUSED_PG_SLOTS + k) * 256 : nullptr; }
+// the workgroup-wide sums live in the slot of the workgroup's FIRST sample: the slots of its other samples are zero
+__device__ __forceinline__ void pg_zero_rest(float* parts, int b0, int nb, int k) {
+  if (!parts) return;
+  for (int e = threadIdx.x; e < (nb - 1) * 256; e += FR_THREADS) pg_slot(parts, b0 + 1 + e / 256, k)[e % 256] = 0.f;
 }
 
 __global__ __launch_bounds__(FR_THREADS) void fused_bwd_c_kernel(FusedBwdC P) {
@@ -155,7 +164,8 @@ __global__ __launch_bounds__(FR_THREADS) void fused_bwd_c_kernel(FusedBwdC P) {
   }
   stage_sync();
   // LayerNorm 2 backward over the token rows (s, b) of these samples
-  ln_bwd_rows(P.ln2, S6K * nb, [&](int i) { return (i / nb) * B + b0 + (i % nb); }, red);
+  ln_bwd_rows(P.ln2, S6K * nb, [&](int i) { return (i / nb) * B + b0 + (i % nb); }, red, pg_slot(P.pg_parts, b0, 0));
+  pg_zero_rest(P.pg_parts, b0, nb, 0);
 }
 
 __global__ __launch_bounds__(FR_THREADS) void fused_bwd_a_kernel(FusedBwdA P) {
@@ -182,7 +192,8 @@ __global__ __launch_bounds__(FR_THREADS) void fused_bwd_a_kernel(FusedBwdA P) {
     stage_sync();
   }
   // ---- LayerNorm 1 backward: d_x6 += ..., d_attn_out
-  ln_bwd_rows(P.ln1, S6K * nb, [&](int i) { return (i / nb) * B + b0 + (i % nb); }, red);
+  ln_bwd_rows(P.ln1, S6K * nb, [&](int i) { return (i / nb) * B + b0 + (i % nb); }, red, pg_slot(P.pg_parts, b0, 1));
+  pg_zero_rest(P.pg_parts, b0, nb, 1);
   stage_sync();
   stamp();
   // token-row tile: tile row r = j nb + bb  <->  global row j B + b0 + bb
@@ -266,18 +277,19 @@ __global__ __launch_bounds__(FR_THREADS) void fused_bwd_a_kernel(FusedBwdA P) {
   }
   stage_sync();
   stamp();
-  // ---- the three projection LayerNorms (with their activation) backward: d_z.  One wave per (modality, sample) row; a wave's
-  // dgamma / dbeta terms go out as its own atomics (two rows per modality and workgroup: nothing to reduce first)
+  // ---- the three projection LayerNorms (with their activation) backward: d_z.  One wave per (modality, sample) row; a row's
+  // dgamma / dbeta terms ARE that sample's partial (slot 2 + modality): stored, not added
   for (int i = wave; i < 3 * nb; i += FR_THREADS / 64) {
     const mmda_ln_bwd_args& a = P.lnp[i / nb];
     float dg[2] = {0.f, 0.f}, db[2] = {0.f, 0.f};
     ln_bwd_row<2>(a, b0 + i % nb, lane, dg, db);
+    float* part = pg_slot(P.pg_parts, b0 + i % nb, 2 + i / nb);
+    if (part) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int c = q * 64 + lane;
-      if (c < a.n) {
-        if (a.dgamma) atomicAdd(&a.dgamma[c], dg[q]);
-        if (a.dbeta) atomicAdd(&a.dbeta[c], db[q]);
+      for (int q = 0; q < 2; ++q) {
+        const int c = q * 64 + lane;
+        part[c] = c < a.n ? dg[q] : 0.f;
+        part[128 + c] = c < a.n ? db[q] : 0.f;
       }
     }
   }
@@ -566,8 +578,29 @@ int mmda_fused_fwd_c(const FusedFwdC* a, void* stream) {
   return MMDA_OK;
 }
 
+// parameter gradients of the five LayerNorms: partials of the samples added in sample order (sixteen loads in flight at a time)
+struct FusedPgOut { float* dgamma[FUSED_PG_SLOTS]; float* dbeta[FUSED_PG_SLOTS]; };
+__global__ __launch_bounds__(256) void fused_pg_finish_kernel(const float* __restrict__ parts, int B, int hs, FusedPgOut out) {
+  const int e = blockIdx.x * 256 + threadIdx.x;                       // (slot k, gamma | beta, column c)
+  if (e >= FUSED_PG_SLOTS * 256) return;
+  const int k = e / 256, which = (e % 256) / 128, c = e % 128;
+  float* dst = which ? out.dbeta[k] : out.dgamma[k];
+  if (!dst || c >= hs) return;
+  dst[c] += sum_parts(parts + (int64_t)k * 256 + which * 128 + c, B, (int64_t)FUSED_PG_SLOTS * 256);
+}
+
+int mmda_fused_pg_finish(const float* pg_parts, int B, int hs, float* const* dgamma, float* const* dbeta, void* stream) {
+  if (!pg_parts || B <= 0 || hs != 128 || !dgamma || !dbeta) return MMDA_EINVAL;
+  FusedPgOut out;
+  for (int k = 0; k < FUSED_PG_SLOTS; ++k) { out.dgamma[k] = dgamma[k]; out.dbeta[k] = dbeta[k]; }
+  hipLaunchKernelGGL(fused_pg_finish_kernel, dim3(FUSED_PG_SLOTS), dim3(256), 0, (hipStream_t)stream, pg_parts, B, hs, out);
+  MMDA_CHECK_LAUNCH("mmda_fused_pg_finish");
+  return MMDA_OK;
+}
+
 int mmda_fused_bwd_c(const FusedBwdC* a, void* stream) {
   if (!a || a->B <= 0 || a->nb <= 0 || a->hs != 128 || a->ln2.n != 128) return MMDA_EINVAL;
+  if ((a->ln2.dgamma || a->ln2.dbeta) && !a->pg_parts) return MMDA_EINVAL;       // parameter gradients go through the partials
   hipLaunchKernelGGL(fused_bwd_c_kernel, dim3(ceil_div(a->B, a->nb)), dim3(FR_THREADS), 0, (hipStream_t)stream, *a);
   MMDA_CHECK_LAUNCH("mmda_fused_bwd_c");
   return MMDA_OK;
@@ -578,6 +611,7 @@ extern "C" int mmda_debug_set_fused_stamps(void* device_buffer) { g_fr_dbg = (un
 
 int mmda_fused_bwd_a(const FusedBwdA* a, void* stream) {
   if (!a || a->B <= 0 || a->nb <= 0 || a->nb > 2 || a->hs != 128 || a->nhead != 2) return MMDA_EINVAL;
+  if ((a->ln1.dgamma || a->ln1.dbeta || a->lnp[0].dgamma || a->lnp[0].dbeta) && !a->pg_parts) return MMDA_EINVAL;
   FusedBwdA P = *a;
   P.dbg = g_fr_dbg;
   hipLaunchKernelGGL(fused_bwd_a_kernel, dim3(ceil_div(a->B, a->nb)), dim3(FR_THREADS), 0, (hipStream_t)stream, P);

@@ -4,7 +4,9 @@
 //
 // Tile 64x64x32, 256 threads = 4 waves (2x2), each wave a 32x32 sub-tile = 2x2 MFMA 16x16 accumulators.
 #include "common.h"
+#include "splitk.h"
 #include <stdlib.h>
+#include <vector>
 
 namespace {
 
@@ -13,7 +15,8 @@ constexpr int LDS_F32_LD = 34;   // floats per LDS row: (2*row + k) % 32 distinc
 constexpr int LDS_BF16_LD = 40;  // shorts per LDS row (80 B, 16-B aligned rows for ds_read_b128)
 
 template <int MODE, int PF>
-__device__ __forceinline__ void gemm_body(const mmda_gemm_args& g, int splitk, unsigned char* smem, int bx, int by, int bzz) {
+__device__ __forceinline__ void gemm_body(const mmda_gemm_args& g, int splitk, unsigned char* smem, int bx, int by, int bzz,
+                                          float* slab, int ldn) {
   float* As_f = reinterpret_cast<float*>(smem);
   float* Bs_f = As_f + BM * LDS_F32_LD;
   unsigned short* As_h = reinterpret_cast<unsigned short*>(smem);
@@ -83,7 +86,8 @@ __device__ __forceinline__ void gemm_body(const mmda_gemm_args& g, int splitk, u
     }
   };
 
-  // split-K: this block reduces k-tiles [kt0, kt1); partial results are combined with float atomics in the epilogue
+  // split-K: this block reduces k-tiles [kt0, kt1); its raw partial tile goes into a slab of its own and the reduce launch behind
+  // this one sums the slabs in slice order (splitk.h): no float atomics, identical bits on every run
   const int nk_all = (K + BK - 1) / BK;
   const int per = (nk_all + splitk - 1) / splitk;
   const int kt0 = sp * per;
@@ -145,6 +149,22 @@ __device__ __forceinline__ void gemm_body(const mmda_gemm_args& g, int splitk, u
   }
 
   // epilogue: C/D fragment map col = lane&15, row = (lane>>4)*4 + reg
+  if (splitk > 1) {                // host guarantees: no act/dropout/gate; slab = [batch][slice][M][ldn]
+    float* S = slab + ((int64_t)bz * splitk + sp) * M * ldn;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = col0 + wn * 32 + j * 16 + (lane & 15);
+        if (n >= ldn) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = row0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r;
+          if (m < M) S[(int64_t)m * ldn + n] = acc[i][j][r];
+        }
+      }
+    return;
+  }
   const float* bias = g.bias ? g.bias + bz * g.strideBias : nullptr;
   const float* bias2 = g.bias2 ? g.bias2 + bz * g.strideBias : nullptr;
   const float alpha = g.alpha == 0.f ? 1.f : g.alpha;
@@ -153,13 +173,13 @@ __device__ __forceinline__ void gemm_body(const mmda_gemm_args& g, int splitk, u
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       int n = col0 + wn * 32 + j * 16 + (lane & 15);
-      if (g.bias_grad && n == N) {                           // column sums of A (= dY): accumulate into the bias gradient(s)
+      if (g.bias_grad && n == N) {                           // column sums of A (= dY) into the bias gradient(s): one writer per entry
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           int m = row0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r;
           if (m < M) {
-            atomicAdd(&g.bias_grad[bz * g.strideBias + m], acc[i][j][r]);
-            if (g.bias_grad2) atomicAdd(&g.bias_grad2[bz * g.strideBias + m], acc[i][j][r]);
+            g.bias_grad[bz * g.strideBias + m] += acc[i][j][r];
+            if (g.bias_grad2) g.bias_grad2[bz * g.strideBias + m] += acc[i][j][r];
           }
         }
         continue;
@@ -173,10 +193,6 @@ __device__ __forceinline__ void gemm_body(const mmda_gemm_args& g, int splitk, u
         int m = row0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r;
         if (m >= M) continue;
         int64_t ci = (int64_t)m * g.ldc + n;
-        if (splitk > 1) {          // host guarantees: no act/dropout/gate, C zeroed or accumulating
-          atomicAdd(&C[ci], alpha * acc[i][j][r] + (sp == 0 ? bsum : 0.f));
-          continue;
-        }
         float v = alpha * acc[i][j][r] + bsum;
         if (g.accumulate) v += C[ci];
         v = act_fwd(g.act, v);
@@ -189,9 +205,9 @@ __device__ __forceinline__ void gemm_body(const mmda_gemm_args& g, int splitk, u
 
 
 template <int MODE, int PF>
-__global__ __launch_bounds__(256) void gemm_kernel(mmda_gemm_args g, int splitk) {
+__global__ __launch_bounds__(256) void gemm_kernel(mmda_gemm_args g, int splitk, float* slab, int ldn) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BM * LDS_F32_LD * 4];
-  gemm_body<MODE, PF>(g, splitk, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+  gemm_body<MODE, PF>(g, splitk, smem, blockIdx.x, blockIdx.y, blockIdx.z, slab, ldn);
 }
 
 // Grouped launch: up to GROUP_MAX independent GEMMs (different shapes, layouts, modes) in ONE grid, so that the many small
@@ -202,6 +218,8 @@ struct GroupLaunch {
   mmda_gemm_args p[GROUP_MAX];
   int start[GROUP_MAX + 1];
   int tx[GROUP_MAX], ty[GROUP_MAX], splitk[GROUP_MAX];
+  float* slab[GROUP_MAX];
+  int ldn[GROUP_MAX];
   int n;
 };
 __global__ __launch_bounds__(256) void gemm_grouped_kernel(GroupLaunch G) {
@@ -214,8 +232,8 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(GroupLaunch G) {
   const int bx = local % G.tx[i], by = (local / G.tx[i]) % G.ty[i], bzz = local / (G.tx[i] * G.ty[i]);
   const mmda_gemm_args g = G.p[i];      // one copy into SGPRs; indexing the kernarg array inside the k-loop would re-load fields
   const int sk = G.splitk[i];
-  if (g.mode == MMDA_BF16) gemm_body<MMDA_BF16, 1>(g, sk, smem, bx, by, bzz);
-  else gemm_body<MMDA_F32, 1>(g, sk, smem, bx, by, bzz);
+  if (g.mode == MMDA_BF16) gemm_body<MMDA_BF16, 1>(g, sk, smem, bx, by, bzz, G.slab[i], G.ldn[i]);
+  else gemm_body<MMDA_F32, 1>(g, sk, smem, bx, by, bzz, G.slab[i], G.ldn[i]);
 }
 
 // ------------------------------------------------------------------------------------------------ 128x128 bf16 tile
@@ -226,7 +244,7 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(GroupLaunch G) {
 constexpr int TM = 128, TN = 128;
 
 template <bool TA, bool TB>
-__global__ __launch_bounds__(256) void gemm128_bf16_kernel(mmda_gemm_args g, int splitk) {
+__global__ __launch_bounds__(256) void gemm128_bf16_kernel(mmda_gemm_args g, int splitk, float* slab, int ldn) {
   __shared__ __attribute__((aligned(16))) unsigned short As[TM * LDS_BF16_LD];
   __shared__ __attribute__((aligned(16))) unsigned short Bs[TN * LDS_BF16_LD];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -336,7 +354,7 @@ __global__ __launch_bounds__(256) void gemm128_bf16_kernel(mmda_gemm_args g, int
         const int m = row0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
         if (m >= M) continue;
         const int64_t ci = (int64_t)m * g.ldc + n;
-        if (splitk > 1) { atomicAdd(&C[ci], alpha * acc[i][j][r] + (sp == 0 ? bsum : 0.f)); continue; }
+        if (splitk > 1) { slab[(((int64_t)bz * splitk + sp) * M + m) * ldn + n] = acc[i][j][r]; continue; }
         float v = alpha * acc[i][j][r] + bsum;
         if (g.accumulate) v += C[ci];
         C[ci] = v;
@@ -344,7 +362,9 @@ __global__ __launch_bounds__(256) void gemm128_bf16_kernel(mmda_gemm_args g, int
     }
 }
 
-__global__ void colsum_kernel(const float* __restrict__ X, int ld, int M, int N, float* out, float* out2, int rows_per_block) {
+// column sums of X (M, N) added into out (and out2): stage 1 writes one partial row per row block, stage 2 adds the partials of a
+// column in block order (no atomics: the same bits on every run)
+__global__ void colsum_kernel(const float* __restrict__ X, int ld, int M, int N, float* part, int rows_per_block) {
   __shared__ float red[4][64];
   int c = blockIdx.x * 64 + (threadIdx.x & 63);
   int rg = threadIdx.x >> 6;
@@ -354,11 +374,15 @@ __global__ void colsum_kernel(const float* __restrict__ X, int ld, int M, int N,
     for (int r = r0 + rg; r < r1; r += 4) s += X[(int64_t)r * ld + c];
   red[rg][threadIdx.x & 63] = s;
   __syncthreads();
-  if (rg == 0 && c < N) {
-    float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    atomicAdd(&out[c], t);
-    if (out2) atomicAdd(&out2[c], t);
-  }
+  if (rg == 0 && c < N) part[(int64_t)blockIdx.y * N + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ void colsum_finish_kernel(const float* __restrict__ part, int nparts, int N, float* out, float* out2) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  float t = 0.f;
+  for (int p = 0; p < nparts; ++p) t += part[(int64_t)p * N + c];
+  out[c] += t;
+  if (out2) out2[c] += t;
 }
 
 }  // namespace
@@ -384,12 +408,16 @@ extern "C" int mmda_gemm(const mmda_gemm_args* a, void* stream) {
     if (splitk > 64) splitk = 64;
     if (splitk < 1) splitk = 1;
   }
-  if (splitk > 1 && !a->accumulate) {
-    // the atomics need a zeroed destination; only done for plain contiguous outputs, otherwise no split
-    bool contiguous = (a->ldc == a->N) && (a->batch == 1 || a->strideC == (int64_t)a->M * a->N);
-    if (!contiguous) splitk = 1;
-    else if (hipMemsetAsync(a->C, 0, sizeof(float) * (size_t)a->M * a->N * a->batch, s) != hipSuccess) return MMDA_ELAUNCH;
-  }
+  // no empty slices (an empty slice would leave its slab unwritten)
+  auto norm_split = [](int nk_, int sk_) { const int per = ceil_div(nk_, sk_ < 1 ? 1 : sk_); return ceil_div(nk_, per); };
+  splitk = norm_split(nk, splitk);
+  auto reduce_job = [&](const float* slab, int ldn, int sk) {
+    SplitKJob J = {};
+    J.slab = slab; J.C = a->C; J.M = a->M; J.N = a->N; J.ldn = ldn; J.ldc = a->ldc; J.sk = sk; J.batch = a->batch;
+    J.strideC = a->strideC; J.strideBias = a->strideBias; J.alpha = a->alpha; J.bias = a->bias; J.bias2 = a->bias2;
+    J.bias_grad = a->bias_grad; J.bias_grad2 = a->bias_grad2; J.accumulate = a->accumulate;
+    return J;
+  };
   // large aligned bf16 GEMMs -> 128x128 tile kernel with 16-byte staging loads
   const bool aligned = ((a->lda | a->ldb | a->K) & 3) == 0 && (((uintptr_t)a->A | (uintptr_t)a->B) & 15) == 0 &&
                        ((a->strideA | a->strideB) & 3) == 0 && (!a->transA || (a->M & 3) == 0) && (a->transB || (a->N & 3) == 0);
@@ -403,32 +431,42 @@ extern "C" int mmda_gemm(const mmda_gemm_args* a, void* stream) {
       if (sk > 64) sk = 64;
       if (sk < 1) sk = 1;
     }
-    if (sk > 1 && !a->accumulate) {
-      bool contiguous = (a->ldc == a->N) && (a->batch == 1 || a->strideC == (int64_t)a->M * a->N);
-      if (!contiguous) sk = 1;
-      else if (splitk <= 1 && hipMemsetAsync(a->C, 0, sizeof(float) * (size_t)a->M * a->N * a->batch, s) != hipSuccess) return MMDA_ELAUNCH;
+    sk = norm_split(nk, sk);
+    float* slab = nullptr;
+    const int ldn = a->N;
+    if (sk > 1) {
+      slab = mmda_scratch_get(s, sizeof(float) * (size_t)a->batch * sk * a->M * ldn);
+      if (!slab) return MMDA_ELAUNCH;
     }
     dim3 grid128(ceil_div(a->N, TN), ceil_div(a->M, TM), a->batch * sk);
     if (grid128.y > 65535 || grid128.z > 65535) return MMDA_EINVAL;
-    if (!a->transA && a->transB) hipLaunchKernelGGL((gemm128_bf16_kernel<false, true>), grid128, dim3(256), 0, s, *a, sk);
-    else if (!a->transA && !a->transB) hipLaunchKernelGGL((gemm128_bf16_kernel<false, false>), grid128, dim3(256), 0, s, *a, sk);
-    else if (a->transA && !a->transB) hipLaunchKernelGGL((gemm128_bf16_kernel<true, false>), grid128, dim3(256), 0, s, *a, sk);
-    else hipLaunchKernelGGL((gemm128_bf16_kernel<true, true>), grid128, dim3(256), 0, s, *a, sk);
+    if (!a->transA && a->transB) hipLaunchKernelGGL((gemm128_bf16_kernel<false, true>), grid128, dim3(256), 0, s, *a, sk, slab, ldn);
+    else if (!a->transA && !a->transB) hipLaunchKernelGGL((gemm128_bf16_kernel<false, false>), grid128, dim3(256), 0, s, *a, sk, slab, ldn);
+    else if (a->transA && !a->transB) hipLaunchKernelGGL((gemm128_bf16_kernel<true, false>), grid128, dim3(256), 0, s, *a, sk, slab, ldn);
+    else hipLaunchKernelGGL((gemm128_bf16_kernel<true, true>), grid128, dim3(256), 0, s, *a, sk, slab, ldn);
     MMDA_CHECK_LAUNCH("mmda_gemm(128)");
+    if (sk > 1) { SplitKJob J = reduce_job(slab, ldn, sk); return mmda_splitk_reduce(&J, 1, s); }
     return MMDA_OK;
+  }
+  float* slab = nullptr;
+  const int ldn = Neff;
+  if (splitk > 1) {
+    slab = mmda_scratch_get(s, sizeof(float) * (size_t)a->batch * splitk * a->M * ldn);
+    if (!slab) return MMDA_ELAUNCH;
   }
   dim3 grid(ceil_div(Neff, BN), ceil_div(a->M, BM), a->batch * splitk);
   if (grid.y > 65535 || grid.z > 65535) return MMDA_EINVAL;
   const int per_split = ceil_div(nk, splitk);
   const bool tiny = per_split <= 4 && (int)(grid.x * grid.y * grid.z) <= 1024;
   if (a->mode == MMDA_BF16) {
-    if (tiny) hipLaunchKernelGGL((gemm_kernel<MMDA_BF16, 4>), grid, dim3(256), 0, s, *a, splitk);
-    else hipLaunchKernelGGL((gemm_kernel<MMDA_BF16, 1>), grid, dim3(256), 0, s, *a, splitk);
+    if (tiny) hipLaunchKernelGGL((gemm_kernel<MMDA_BF16, 4>), grid, dim3(256), 0, s, *a, splitk, slab, ldn);
+    else hipLaunchKernelGGL((gemm_kernel<MMDA_BF16, 1>), grid, dim3(256), 0, s, *a, splitk, slab, ldn);
   } else {
-    if (tiny) hipLaunchKernelGGL((gemm_kernel<MMDA_F32, 4>), grid, dim3(256), 0, s, *a, splitk);
-    else hipLaunchKernelGGL((gemm_kernel<MMDA_F32, 1>), grid, dim3(256), 0, s, *a, splitk);
+    if (tiny) hipLaunchKernelGGL((gemm_kernel<MMDA_F32, 4>), grid, dim3(256), 0, s, *a, splitk, slab, ldn);
+    else hipLaunchKernelGGL((gemm_kernel<MMDA_F32, 1>), grid, dim3(256), 0, s, *a, splitk, slab, ldn);
   }
   MMDA_CHECK_LAUNCH("mmda_gemm");
+  if (splitk > 1) { SplitKJob J = reduce_job(slab, ldn, splitk); return mmda_splitk_reduce(&J, 1, s); }
   return MMDA_OK;
 }
 
@@ -449,12 +487,16 @@ extern "C" int mmda_gemm_grouped(const mmda_gemm_args* args, int n, void* stream
       if (a.bias_grad && !a.transA) return MMDA_EINVAL;
       tiles_total += ceil_div(a.N + (a.bias_grad ? 1 : 0), BN) * ceil_div(a.M, BM) * a.batch;
     }
+    std::vector<SplitKJob> jobs;
+    std::vector<int> jk;                   // group slot of each job
+    int64_t slab_floats = 0;
     for (int i = 0; i < cnt; ++i) {
       const mmda_gemm_args& a = args[base + i];
       if (a.M == 0 || a.N == 0 || a.batch == 0) continue;
       const int k = G.n++;
       G.p[k] = a;
-      G.tx[k] = ceil_div(a.N + (a.bias_grad ? 1 : 0), BN); G.ty[k] = ceil_div(a.M, BM);
+      const int Ne = a.N + (a.bias_grad ? 1 : 0);
+      G.tx[k] = ceil_div(Ne, BN); G.ty[k] = ceil_div(a.M, BM);
       const int nk = ceil_div(a.K, BK);
       int sk = 1;
       const bool plain = a.act == MMDA_ACT_NONE && a.drop_p <= 0.f && !a.gate;
@@ -464,20 +506,35 @@ extern "C" int mmda_gemm_grouped(const mmda_gemm_args* args, int n, void* stream
         if (sk > 32) sk = 32;
         if (sk < 1) sk = 1;
       }
-      if (sk > 1 && !a.accumulate) {
-        bool contiguous = (a.ldc == a.N) && (a.batch == 1 || a.strideC == (int64_t)a.M * a.N);
-        if (!contiguous) sk = 1;
-        else if (hipMemsetAsync(a.C, 0, sizeof(float) * (size_t)a.M * a.N * a.batch, s) != hipSuccess) return MMDA_ELAUNCH;
-      }
+      { const int per = ceil_div(nk, sk); sk = ceil_div(nk, per); }     // no empty slices
       G.splitk[k] = sk;
+      G.slab[k] = nullptr; G.ldn[k] = Ne;
+      if (sk > 1) {
+        SplitKJob J = {};
+        J.C = a.C; J.M = a.M; J.N = a.N; J.ldn = Ne; J.ldc = a.ldc; J.sk = sk; J.batch = a.batch;
+        J.strideC = a.strideC; J.strideBias = a.strideBias; J.alpha = a.alpha; J.bias = a.bias; J.bias2 = a.bias2;
+        J.bias_grad = a.bias_grad; J.bias_grad2 = a.bias_grad2; J.accumulate = a.accumulate;
+        J.slab = reinterpret_cast<const float*>((uintptr_t)slab_floats);      // offset for now; the base is added below
+        slab_floats += (int64_t)a.batch * sk * a.M * Ne;
+        jobs.push_back(J); jk.push_back(k);
+      }
       G.start[k] = blocks;
       blocks += G.tx[k] * G.ty[k] * a.batch * sk;
     }
     for (int k = G.n; k <= GROUP_MAX; ++k) G.start[k] = blocks;
-    for (int k = G.n; k < GROUP_MAX; ++k) { G.p[k] = G.p[0]; G.tx[k] = G.ty[k] = G.splitk[k] = 1; }
+    for (int k = G.n; k < GROUP_MAX; ++k) { G.p[k] = G.p[0]; G.tx[k] = G.ty[k] = G.splitk[k] = 1; G.slab[k] = nullptr; G.ldn[k] = 0; }
     if (blocks == 0) continue;
+    if (!jobs.empty()) {
+      float* slab_base = mmda_scratch_get(s, sizeof(float) * (size_t)slab_floats);
+      if (!slab_base) return MMDA_ELAUNCH;
+      for (size_t j = 0; j < jobs.size(); ++j) {
+        float* p = slab_base + (int64_t)(uintptr_t)jobs[j].slab;
+        jobs[j].slab = p; G.slab[jk[j]] = p;
+      }
+    }
     hipLaunchKernelGGL(gemm_grouped_kernel, dim3(blocks), dim3(256), 0, s, G);
     MMDA_CHECK_LAUNCH("mmda_gemm_grouped");
+    if (!jobs.empty()) { const int rc = mmda_splitk_reduce(jobs.data(), (int)jobs.size(), s); if (rc) return rc; }
   }
   return MMDA_OK;
 }
@@ -487,7 +544,10 @@ extern "C" int mmda_colsum(const float* X, int ld, int M, int N, float* out, flo
   if (M == 0) return MMDA_OK;
   int rpb = 256;
   dim3 grid(ceil_div(N, 64), ceil_div(M, rpb));
-  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, ld, M, N, out, out2, rpb);
+  float* part = mmda_scratch_get((hipStream_t)stream, sizeof(float) * (size_t)grid.y * N);
+  if (!part) return MMDA_ELAUNCH;
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, ld, M, N, part, rpb);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream, part, (int)grid.y, N, out, out2);
   MMDA_CHECK_LAUNCH("mmda_colsum");
   return MMDA_OK;
 }

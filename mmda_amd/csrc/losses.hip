@@ -3,6 +3,7 @@
 // the total loss is a fixed weighted sum (solver.py:175-181), so the backward seed of each term is its weight.
 // These are batch-statistic reductions over (B, 128)-sized tensors: latency work on a handful of workgroups.
 #include "common.h"
+#include "splitk.h"
 
 namespace {
 
@@ -41,6 +42,20 @@ __global__ void heads_bwd_kernel(const float* __restrict__ tcp, const float* __r
     }
     dlogits[e] = g;
   }
+}
+
+// A loss that several workgroups contribute to: every workgroup leaves its partial in parts[block] and ONE thread adds them in block
+// order (float atomics added them in arrival order: the reported value changed in its last bits from run to run).
+__global__ void loss_parts_finish_kernel(const float* __restrict__ parts, int n, float* loss) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float t = 0.f;
+  for (int i = 0; i < n; ++i) t += parts[i];
+  *loss += t;
+}
+__device__ __forceinline__ void loss_parts_add(const float* __restrict__ parts, int n, float* loss) {   // same, from inside a later kernel
+  float t = 0.f;
+  for (int i = 0; i < n; ++i) t += parts[i];
+  *loss += t;
 }
 
 // ------------------------------------------------------------------------------------------------ cls (BCE)
@@ -101,7 +116,7 @@ __global__ __launch_bounds__(256) void conf_kernel(const float* __restrict__ s, 
   }
   lt = block_sum(lt, red);
   lm = block_sum(lm, red);
-  if (threadIdx.x == 0 && loss) atomicAdd(loss, lt / (B * nz) + lm / nz);
+  if (threadIdx.x == 0 && loss) loss[blockIdx.x] = lt / (B * nz) + lm / nz;      // `loss` = this launch's partial array (one per class)
 }
 
 // ------------------------------------------------------------------------------------------------ cls + conf + recon + total
@@ -115,6 +130,7 @@ struct MiscLossArgs {
   float conf_scale;
   const float* recon; const float* orig; int64_t n_recon; float recon_inv_n, recon_scale; float* d_recon; float* d_orig;
   float* L;                                 // cls, diff, sim, recon, conf, total, -, ticket
+  float* parts;                             // one partial per workgroup (role order); the last workgroup adds them in that order
   float dw, sw, rw, cw; int use_conf, with_conf;
   int recon_blocks;
 };
@@ -133,7 +149,7 @@ __global__ __launch_bounds__(256) void misc_losses_kernel(MiscLossArgs a) {
       if (a.d_scores) atomicAdd(&a.d_scores[e], (sv - yv) / fmaxf(sv * (1.f - sv), 1e-12f) / B);
     }
     float t = block_sum(acc, red);
-    if (threadIdx.x == 0) atomicAdd(&a.L[0], t / B);
+    if (threadIdx.x == 0) a.parts[role] = t / B;
   } else if (role <= (a.with_conf ? ncls : 0)) {
     const int c = role - 1;
     const float* s = a.scores; const float* y = a.emo;
@@ -171,7 +187,7 @@ __global__ __launch_bounds__(256) void misc_losses_kernel(MiscLossArgs a) {
     }
     lt = block_sum(lt, red);
     lm = block_sum(lm, red);
-    if (threadIdx.x == 0) atomicAdd(&a.L[4], lt / (B * nz) + lm / nz);
+    if (threadIdx.x == 0) a.parts[role] = lt / (B * nz) + lm / nz;
   } else {
     const int rb = role - 1 - (a.with_conf ? ncls : 0);
     float acc = 0.f;
@@ -183,7 +199,7 @@ __global__ __launch_bounds__(256) void misc_losses_kernel(MiscLossArgs a) {
       if (a.d_orig) a.d_orig[e] -= g;
     }
     float t = block_sum(acc, red);
-    if (threadIdx.x == 0) atomicAdd(&a.L[3], t * a.recon_inv_n);
+    if (threadIdx.x == 0) a.parts[role] = t * a.recon_inv_n;
   }
   // the last block to arrive sees every sum (release by the fence before the ticket, agent-scope reads after it)
   if (threadIdx.x == 0) {
@@ -191,6 +207,13 @@ __global__ __launch_bounds__(256) void misc_losses_kernel(MiscLossArgs a) {
     unsigned* ticket = reinterpret_cast<unsigned*>(a.L + 7);
     const unsigned prev = atomicAdd(ticket, 1u);
     if (prev == gridDim.x - 1) {
+      __threadfence();
+      // cls, conf and recon: the workgroups' partials in role order (L[0], L[3], L[4] were cleared with the rest of the loss block)
+      const int nconf = a.with_conf ? ncls : 0;
+      float cls = __hip_atomic_load(a.parts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), conf = 0.f, rec = 0.f;
+      for (int i = 0; i < nconf; ++i) conf += __hip_atomic_load(a.parts + 1 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int i = 0; i < a.recon_blocks; ++i) rec += __hip_atomic_load(a.parts + 1 + nconf + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      a.L[0] += cls; a.L[4] += conf; a.L[3] += rec;
       __threadfence();
       float v[5];
       for (int i = 0; i < 5; ++i) v[i] = __hip_atomic_load(a.L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -292,9 +315,10 @@ __global__ __launch_bounds__(1024) void diff_prep_fast_kernel(const float* __res
 
 template <int RPT>
 __global__ __launch_bounds__(1024) void diff_finish_fast_kernel(const float* __restrict__ dA, const float* __restrict__ invn, int B,
-                                                                int D, int64_t stride, float* dx) {
+                                                                int D, int64_t stride, float* dx, const float* lparts, int nparts, float* loss) {
   __shared__ float P[8][128];
   const int k = blockIdx.x, tid = threadIdx.x, c = tid & 127, rg = tid >> 7;
+  if (k == 0 && tid == 0 && loss) loss_parts_add(lparts, nparts, loss);        // the combine launch's loss partials, in block order
   const int cc = min(c, D - 1);
   const bool c_ok = c < D;
   float v[RPT], old[RPT];
@@ -354,12 +378,13 @@ __global__ __launch_bounds__(256) void diff_combine_kernel(const float* __restri
       if (t < pl.nt) Ksum[t * BB + e] = ks[t] * gscale;
   }
   float t = block_sum(acc, red);
-  if (threadIdx.x == 0 && loss) atomicAdd(loss, t / ((float)D * D));
+  if (threadIdx.x == 0 && loss) loss[blockIdx.x] = t / ((float)D * D);          // `loss` = this launch's partial array (one per block)
 }
 
 __global__ __launch_bounds__(256) void diff_finish_kernel(const float* __restrict__ dA, const float* __restrict__ invn, int B,
-                                                          int D, int64_t stride, float* dx) {
+                                                          int D, int64_t stride, float* dx, const float* lparts, int nparts, float* loss) {
   const int k = blockIdx.x;
+  if (k == 0 && threadIdx.x == 0 && loss) loss_parts_add(lparts, nparts, loss);
   for (int i = threadIdx.x; i < D; i += blockDim.x) {
     float s = 0.f;
     for (int r = 0; r < B; ++r) s += dA[((int64_t)k * B + r) * D + i] * invn[k * B + r];
@@ -699,7 +724,7 @@ __global__ __launch_bounds__(256) void recon_kernel(const float* __restrict__ re
     if (dorig) dorig[e] -= g;
   }
   float t = block_sum(acc, red);
-  if (threadIdx.x == 0 && loss) atomicAdd(loss, t * inv_n);
+  if (threadIdx.x == 0 && loss) loss[blockIdx.x] = t * inv_n;                   // `loss` = this launch's partial array (one per block)
 }
 
 // ------------------------------------------------------------------------------------------------ domain (CE)
@@ -801,7 +826,10 @@ extern "C" int mmda_loss_cls(const float* scores, const float* emo, int B, int n
 extern "C" int mmda_loss_conf(const float* scores, const float* tcp, const float* emo, int B, int ncls, float scale, float* loss,
                               float* dscores, float* dtcp, void* stream) {
   if (!scores || !tcp || !emo || B <= 0 || ncls != 6) return MMDA_EINVAL;   // tcp has 6 columns (models.py:139)
-  hipLaunchKernelGGL(conf_kernel, dim3(ncls), dim3(256), 0, (hipStream_t)stream, scores, tcp, emo, B, ncls, scale, loss, dscores, dtcp);
+  float* parts = loss ? mmda_scratch_get((hipStream_t)stream, sizeof(float) * ncls) : nullptr;
+  if (loss && !parts) return MMDA_ELAUNCH;
+  hipLaunchKernelGGL(conf_kernel, dim3(ncls), dim3(256), 0, (hipStream_t)stream, scores, tcp, emo, B, ncls, scale, parts, dscores, dtcp);
+  if (loss) hipLaunchKernelGGL(loss_parts_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, parts, ncls, loss);
   MMDA_CHECK_LAUNCH("mmda_loss_conf");
   return MMDA_OK;
 }
@@ -865,8 +893,18 @@ extern "C" int mmda_loss_diff_pairs(const float* x, int64_t stride, int nt, int 
   }
   if (rc) return rc;
   int blocks = (int)((BB + 255) / 256); if (blocks > 256) blocks = 256;
-  hipLaunchKernelGGL(diff_combine_kernel, dim3(blocks), dim3(256), 0, s, K, B, D, scale, loss, Ksum, pl);
+  // the loss value: one partial per block (per-stream scratch), added in block order -- by the finish launch below when it follows with
+  // nothing but a row-skinny GEMM in between (which takes no scratch), else by a launch of its own right here
+  float* lparts = loss ? mmda_scratch_get(s, sizeof(float) * 256) : nullptr;
+  if (loss && !lparts) return MMDA_ELAUNCH;
+  hipLaunchKernelGGL(diff_combine_kernel, dim3(blocks), dim3(256), 0, s, K, B, D, scale, lparts, Ksum, pl);
   MMDA_CHECK_LAUNCH("mmda_loss_diff/combine");
+  const bool sum_later = loss && dx && B <= 256;
+  if (loss && !sum_later) {
+    hipLaunchKernelGGL(loss_parts_finish_kernel, dim3(1), dim3(64), 0, s, lparts, blocks, loss);
+    MMDA_CHECK_LAUNCH("mmda_loss_diff/loss");
+  }
+  float* const loss_later = sum_later ? loss : nullptr;
   if (!dx) return MMDA_OK;
   if (B <= 256) {
     mmda_skinny_args sk[6];
@@ -886,12 +924,12 @@ extern "C" int mmda_loss_diff_pairs(const float* x, int64_t stride, int nt, int 
   }
   if (rc) return rc;
   if (fast) {
-    if (B <= 32) hipLaunchKernelGGL(diff_finish_fast_kernel<4>, dim3(nt), dim3(1024), 0, s, dA, invn, B, D, stride, dx);
-    else if (B <= 64) hipLaunchKernelGGL(diff_finish_fast_kernel<8>, dim3(nt), dim3(1024), 0, s, dA, invn, B, D, stride, dx);
-    else if (B <= 128) hipLaunchKernelGGL(diff_finish_fast_kernel<16>, dim3(nt), dim3(1024), 0, s, dA, invn, B, D, stride, dx);
-    else hipLaunchKernelGGL(diff_finish_fast_kernel<32>, dim3(nt), dim3(1024), 0, s, dA, invn, B, D, stride, dx);
+    if (B <= 32) hipLaunchKernelGGL(diff_finish_fast_kernel<4>, dim3(nt), dim3(1024), 0, s, dA, invn, B, D, stride, dx, lparts, blocks, loss_later);
+    else if (B <= 64) hipLaunchKernelGGL(diff_finish_fast_kernel<8>, dim3(nt), dim3(1024), 0, s, dA, invn, B, D, stride, dx, lparts, blocks, loss_later);
+    else if (B <= 128) hipLaunchKernelGGL(diff_finish_fast_kernel<16>, dim3(nt), dim3(1024), 0, s, dA, invn, B, D, stride, dx, lparts, blocks, loss_later);
+    else hipLaunchKernelGGL(diff_finish_fast_kernel<32>, dim3(nt), dim3(1024), 0, s, dA, invn, B, D, stride, dx, lparts, blocks, loss_later);
   } else {
-    hipLaunchKernelGGL(diff_finish_kernel, dim3(nt), dim3(256), 0, s, dA, invn, B, D, stride, dx);
+    hipLaunchKernelGGL(diff_finish_kernel, dim3(nt), dim3(256), 0, s, dA, invn, B, D, stride, dx, lparts, blocks, loss_later);
   }
   MMDA_CHECK_LAUNCH("mmda_loss_diff/finish");
   return MMDA_OK;
@@ -949,8 +987,11 @@ extern "C" int mmda_loss_recon(const float* recon, const float* orig, int64_t st
   for (int k = 0; k < nl; ++k) {
     int64_t cnt = (nl == 1) ? 3 * n : n;
     int blocks = (int)((cnt + 255) / 256); if (blocks > 64) blocks = 64;
+    float* parts = loss ? mmda_scratch_get((hipStream_t)stream, sizeof(float) * 64) : nullptr;
+    if (loss && !parts) return MMDA_ELAUNCH;
     hipLaunchKernelGGL(recon_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, recon + k * stride, orig + k * stride, cnt,
-                       1.0f / (3.0f * n), scale, loss, drecon ? drecon + k * stride : nullptr, dorig ? dorig + k * stride : nullptr);
+                       1.0f / (3.0f * n), scale, parts, drecon ? drecon + k * stride : nullptr, dorig ? dorig + k * stride : nullptr);
+    if (loss) hipLaunchKernelGGL(loss_parts_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, parts, blocks, loss);
   }
   MMDA_CHECK_LAUNCH("mmda_loss_recon");
   return MMDA_OK;
@@ -970,6 +1011,8 @@ extern "C" int mmda_loss_misc(const float* scores, const float* tcp, const float
   int rb = (int)((n_recon + 255) / 256); if (rb > 64) rb = 64;
   a.recon_blocks = rb;
   const int blocks = 1 + (with_conf ? ncls : 0) + rb;
+  a.parts = mmda_scratch_get((hipStream_t)stream, sizeof(float) * blocks);
+  if (!a.parts) return MMDA_ELAUNCH;
   hipLaunchKernelGGL(misc_losses_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
   MMDA_CHECK_LAUNCH("mmda_loss_misc");
   return MMDA_OK;

@@ -64,7 +64,7 @@ struct mmda_misa {
   int64_t zero_begin = 0, zero_end = 0;      // activation-gradient region that is zeroed per step
   int64_t gpad_begin = 0, gpad_end = 0;      // GRU: four-slot weight gradients (zeroed at set_workspace, re-zeroed by the unpad kernel)
   int64_t z, pmean, prstd, orig, x6, rsum, recon, dom_z, dom_h, dom, qkv, probs, ctx, attn_out, ln1_mean, ln1_rstd, x1, f1, f2,
-      ln2_mean, ln2_rstd, hfused, logits, tcp, scores, labels, losses, diff_work, touched, ffn_parts;
+      ln2_mean, ln2_rstd, hfused, logits, tcp, scores, labels, losses, diff_work, touched, ffn_parts, pg_parts;
   // K-major (transposed) fp32 copies of the fusion block's weights for its input-gradient GEMMs (made once per step)
   int64_t head_wT, l2_wT, l1_wT, out_wT, in_wT, rec_wT, priv_wT, sh_wT, d1_wT = -1, d2_wT = -1, pwT[3];
   int wT_valid = 0;
@@ -282,6 +282,7 @@ int64_t layout(mmda_misa* m, int B, int T, bool commit) {
   o->w2q = k.take((int64_t)hs * FFN / 4); o->w2s = k.take((int64_t)hs * FFN / 128 + 4);
   o->diff_work = k.take(mmda_loss_diff_work_floats(B, hs));
   o->ffn_parts = k.take((int64_t)(FFN / 32) * 6 * BH);      // partial products of the hidden-sliced feed-forward kernels (fused_rows.hip)
+  o->pg_parts = k.take((int64_t)B * FUSED_PG_SLOTS * 2 * 128);      // per-sample LayerNorm gamma / beta gradient partials of the fused backward stretches
   o->touched = k.take((c.vocab + 3) / 4);              // one byte per embedding row: occurs in this batch (see mmda_clamp_adam_rows)
   o->head_wT = k.take((int64_t)6 * hs * NC); o->l2_wT = k.take((int64_t)FFN * hs); o->l1_wT = k.take((int64_t)hs * FFN);
   o->out_wT = k.take((int64_t)hs * hs); o->in_wT = k.take((int64_t)hs * 3 * hs); o->rec_wT = k.take((int64_t)3 * hs * hs);
@@ -794,7 +795,9 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
   // and runs 15 - 20 % slower at K = 12800 (twice the LDS read instructions per k-tile), which at large batches outweighs the
   // conversions it saves.  MMDA_GEMM_TN=0: the transposed-copy (nt) form everywhere; MMDA_GEMM_TN_MAX_ROWS moves the limit.
   static const int tn_on = getenv("MMDA_GEMM_TN") ? atoi(getenv("MMDA_GEMM_TN")) : 1;
-  static const int tn_max_rows = getenv("MMDA_GEMM_TN_MAX_ROWS") ? atoi(getenv("MMDA_GEMM_TN_MAX_ROWS")) : 4096;
+  // Round 3: the LDS-DMA pipelined GEMM (gemm_bf16_dma_kernel) runs the tn form at K = 12800 as fast as the nt form, so the limit is
+  // gone by default (B=256: the 0.47 ms of transposing conversions per step with it).
+  static const int tn_max_rows = getenv("MMDA_GEMM_TN_MAX_ROWS") ? atoi(getenv("MMDA_GEMM_TN_MAX_ROWS")) : (1 << 30);
   // (Layer 1 alone in the tn form beyond that limit -- its transposed gate-gradient copy, 0.2 ms at B=256, is the one that cannot hide
   // beside a recurrence -- measured slower too: B=128 1.285 -> 1.315 ms, B=256 2.20 -> 2.29, T=500 3.92 -> 3.96.  MMDA_GEMM_TN_L1=1.)
   static const int tn_l1 = getenv("MMDA_GEMM_TN_L1") ? atoi(getenv("MMDA_GEMM_TN_L1")) : 0;
@@ -1196,6 +1199,7 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
   // Weight-gradient GEMMs of the fusion block are collected and issued as one grouped launch on the side stream once
   // the dX chain (the critical path into the encoders) is through; their inputs are not modified afterwards.
   x.deferring = true;
+  bool pg_pending = false;               // the fused stretches left LayerNorm parameter-gradient partials (mmda_fused_pg_finish)
   if (B <= SKINNY_MAX_B) {
     // ---- few rows: the dX chain on row-skinny GEMMs (13 launches); weight gradients deferred exactly as below
     mmda_skinny_args g[8];
@@ -1216,6 +1220,7 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
       f.B = B; f.hs = hs; f.ncls = c.ncls; f.nb = fuse_nb;
       f.tcp = WS(m->tcp); f.scores = WS(m->scores); f.d_tcp = WS(m->d_tcp); f.d_scores = WS(m->d_scores); f.d_logits = WS(m->d_logits);
       f.p_cls = p_cls; f.seed = seed; f.site_cls = SITE_CLS; f.head_w = PP(m->head_w); f.d_hfused = WS(m->d_hfused); f.ln2 = l2a;
+      f.pg_parts = WS(m->pg_parts);
       x.rc = mmda_fused_bwd_c(&f, stream);
     } else {
       x.rc = mmda_heads_bwd(WS(m->tcp), WS(m->scores), WS(m->d_tcp), WS(m->d_scores), B, c.ncls, WS(m->d_logits), p_cls, seed, SITE_CLS,
@@ -1270,7 +1275,9 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
         lp.dgamma = GG(md.plw); lp.dbeta = GG(md.plb); lp.act = c.act;
         lp.actp = act_params(m, training, seed, SITE_RRELU + i, true);
       }
+      f.pg_parts = WS(m->pg_parts);
       x.rc = mmda_fused_bwd_a(&f, stream);
+      pg_pending = true;
       // the weight gradients of the stretch (deferred: one grouped launch on the side stream, as below)
       lin_dw(x, fmode, 6 * B, hs, hs, WS(m->d_attn_out), WS(m->ctx), GG(m->out_w), GG(m->out_b));
       lin_dw(x, fmode, 6 * B, 3 * hs, hs, WS(m->d_qkv), WS(m->x6), GG(m->in_w), GG(m->in_b));
@@ -1462,6 +1469,12 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
     void* ss = nullptr;
     x.rc = side_fork(m, stream, &ss);
     if (!x.rc && B <= SKINNY_MAX_B) x.rc = mmda_add(WS(m->x6), WS(m->x6 + 3 * BH), WS(m->rsum), 3 * BH, ss);
+    if (!x.rc && pg_pending) {
+      // gamma / beta gradients of the five LayerNorms the fused stretches walked: per-sample partials added in sample order
+      float* dg[FUSED_PG_SLOTS] = {GG(m->n2_w), GG(m->n1_w), GG(m->mod[0].plw), GG(m->mod[1].plw), GG(m->mod[2].plw)};
+      float* db[FUSED_PG_SLOTS] = {GG(m->n2_b), GG(m->n1_b), GG(m->mod[0].plb), GG(m->mod[1].plb), GG(m->mod[2].plb)};
+      x.rc = mmda_fused_pg_finish(WS(m->pg_parts), B, hs, dg, db, ss);
+    }
     if (!x.rc && !x.deferred.empty()) x.rc = mmda_gemm_grouped(x.deferred.data(), (int)x.deferred.size(), ss);
     x.deferred.clear();
     // the bf16 operand copies that only the weight-gradient GEMMs read (hseq of both layers, nt form: transposed layer-2 inputs): here,

@@ -2,6 +2,7 @@
 // small elementwise helpers.  All HBM-bound; loads are lane-consecutive (coalesced 256 B per wave instruction).
 #include "common.h"
 #include "rowlocal.h"
+#include "splitk.h"
 
 namespace {
 
@@ -9,7 +10,9 @@ constexpr int LN_MAXQ = 16;   // up to 16*64 = 1024 columns cached in registers 
 
 constexpr int LN_MAXP = 4;      // problems per launch (the three modalities' LayerNorms go out together)
 struct LnMulti { mmda_ln_args a[LN_MAXP]; int start[LN_MAXP + 1]; int n; };
-struct LnBwdMulti { mmda_ln_bwd_args a[LN_MAXP]; int start[LN_MAXP + 1]; int nblk[LN_MAXP]; int n; };
+// part[p]: (nblk[p], 2, n) partial gamma / beta gradients of problem p, one row pair per block (ln_bwd_kernel) or row chunk
+// (ln_param_grads_kernel); ln_pg_finish_kernel adds them in block order -- no float atomics, identical bits on every run
+struct LnBwdMulti { mmda_ln_bwd_args a[LN_MAXP]; int start[LN_MAXP + 1]; int nblk[LN_MAXP]; float* part[LN_MAXP]; int n; };
 
 // NQ = values per lane kept in registers (64 NQ >= n): the loops below are fully unrolled over it, so a launch is instantiated
 // for the smallest NQ that covers its widest problem (n = 128 needs 2; the generic 16 costs 8x the instructions)
@@ -43,7 +46,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdMulti L) {
   for (int q = 0; q < NQ; ++q) { dg[q] = 0.f; db[q] = 0.f; }
   for (int row = blk * 4 + wave; row < a.rows; row += nblk * 4) ln_bwd_row<NQ>(a, row, lane, dg, db);      // (rowlocal.h)
   if (!want_pg) return;            // block-uniform: parameter gradients come from mmda_layernorm_param_grads instead
-  // reduce the per-wave column partials across the block's 4 waves, then one atomic per column per block
+  // reduce the per-wave column partials across the block's 4 waves (fixed order): the block's partial row pair
   const int nq = (n + 63) / 64;
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
@@ -53,13 +56,42 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdMulti L) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     float g = red[0][0][i] + red[0][1][i] + red[0][2][i] + red[0][3][i];
     float b = red[1][0][i] + red[1][1][i] + red[1][2][i] + red[1][3][i];
-    if (a.dgamma) atomicAdd(&a.dgamma[i], g);
-    if (a.dbeta) atomicAdd(&a.dbeta[i], b);
+    L.part[pi][((int64_t)blk * 2 + 0) * n + i] = g;
+    L.part[pi][((int64_t)blk * 2 + 1) * n + i] = b;
   }
 }
 
+// dgamma[i] += sum over the blocks' partials in block order (sixteen loads in flight at a time)
+__global__ __launch_bounds__(256) void ln_pg_finish_kernel(LnBwdMulti L) {
+  int pi = 0;
+#pragma unroll
+  for (int k = 1; k < LN_MAXP; ++k)
+    if (k < L.n && (int)blockIdx.x >= L.start[k]) pi = k;
+  const mmda_ln_bwd_args& a = L.a[pi];
+  const int n = a.n;
+  const int e = ((int)blockIdx.x - L.start[pi]) * 256 + threadIdx.x;       // (gamma | beta, column)
+  if (e >= 2 * n) return;
+  const int which = e / n, i = e % n;
+  float* dst = which ? a.dbeta : a.dgamma;
+  if (!dst) return;
+  const float* p = L.part[pi] + (int64_t)which * n + i;
+  const int64_t stride = 2 * (int64_t)n;
+  const int nb = L.nblk[pi];
+  float acc = 0.f;
+  int q = 0;
+  for (; q + 16 <= nb; q += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = p[(q + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc += v[u];
+  }
+  for (; q < nb; ++q) acc += p[q * stride];
+  dst[i] += acc;
+}
+
 // dgamma / dbeta alone, parallel over column strips x row chunks: lane = column (coalesced 256-B rows), no wave reductions,
-// rows/chunk atomics per column instead of one per row-block.  For the three big inter-layer LayerNorms (rows = T*B) the
+// one partial per column and row chunk (added in chunk order by ln_pg_finish_kernel).  For the three big inter-layer LayerNorms (rows = T*B) the
 // fused form above spends most of its time in ~200-way contended atomics; this pass runs off the critical path instead.
 __global__ __launch_bounds__(256) void ln_param_grads_kernel(LnBwdMulti L) {
   __shared__ float red[2][4][64];
@@ -92,8 +124,8 @@ __global__ __launch_bounds__(256) void ln_param_grads_kernel(LnBwdMulti L) {
   if (wave == 0 && i < n) {
     const float g = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
     const float b = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
-    if (a.dgamma) atomicAdd(&a.dgamma[i], g);
-    if (a.dbeta) atomicAdd(&a.dbeta[i], b);
+    L.part[pi][((int64_t)chunk * 2 + 0) * n + i] = g;
+    L.part[pi][((int64_t)chunk * 2 + 1) * n + i] = b;
   }
 }
 
@@ -105,12 +137,50 @@ __global__ void embed_gather_kernel(const float* __restrict__ W, const int64_t* 
   for (int i = threadIdx.x & 63; i < dim; i += 64) dst[i] = src[i];
 }
 
-__global__ void embed_scatter_kernel(float* dW, const int64_t* __restrict__ ids, int rows, int dim, const float* __restrict__ dX) {
-  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  float* dst = dW + ids[row] * (int64_t)dim;
-  const float* src = dX + (int64_t)row * dim;
-  for (int i = threadIdx.x & 63; i < dim; i += 64) atomicAdd(&dst[i], src[i]);   // 256-B contiguous per wave-instruction
+// dW[ids[p]] += dX[p] for every position p, deterministically: one workgroup per position; the workgroup of the FIRST position that
+// holds an id owns that id -- it marks every position with the same id in an LDS bit mask (one pass over the id list), adds their
+// rows in position order and adds the sum to the table row (single writer: no atomics, identical bits on every run; float atomics
+// gave the rows of repeated ids in arrival order).  Windows of 32768 positions keep the mask at 4 KB for any list length.
+constexpr int ES_WIN = 32768;
+__global__ __launch_bounds__(256) void embed_scatter_kernel(float* dW, const int64_t* __restrict__ ids, int rows, int dim, const float* __restrict__ dX) {
+  __shared__ unsigned mask[ES_WIN / 32];
+  __shared__ int earlier;
+  const int p = blockIdx.x;
+  const int64_t id = ids[p];
+  if (id < 0) return;                                    // (padding marker of the gathered lists; block-uniform)
+  if (threadIdx.x == 0) earlier = 0;
+  __syncthreads();
+  for (int q = threadIdx.x; q < p; q += 256)
+    if (ids[q] == id) earlier = 1;                       // benign race: every writer stores 1
+  __syncthreads();
+  if (earlier) return;                                   // an earlier position owns this id (block-uniform)
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};                   // dims threadIdx.x + 256 j (dim <= 1024)
+  for (int w0 = p; w0 < rows; w0 += ES_WIN) {
+    const int wn = min(ES_WIN, rows - w0);
+    for (int i = threadIdx.x; i < (wn + 31) / 32; i += 256) mask[i] = 0u;
+    __syncthreads();
+    for (int q = threadIdx.x; q < wn; q += 256)
+      if (ids[w0 + q] == id) atomicOr(&mask[q >> 5], 1u << (q & 31));
+    __syncthreads();
+    for (int i = 0; i < (wn + 31) / 32; ++i) {
+      unsigned m = mask[i];
+      while (m) {
+        const int q = w0 + 32 * i + __builtin_ctz(m);
+        m &= m - 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int d = threadIdx.x + 256 * j;
+          if (d < dim) acc[j] += dX[(int64_t)q * dim + d];
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int d = threadIdx.x + 256 * j;
+    if (d < dim) dW[id * (int64_t)dim + d] += acc[j];
+  }
 }
 
 __global__ void add_kernel(const float* a, const float* b, float* y, int64_t n) {
@@ -163,6 +233,38 @@ int ln_bwd_check(const mmda_ln_bwd_args* a) {
 }
 }  // namespace
 
+namespace {
+// partial buffers of the problems that want parameter gradients (per-stream scratch, api.hip) ...
+int ln_pg_alloc(LnBwdMulti& L, hipStream_t s) {
+  int64_t floats = 0;
+  for (int k = 0; k < L.n; ++k)
+    if (L.a[k].dgamma || L.a[k].dbeta) floats += (int64_t)L.nblk[k] * 2 * L.a[k].n;
+  for (int k = 0; k < LN_MAXP; ++k) L.part[k] = nullptr;
+  if (floats == 0) return MMDA_OK;
+  float* base = mmda_scratch_get(s, sizeof(float) * (size_t)floats);
+  if (!base) return MMDA_ELAUNCH;
+  for (int k = 0; k < L.n; ++k)
+    if (L.a[k].dgamma || L.a[k].dbeta) { L.part[k] = base; base += (int64_t)L.nblk[k] * 2 * L.a[k].n; }
+  return MMDA_OK;
+}
+// ... and the launch that adds them up, behind the launch that wrote them (same stream)
+int ln_pg_finish(const LnBwdMulti& Lw, hipStream_t s) {
+  LnBwdMulti F = Lw;
+  int blocks = 0, n = 0;
+  for (int k = 0; k < Lw.n; ++k) {
+    if (!Lw.part[k]) continue;
+    F.a[n] = Lw.a[k]; F.nblk[n] = Lw.nblk[k]; F.part[n] = Lw.part[k]; F.start[n] = blocks; blocks += ceil_div(2 * Lw.a[k].n, 256); n++;
+  }
+  if (n == 0) return MMDA_OK;
+  F.n = n;
+  for (int k = n; k <= LN_MAXP; ++k) F.start[k] = blocks;
+  for (int k = n; k < LN_MAXP; ++k) { F.a[k] = F.a[0]; F.nblk[k] = 1; F.part[k] = F.part[0]; }
+  hipLaunchKernelGGL(ln_pg_finish_kernel, dim3(blocks), dim3(256), 0, s, F);
+  MMDA_CHECK_LAUNCH("mmda_layernorm_param_grads(finish)");
+  return MMDA_OK;
+}
+}  // namespace
+
 extern "C" int mmda_layernorm_fwd_multi(const mmda_ln_args* a, int n, void* stream) {
   if (!a || n < 0) return MMDA_EINVAL;
   for (int i = 0; i < n; ++i)
@@ -209,6 +311,7 @@ extern "C" int mmda_layernorm_bwd_multi(const mmda_ln_bwd_args* a, int n, void* 
     for (int k = L.n; k <= LN_MAXP; ++k) L.start[k] = blocks;
     for (int k = L.n; k < LN_MAXP; ++k) { L.a[k] = L.a[0]; L.nblk[k] = 1; }
     if (blocks == 0) continue;
+    if (ln_pg_alloc(L, (hipStream_t)stream)) return MMDA_ELAUNCH;
     int nq = 1;
     for (int k = 0; k < L.n; ++k) nq = max(nq, ceil_div(L.a[k].n, 64));
     if (nq <= 2) hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
@@ -216,6 +319,7 @@ extern "C" int mmda_layernorm_bwd_multi(const mmda_ln_bwd_args* a, int n, void* 
     else if (nq <= 10) hipLaunchKernelGGL(ln_bwd_kernel<10>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
     else hipLaunchKernelGGL(ln_bwd_kernel<LN_MAXQ>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
     MMDA_CHECK_LAUNCH("mmda_layernorm_bwd");
+    if (ln_pg_finish(L, (hipStream_t)stream)) return MMDA_ELAUNCH;
   }
   return MMDA_OK;
 }
@@ -239,8 +343,10 @@ extern "C" int mmda_layernorm_param_grads(const mmda_ln_bwd_args* a, int n, void
     for (int k = L.n; k <= LN_MAXP; ++k) L.start[k] = blocks;
     for (int k = L.n; k < LN_MAXP; ++k) { L.a[k] = L.a[0]; L.nblk[k] = 1; }
     if (blocks == 0) continue;
+    if (ln_pg_alloc(L, (hipStream_t)stream)) return MMDA_ELAUNCH;
     hipLaunchKernelGGL(ln_param_grads_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
     MMDA_CHECK_LAUNCH("mmda_layernorm_param_grads");
+    if (ln_pg_finish(L, (hipStream_t)stream)) return MMDA_ELAUNCH;
   }
   return MMDA_OK;
 }
@@ -254,9 +360,9 @@ extern "C" int mmda_embed_gather(const float* W, const int64_t* ids, int rows, i
 }
 
 extern "C" int mmda_embed_scatter_add(float* dW, const int64_t* ids, int rows, int dim, const float* dX, void* stream) {
-  if (!dW || !ids || !dX || rows < 0 || dim <= 0) return MMDA_EINVAL;
+  if (!dW || !ids || !dX || rows < 0 || dim <= 0 || dim > 1024) return MMDA_EINVAL;
   if (rows == 0) return MMDA_OK;
-  hipLaunchKernelGGL(embed_scatter_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, dW, ids, rows, dim, dX);
+  hipLaunchKernelGGL(embed_scatter_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, dW, ids, rows, dim, dX);
   MMDA_CHECK_LAUNCH("mmda_embed_scatter_add");
   return MMDA_OK;
 }

@@ -174,3 +174,76 @@ def test_two_rank_overlapped_reduction_gives_the_summed_gradients(precision):
                 continue
             err = np.linalg.norm(got - ref) / nr
             assert err < (2e-4 if precision == "fp32" else 1e-2), (k, err, "early" if off < early else "late")
+
+
+def _nccl_one_rank_worker(port, q, precision):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from oracle import misa_oracle as orc
+        from mmda_amd import make_config, MISA
+        from mmda_amd.dist import DataParallelSync
+        cfg = orc.default_config(vocab_size=120)
+        P = orc.synth_params(cfg, 21)
+        batch = orc.synth_batch(cfg, 8, 9, 40, ragged=True)
+        d = {k: (v.to("cuda:0") if k != "l" else v) for k, v in batch.items()}
+
+        def run(grad_sync, steps=3):
+            m = MISA(make_config(precision=precision, device="cuda:0", **vars(cfg)))
+            m.load_state_dict(P); m.to("cuda:0")
+            for _ in range(steps):
+                m.train_step(d["t"], d["v"], d["a"], d["l"], d["emo"], lr=1e-3, clip=1.0, training=False, grad_sync=grad_sync)
+            torch.cuda.synchronize()
+            return m, {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
+
+        _, plain = run(None)
+        outs = {}
+        for sparse in (None, False):
+            dp = DataParallelSync(force_collectives=True, sparse_embedding=sparse, equal_shapes=(sparse is False))
+            assert dp.world == 1 and dist.get_backend() == "nccl"
+            m, sd = run(dp.sync)
+            # the early prefix was reduced AND stepped on the communication stream, the exchange ran on a stream of its own
+            assert 0 < dp.early_stepped < m.flat_buckets()[0].numel() and dp._comm is not None
+            outs["sparse" if sparse is None else "dense"] = sd
+        # also the raw exchange: a one-rank all-reduce is the identity, the (ids, rows) exchange re-sums the embedding rows
+        m = MISA(make_config(precision=precision, device="cuda:0", **vars(cfg))); m.load_state_dict(P); m.to("cuda:0")
+        m.train_step(d["t"], d["v"], d["a"], d["l"], d["emo"], lr=1e-3, clip=1.0, training=False, do_adam=False)
+        before = m._G.detach().clone()
+        dp = DataParallelSync(force_collectives=True)
+        scale = dp.sync(m._G, m._dense_floats, m)
+        torch.cuda.synchronize()
+        q.put((plain, outs, before.cpu().numpy(), m._G.detach().cpu().numpy(), scale, int(m._dense_floats)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_one_rank_rccl_group_walks_the_whole_exchange(precision):
+    """The RCCL branch of DataParallelSync.sync on the one GPU of a test box: a ONE-rank `nccl` process group with
+    force_collectives=True runs the communication stream, the early-event wait, the early clip + Adam, both all-reduces, the row-count
+    collective, both all-gathers and the deterministic segment sum -- device collectives on RCCL's own stream, not gloo's host
+    staging.  Summing over one rank is the identity, so three training steps through the exchange must leave the SAME parameters as
+    three steps without it: bit for bit (the gradient reductions are deterministic; the (ids, rows) form re-sums the embedding rows
+    in list order, which is also what the single-GPU scatter does)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_one_rank_worker, args=(_free_port(), q, precision))
+    p.start()
+    plain, outs, g_before, g_after, scale, dense = q.get(timeout=240)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert scale == 1.0
+    np.testing.assert_array_equal(g_before[:dense], g_after[:dense])            # all-reduce over one rank
+    np.testing.assert_allclose(g_after[dense:], g_before[dense:], rtol=0, atol=1e-6 * max(1.0, float(np.abs(g_before[dense:]).max())))
+    for form, sd in outs.items():
+        for k in plain:
+            if k == "embed.weight" and form == "sparse":
+                # rows hit by several positions are summed in list order by the segment sum, in atomic order by the scatter
+                np.testing.assert_allclose(sd[k], plain[k], rtol=0, atol=2e-6, err_msg=k)
+            else:
+                np.testing.assert_array_equal(sd[k], plain[k], err_msg=f"{form}: {k}")

@@ -343,8 +343,9 @@ def test_c3_full_size_b256_t50_properties(precision):
     assert bool(torch.isfinite(G1).all()) and float(G1.abs().max()) > 0
     s_full = model._public()["scores"].clone()
     model.train_step(full["t"], full["v"], full["a"], full["l"], full["emo"], lr=0.0, clip=1.0, do_adam=False, training=False)
-    assert rel(model._public()["scores"], s_full) < 1e-5
-    assert float((model.flat_buckets()[1] - G1).norm() / G1.norm()) < (1e-3 if precision == "bf16" else 1e-5)
+    assert torch.equal(model._public()["scores"], s_full)
+    assert torch.equal(model.flat_buckets()[1], G1)           # bit-identical: no float atomics anywhere in the step
+    assert model.read_losses() == L1
     tol = 2e-3 if precision == "bf16" else 1e-5
     model.eval()
     with torch.no_grad():
@@ -586,6 +587,57 @@ def test_fp8_fusion_ffn_matches_its_emulation_and_stays_near_the_exact_path(name
     assert rel(model._public()["scores"], z["out::scores"]) < (1e-4 if precision == "fp32" else 1e-2)
 
 
+def test_c5_as_one_configuration_bf16_encoders_fp8_ffn_confidnet():
+    """BASELINE configs[4] with everything on together: bf16 encoders (GEMM operands + recurrences), block-scaled fp8 feed-forward
+    products in the fusion layer, ConfidNet head in the loss (train_confid.sh path, solver.py:451-462), adversarial similarity branch
+    -- on the reference-generated fixture real_b16_t20_adv_confid: outputs (scores, tcp, side channel) and the six losses (the
+    confidence loss included) within 2e-2 of the fixture, every gradient's cosine with the reference's >= 0.95 and the ConfidNet
+    head's own gradients non-zero.  Then the same flags at the per-GPU batch of the 8-GPU configuration (B = 256, T = 50):
+    finite, no cluster abort, scores of a 32-sample slice equal to the slice run alone."""
+    from mmda_amd import make_config, MISA
+    name = "real_b16_t20_adv_confid"
+    z, meta, cfg = load_case(name)
+    assert cfg.use_confidNet and not cfg.use_cmd_sim
+    P = orc.synth_params(cfg, meta["seed"])
+    batch = batch_of(z)
+    b = to_dev(batch)
+    c = make_config(precision="bf16", device=DEV, fusion_fp8=True, **vars(cfg))
+    model = MISA(c); model.load_state_dict(P); model.to(DEV)
+    model.train_step(b["t"], b["v"], b["a"], b["l"], b["emo"], lr=cfg.learning_rate, clip=cfg.clip, do_adam=False, training=False)
+    assert not model.cluster_aborted()
+    pub = model._public()
+    assert rel(pub["scores"], z["out::scores"]) < 2e-2 and rel(pub["tcp"], z["out::tcp"]) < 2e-2
+    for s in SIDE:
+        assert rel(pub[s], z["out::" + s]) < 2e-2, s
+    L = model.read_losses()
+    for k in ("cls", "diff", "sim", "recon", "conf", "total"):
+        assert abs(L[k] - float(z["loss::" + k])) < 2e-2 * abs(float(z["loss::" + k])), (k, L[k], float(z["loss::" + k]))
+    assert float(z["loss::conf"]) != 0.0
+    _, _, G = orc.loss_and_grads(P, cfg, batch)
+    model._assign_grad_views()
+    for k, (l2, cos) in _grad_rel_l2(model, G, cfg, set(meta["none_grads"])).items():
+        assert cos >= 0.95, f"{k}: cosine {cos:.5f} against the exact oracle"
+    assert float(model.confidence.confidence_layer_1.weight.grad.abs().max()) > 0
+    # ---- the same flags at B = 256 / GPU
+    cfg2 = orc.default_config(vocab_size=2000, use_confidNet=True)
+    P2 = orc.synth_params(cfg2, 92)
+    m2 = MISA(make_config(precision="bf16", device=DEV, fusion_fp8=True, **vars(cfg2))); m2.load_state_dict(P2); m2.to(DEV)
+    full = to_dev(orc.synth_batch(cfg2, 256, 50, 7, ragged=True))
+    m2.train_step(full["t"], full["v"], full["a"], full["l"], full["emo"], lr=0.0, clip=1.0, do_adam=False, training=False)
+    assert not m2.cluster_aborted()
+    L2 = m2.read_losses()
+    assert all(np.isfinite(v) for v in L2.values()) and L2["conf"] != 0.0, L2
+    G2 = m2.flat_buckets()[1]
+    assert bool(torch.isfinite(G2).all()) and float(G2.abs().max()) > 0
+    s_full = m2._public()["scores"].clone(); t_full = m2._public()["tcp"].clone()
+    m2.eval()
+    with torch.no_grad():
+        sl = slice(64, 96)
+        s_sub, _ = m2(full["t"][:, sl].contiguous(), full["v"][:, sl].contiguous(), full["a"][:, sl].contiguous(), full["l"][sl])
+        assert rel(s_sub, s_full[sl]) < 2e-3
+        assert rel(m2.tcp, t_full[sl]) < 2e-3
+
+
 def test_rrelu_training_mode_draws_slopes_and_replays_them_in_backward():
     """config.activation = rrelu (config.py:27): in training mode nn.RReLU draws a slope ~ U(1/8, 1/3) per negative element.  The draws
     cannot match torch's CPU stream, so: two training forwards differ, the evaluation forward equals the mean-slope form (pinned by the
@@ -625,8 +677,11 @@ def test_rrelu_training_mode_draws_slopes_and_replays_them_in_backward():
 
 
 @pytest.mark.parametrize("switches", [{"MMDA_ROW_FUSE": "0"}, {"MMDA_FFN_FUSE": "0"}, {"MMDA_GEMM_TN": "0"}, {"MMDA_LSTM_NO_QUAD": "1"},
-                                      {"MMDA_ROW_FUSE": "0", "MMDA_GEMM_TN": "0", "MMDA_LSTM_NO_QUAD": "1"}],
-                         ids=["stand_alone_fusion_launches", "skinny_feed_forward", "nt_weight_gradients", "one_wave_per_tile", "all_round1_forms"])
+                                      {"MMDA_ROW_FUSE": "0", "MMDA_GEMM_TN": "0", "MMDA_LSTM_NO_QUAD": "1"},
+                                      {"MMDA_GEMM_DMA_MIN_ROWS": "0"}, {"MMDA_GEMM_DMA_MIN_ROWS": "0", "MMDA_GEMM_DMA_STAGES": "3"},
+                                      {"MMDA_GEMM_DMA_MIN_ROWS": "0", "MMDA_GEMM_TN": "0"}],
+                         ids=["stand_alone_fusion_launches", "skinny_feed_forward", "nt_weight_gradients", "one_wave_per_tile", "all_round1_forms",
+                              "lds_dma_gemm_two_stages", "lds_dma_gemm_three_stages", "lds_dma_gemm_nt_only"])
 def test_ablation_switches_take_the_replaced_launches_and_agree(switches):
     """Every fused / re-formed path of round 2 keeps the launches it replaced behind a switch (they are also what the configurations
     outside its preconditions run: the adversarial branch, large batches, fp8 feed-forward).  One bf16 training step (no optimizer) in

@@ -63,16 +63,14 @@ def _assert_params_match(model, P_ref, P0, cfg, steps, lr):
             got, ref, base = got[keep], ref[keep], base[keep]
         d = np.abs(got - ref)
         assert d.max() <= 2 * steps * lr + 1e-7, k
-        # (over many steps the elements whose gradients are rounding noise -- relu-gated feed-forward weights -- add up: 98 %)
-        # (98 %: the split-K weight-gradient GEMMs combine through float atomics, so noise-level gradient elements differ from run to run;
-        #  0.985 has been seen on a 140 x 35 tensor after three steps)
-        bulk = 0.98
+        # (over many steps the elements whose gradients are rounding noise -- relu-gated feed-forward weights -- add up: 99 %.  Round 2
+        #  sat at 98 % because the split-K GEMMs combined through float atomics; every reduction of the step is deterministic now.)
+        bulk = 0.99
         assert (d <= 0.01 * steps * lr).mean() >= bulk, (k, float((d <= 0.01 * steps * lr).mean()))
         upd_ref = (ref - base).astype(np.float64); upd = (got - base).astype(np.float64)
         if np.linalg.norm(upd_ref) > 0:
-            # (the same accumulation of noise-gradient elements over more steps: 2 % of the update's norm up to three steps, 3 % beyond;
-            #  the gradients themselves are held to 1e-4 per step in test_gpu_model)
-            tol = 2e-2 if steps <= 3 else 3e-2
+            # (2 % of the update's norm; the gradients themselves are held to 1e-4 per step in test_gpu_model)
+            tol = 2e-2
             assert np.linalg.norm(upd - upd_ref) <= tol * np.linalg.norm(upd_ref), (k, np.linalg.norm(upd - upd_ref) / np.linalg.norm(upd_ref))
         else:
             assert np.abs(upd).max() == 0.0, k
@@ -183,9 +181,11 @@ def test_shape_changes_keep_the_exchange_state(monkeypatch):
     s2.model.load_state_dict(P0); s2.model.to(DEV)
     b = train[-1]
     s2.model.train_step(b["t"].to(DEV), b["v"].to(DEV), b["a"].to(DEV), b["l"], b["emo"].to(DEV), lr=0.0, clip=1.0, training=False)
-    assert float((s2.model._public()["scores"] - got).abs().max()) < 1e-5
+    # every reduction of the step is deterministic (slab split-K, ordered partial sums, single-writer scatter): the same batch on the
+    # same weights gives the same bits, whatever ran before it (reference train.py:46-51 asks for reproducible runs)
+    assert torch.equal(s2.model._public()["scores"], got)
     G2 = s2.model.flat_buckets()[1]
-    assert float((G1 - G2).norm() / G2.norm()) < 1e-3          # float-atomic split-K order only
+    assert torch.equal(G1, G2)
 
 
 def test_written_but_unread_attributes_are_materialisable():
