@@ -7,6 +7,7 @@
 //   * mmda_allreduce           in-place sum all-reduce of a float buffer on an RCCL communicator, for hosts that own one (a native
 //                              trainer; the Python host goes through torch.distributed, whose communicator is not exposed).
 #include "common.h"
+#include "splitk.h"
 #include <dlfcn.h>
 #include <hipcub/hipcub.hpp>
 
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(256) void seg_level1_kernel(const unsigned* __restr
 
 // level 2: one wave per segment head; dW[id] = sum of the segment's run partials, in list order (overwrites the row)
 __global__ __launch_bounds__(256) void seg_level2_kernel(const unsigned* __restrict__ sid, int n, int D, const float* __restrict__ part,
-                                                         float* dW) {
+                                                         float* dW, int accumulate) {
   const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (p >= n) return;
   const unsigned id = sid[p];
@@ -57,7 +58,8 @@ __global__ __launch_bounds__(256) void seg_level2_kernel(const unsigned* __restr
   for (int c = lane; c < D; c += 64) {
     float acc = 0.f;
     for (int q = p; q < n && sid[q] == id; q = (q / CHUNK + 1) * CHUNK) acc += part[(int64_t)q * D + c];
-    dW[(int64_t)id * D + c] = acc;
+    float* dst = dW + (int64_t)id * D + c;                            // one writer per table row
+    *dst = accumulate ? *dst + acc : acc;
   }
 }
 
@@ -89,8 +91,25 @@ extern "C" int64_t mmda_embed_segment_sum_work_bytes(int n, int D) {
   return (int64_t)seg_layout(n, D).total;
 }
 
+static int seg_sum(float* dW, const int64_t* ids, int n, int D, const float* rows, void* work, int64_t work_bytes, void* stream, int accumulate);
+
 extern "C" int mmda_embed_segment_sum(float* dW, const int64_t* ids, int n, int D, const float* rows, void* work, int64_t work_bytes,
                                       void* stream) {
+  return seg_sum(dW, ids, n, D, rows, work, work_bytes, stream, 0);
+}
+
+// dW[ids[p]] += rows[p] by the same machinery (stable sort, list-order sums), work buffer from the stream's scratch: what
+// mmda_embed_scatter_add runs for long lists, where its one-workgroup-per-position scan (O(n^2 / 256) id compares) loses
+int mmda_embed_scatter_sorted(float* dW, const int64_t* ids, int n, int D, const float* rows, void* stream) {
+  if (n == 0) return MMDA_OK;
+  const int64_t bytes = (int64_t)seg_layout(n, D).total;
+  float* work = mmda_scratch_get((hipStream_t)stream, (size_t)bytes + 256);
+  if (!work) return MMDA_ELAUNCH;
+  void* w = (void*)(((uintptr_t)work + 255) & ~(uintptr_t)255);
+  return seg_sum(dW, ids, n, D, rows, w, bytes, stream, 1);
+}
+
+static int seg_sum(float* dW, const int64_t* ids, int n, int D, const float* rows, void* work, int64_t work_bytes, void* stream, int accumulate) {
   if (!dW || !ids || !rows || !work || n < 0 || D <= 0) return MMDA_EINVAL;
   if (n == 0) return MMDA_OK;
   const SegLayout L = seg_layout(n, D);
@@ -110,7 +129,7 @@ extern "C" int mmda_embed_segment_sum(float* dW, const int64_t* ids, int n, int 
   }
   hipLaunchKernelGGL(seg_level1_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, s, kout, vout, n, D, rows, part);
   MMDA_CHECK_LAUNCH("mmda_embed_segment_sum/level1");
-  hipLaunchKernelGGL(seg_level2_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, s, kout, n, D, part, dW);
+  hipLaunchKernelGGL(seg_level2_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, s, kout, n, D, part, dW, accumulate);
   MMDA_CHECK_LAUNCH("mmda_embed_segment_sum/level2");
   return MMDA_OK;
 }

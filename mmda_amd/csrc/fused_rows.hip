@@ -581,19 +581,42 @@ int mmda_fused_fwd_c(const FusedFwdC* a, void* stream) {
 // parameter gradients of the five LayerNorms: partials of the samples added in sample order (sixteen loads in flight at a time)
 struct FusedPgOut { float* dgamma[FUSED_PG_SLOTS]; float* dbeta[FUSED_PG_SLOTS]; };
 __global__ __launch_bounds__(256) void fused_pg_finish_kernel(const float* __restrict__ parts, int B, int hs, FusedPgOut out) {
-  const int e = blockIdx.x * 256 + threadIdx.x;                       // (slot k, gamma | beta, column c)
-  if (e >= FUSED_PG_SLOTS * 256) return;
-  const int k = e / 256, which = (e % 256) / 128, c = e % 128;
+  // sixteen threads per output (slot k, gamma | beta, column c): each adds every sixteenth sample's partial, the sub-sums in lane order
+  __shared__ float sub[256];
+  const int e = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int j = threadIdx.x & 15;
+  const bool ok = e < FUSED_PG_SLOTS * 256;
+  const int k = ok ? e / 256 : 0, which = (e % 256) / 128, c = e % 128;
+  const float* p = parts + (int64_t)k * 256 + which * 128 + c;
+  float acc = 0.f;
+  if (ok) {
+    const int64_t st = (int64_t)FUSED_PG_SLOTS * 256;
+    int b = j;
+    for (; b + 7 * 16 < B; b += 8 * 16) {                  // eight loads in flight
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(b + 16 * u) * st];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; b < B; b += 16) acc += p[b * st];
+  }
+  sub[threadIdx.x] = acc;
+  __syncthreads();
   float* dst = which ? out.dbeta[k] : out.dgamma[k];
-  if (!dst || c >= hs) return;
-  dst[c] += sum_parts(parts + (int64_t)k * 256 + which * 128 + c, B, (int64_t)FUSED_PG_SLOTS * 256);
+  if (ok && j == 0 && dst && c < hs) {
+    float t = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) t += sub[(threadIdx.x & ~15) + u];
+    dst[c] += t;
+  }
 }
 
 int mmda_fused_pg_finish(const float* pg_parts, int B, int hs, float* const* dgamma, float* const* dbeta, void* stream) {
   if (!pg_parts || B <= 0 || hs != 128 || !dgamma || !dbeta) return MMDA_EINVAL;
   FusedPgOut out;
   for (int k = 0; k < FUSED_PG_SLOTS; ++k) { out.dgamma[k] = dgamma[k]; out.dbeta[k] = dbeta[k]; }
-  hipLaunchKernelGGL(fused_pg_finish_kernel, dim3(FUSED_PG_SLOTS), dim3(256), 0, (hipStream_t)stream, pg_parts, B, hs, out);
+  hipLaunchKernelGGL(fused_pg_finish_kernel, dim3(FUSED_PG_SLOTS * 256 / 16), dim3(256), 0, (hipStream_t)stream, pg_parts, B, hs, out);
   MMDA_CHECK_LAUNCH("mmda_fused_pg_finish");
   return MMDA_OK;
 }

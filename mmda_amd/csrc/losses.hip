@@ -210,9 +210,17 @@ __global__ __launch_bounds__(256) void misc_losses_kernel(MiscLossArgs a) {
       __threadfence();
       // cls, conf and recon: the workgroups' partials in role order (L[0], L[3], L[4] were cleared with the rest of the loss block)
       const int nconf = a.with_conf ? ncls : 0;
-      float cls = __hip_atomic_load(a.parts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), conf = 0.f, rec = 0.f;
-      for (int i = 0; i < nconf; ++i) conf += __hip_atomic_load(a.parts + 1 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      for (int i = 0; i < a.recon_blocks; ++i) rec += __hip_atomic_load(a.parts + 1 + nconf + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (agent-scope loads, sixteen in flight: one at a time is an L2 round trip each)
+      auto ld = [&](int i) { return __hip_atomic_load(a.parts + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+      float cls = ld(0), conf = 0.f, rec = 0.f;
+      for (int i = 0; i < nconf; ++i) conf += ld(1 + i);
+      for (int i0 = 0; i0 < a.recon_blocks; i0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = ld(1 + nconf + min(i0 + u, a.recon_blocks - 1));      // (clamped: no load under a branch)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) rec += (i0 + u < a.recon_blocks) ? v[u] : 0.f;
+      }
       a.L[0] += cls; a.L[4] += conf; a.L[3] += rec;
       __threadfence();
       float v[5];

@@ -4,6 +4,12 @@
 // memory is owned here; no torch types; no host<->device synchronisation anywhere in a step.
 #include "common.h"
 #include "fused_rows.h"
+// internal entry points of norm.hip (not part of the C ABI)
+bool mmda_ln_bwd_parts_applies(const mmda_ln_bwd_args* a, int n);
+int64_t mmda_ln_parts_floats(const mmda_ln_bwd_args* a, int n);
+int mmda_ln_bwd_parts(const mmda_ln_bwd_args* a, int n, float* parts, void* stream);
+int mmda_ln_parts_finish(const mmda_ln_bwd_args* a, int n, float* parts, void* stream);
+
 #include <map>
 #include <string>
 #include <vector>
@@ -64,7 +70,7 @@ struct mmda_misa {
   int64_t zero_begin = 0, zero_end = 0;      // activation-gradient region that is zeroed per step
   int64_t gpad_begin = 0, gpad_end = 0;      // GRU: four-slot weight gradients (zeroed at set_workspace, re-zeroed by the unpad kernel)
   int64_t z, pmean, prstd, orig, x6, rsum, recon, dom_z, dom_h, dom, qkv, probs, ctx, attn_out, ln1_mean, ln1_rstd, x1, f1, f2,
-      ln2_mean, ln2_rstd, hfused, logits, tcp, scores, labels, losses, diff_work, touched, ffn_parts, pg_parts;
+      ln2_mean, ln2_rstd, hfused, logits, tcp, scores, labels, losses, diff_work, touched, ffn_parts, pg_parts, ln_parts;
   // K-major (transposed) fp32 copies of the fusion block's weights for its input-gradient GEMMs (made once per step)
   int64_t head_wT, l2_wT, l1_wT, out_wT, in_wT, rec_wT, priv_wT, sh_wT, d1_wT = -1, d2_wT = -1, pwT[3];
   int wT_valid = 0;
@@ -282,6 +288,7 @@ int64_t layout(mmda_misa* m, int B, int T, bool commit) {
   o->w2q = k.take((int64_t)hs * FFN / 4); o->w2s = k.take((int64_t)hs * FFN / 128 + 4);
   o->diff_work = k.take(mmda_loss_diff_work_floats(B, hs));
   o->ffn_parts = k.take((int64_t)(FFN / 32) * 6 * BH);      // partial products of the hidden-sliced feed-forward kernels (fused_rows.hip)
+  o->ln_parts = k.take((int64_t)512 * 2 * 2 * (o->mod[0].H + o->mod[1].H + o->mod[2].H));   // <= 512 block partials of the three inter-layer LayerNorms' gamma / beta gradients (norm.hip)
   o->pg_parts = k.take((int64_t)B * FUSED_PG_SLOTS * 2 * 128);      // per-sample LayerNorm gamma / beta gradient partials of the fused backward stretches
   o->touched = k.take((c.vocab + 3) / 4);              // one byte per embedding row: occurs in this batch (see mmda_clamp_adam_rows)
   o->head_wT = k.take((int64_t)6 * hs * NC); o->l2_wT = k.take((int64_t)FFN * hs); o->l1_wT = k.take((int64_t)hs * FFN);
@@ -1637,12 +1644,21 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
       }
       // (the input-gradient launch goes out BEFORE the fork: it reads the LayerNorm weights, which the early optimizer step below may
       // update on the side stream -- the fork orders the side stream behind it)
-      x.rc = mmda_layernorm_bwd_multi(lb, 3, stream);
+      // 16-byte form (norm.hip): the d_x launch leaves the gamma / beta gradients as per-block partials on its way (it reads dy and x
+      // anyway) and the side stream only adds them up -- instead of a second pass over dy and x there (100 us at B = 256)
+      const bool ln_split = mmda_ln_bwd_parts_applies(lb, 3) &&
+                            mmda_ln_parts_floats(lb, 3) <= (int64_t)512 * 2 * 2 * (m->mod[0].H + m->mod[1].H + m->mod[2].H);
+      if (ln_split) {
+        for (int i = 0; i < 3; ++i) { lb[i].dgamma = GG(m->mod[i].ln_w); lb[i].dbeta = GG(m->mod[i].ln_b); }
+        x.rc = mmda_ln_bwd_parts(lb, 3, WS(m->ln_parts), stream);
+      } else {
+        x.rc = mmda_layernorm_bwd_multi(lb, 3, stream);
+      }
       void* ss = nullptr;
       if (!x.rc) x.rc = side_fork(m, stream, &ss);
-      for (int i = 0; i < 3; ++i) { lb[i].dgamma = GG(m->mod[i].ln_w); lb[i].dbeta = GG(m->mod[i].ln_b); lb[i].d_x = nullptr; }
+      for (int i = 0; i < 3; ++i) { lb[i].dgamma = GG(m->mod[i].ln_w); lb[i].dbeta = GG(m->mod[i].ln_b); if (!ln_split) lb[i].d_x = nullptr; }
       if (!x.rc && dg_on_side) x.rc = mmda_convert_bf16(dgj, 3, ss);
-      if (!x.rc) x.rc = mmda_layernorm_param_grads(lb, 3, ss);
+      if (!x.rc) x.rc = ln_split ? mmda_ln_parts_finish(lb, 3, WS(m->ln_parts), ss) : mmda_layernorm_param_grads(lb, 3, ss);
       if (!x.rc && !x.deferred.empty()) x.rc = mmda_gemm_grouped(x.deferred.data(), (int)x.deferred.size(), ss);
       const bool l2_early = !bside.empty() && dw_overlap;
       if (!x.rc && l2_early) { x.rc = mmda_gemm_bf16_grouped(bside.data(), (int)bside.size(), ss); bside.clear(); }

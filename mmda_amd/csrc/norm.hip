@@ -1,8 +1,11 @@
 // Row-wise kernels: LayerNorm forward/backward (wave-per-row shuffle reductions), embedding gather / scatter-add,
 // small elementwise helpers.  All HBM-bound; loads are lane-consecutive (coalesced 256 B per wave instruction).
 #include "common.h"
+#include <stdlib.h>
 #include "rowlocal.h"
 #include "splitk.h"
+
+int mmda_embed_scatter_sorted(float* dW, const int64_t* ids, int n, int D, const float* rows, void* stream);   // dist.hip
 
 namespace {
 
@@ -61,33 +64,199 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdMulti L) {
   }
 }
 
-// dgamma[i] += sum over the blocks' partials in block order (sixteen loads in flight at a time)
+// dgamma[i] += the blocks' partials, in a FIXED order: sixteen threads per output take every sixteenth partial each (their loads are
+// independent), and the sixteen sub-sums are added in lane order
 __global__ __launch_bounds__(256) void ln_pg_finish_kernel(LnBwdMulti L) {
+  __shared__ float sub[256];
   int pi = 0;
 #pragma unroll
   for (int k = 1; k < LN_MAXP; ++k)
     if (k < L.n && (int)blockIdx.x >= L.start[k]) pi = k;
   const mmda_ln_bwd_args& a = L.a[pi];
   const int n = a.n;
-  const int e = ((int)blockIdx.x - L.start[pi]) * 256 + threadIdx.x;       // (gamma | beta, column)
-  if (e >= 2 * n) return;
-  const int which = e / n, i = e % n;
-  float* dst = which ? a.dbeta : a.dgamma;
-  if (!dst) return;
+  const int e = ((int)blockIdx.x - L.start[pi]) * 16 + (threadIdx.x >> 4);       // (gamma | beta, column)
+  const int j = threadIdx.x & 15;
+  const bool ok = e < 2 * n;
+  const int which = ok ? e / n : 0, i = ok ? e % n : 0;
   const float* p = L.part[pi] + (int64_t)which * n + i;
   const int64_t stride = 2 * (int64_t)n;
   const int nb = L.nblk[pi];
   float acc = 0.f;
-  int q = 0;
-  for (; q + 16 <= nb; q += 16) {
-    float v[16];
+  if (ok) {
+    int q = j;
+    for (; q + 7 * 16 < nb; q += 8 * 16) {                 // eight loads in flight (one at a time is a cache latency per partial)
+      float v[8];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) v[u] = p[(q + u) * stride];
+      for (int u = 0; u < 8; ++u) v[u] = p[(q + 16 * u) * stride];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) acc += v[u];
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; q < nb; q += 16) acc += p[q * stride];
   }
-  for (; q < nb; ++q) acc += p[q * stride];
-  dst[i] += acc;
+  sub[threadIdx.x] = acc;
+  __syncthreads();
+  float* dst = which ? a.dbeta : a.dgamma;
+  if (ok && j == 0 && dst) {
+    float t = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) t += sub[(threadIdx.x & ~15) + u];
+    dst[i] += t;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ 16-byte forms
+// The inter-layer LayerNorms (rows = T * B, n = 2H: 600 / 148 wide; plain: no activation, residual or permutation) with 16-byte
+// accesses: a wave per row, lane l holds the float4 groups l, l + 64, ... of the row (n a multiple of 4, n <= 1024).  The scalar forms
+// above move 4 bytes per lane and instruction and ran at 2 TB/s at B = 256 (ln_fwd 40 us, ln_bwd 68 us for 84 / 126 MB).
+// Rows whose width is even but not a multiple of four (the visual encoder: 70) take the same path with 8-byte groups.
+constexpr int LNV_MAX = 4;         // groups per lane: n <= 1024 (16-byte groups)
+template <int VW> struct VecOf;
+template <> struct VecOf<4> { typedef float T __attribute__((ext_vector_type(4))); };
+template <> struct VecOf<2> { typedef float T __attribute__((ext_vector_type(2))); };
+template <int VW> __device__ __forceinline__ float vsum(typename VecOf<VW>::T v) {
+  if (VW == 4) return (v[0] + v[1]) + (v[2] + v[3]);
+  return v[0] + v[1];
+}
+template <int VW> __device__ __forceinline__ typename VecOf<VW>::T vzero() {
+  typename VecOf<VW>::T z;
+#pragma unroll
+  for (int e = 0; e < VW; ++e) z[e] = 0.f;
+  return z;
+}
+
+template <int NV, int VW>
+__device__ __forceinline__ void ln_fwd_vec_row(const mmda_ln_args& a, int row, int lane) {
+  typedef typename VecOf<VW>::T V;
+  const int n = a.n, ng = n / VW;
+  const V* x = reinterpret_cast<const V*>(a.x + (int64_t)row * n);
+  V v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    const int g = lane + 64 * q;
+    v[q] = g < ng ? x[g] : vzero<VW>();
+    s += vsum<VW>(v[q]);
+  }
+  const float mean = wave_sum(s) / n;
+  float ss = 0.f;
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    if (lane + 64 * q < ng) {
+      const V d = v[q] - mean;
+      ss += vsum<VW>(d * d);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(ss) / n + a.eps);
+  if (lane == 0) {
+    if (a.mean) a.mean[row] = mean;
+    if (a.rstd) a.rstd[row] = rstd;
+  }
+  const V* gm = reinterpret_cast<const V*>(a.gamma);
+  const V* bt = reinterpret_cast<const V*>(a.beta);
+  V* y = reinterpret_cast<V*>(a.y + (int64_t)row * n);
+  unsigned short* yb = a.y_bf16 ? reinterpret_cast<unsigned short*>(a.y_bf16) + (int64_t)row * a.ld_bf16 : nullptr;
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    const int g = lane + 64 * q;
+    V o = vzero<VW>();
+    if (g < ng) { o = (v[q] - mean) * rstd * gm[g] + bt[g]; y[g] = o; }
+    if (yb && VW * g < a.ld_bf16) {                                     // (ld_bf16 is a multiple of 8: whole groups; zero in the padding)
+      if (VW == 4) {
+        typedef unsigned u2v __attribute__((ext_vector_type(2)));
+        const u2v pk = {(unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16), (unsigned)f2bf(o[2 % VW]) | ((unsigned)f2bf(o[3 % VW]) << 16)};
+        *reinterpret_cast<u2v*>(yb + 4 * g) = pk;
+      } else {
+        *reinterpret_cast<unsigned*>(yb + 2 * g) = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
+      }
+    }
+  }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_vec_kernel(LnMulti L) {
+  int pi = 0;
+#pragma unroll
+  for (int k = 1; k < LN_MAXP; ++k)
+    if (k < L.n && (int)blockIdx.x >= L.start[k]) pi = k;
+  const mmda_ln_args& a = L.a[pi];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = ((int)blockIdx.x - L.start[pi]) * 4 + wave;
+  if (row >= a.rows) return;
+  if (a.n & 3) ln_fwd_vec_row<NV, 2>(a, row, lane);        // problem-uniform
+  else ln_fwd_vec_row<NV, 4>(a, row, lane);
+}
+
+// backward, d_x of every row plus (parts != null) the block's partial gamma / beta gradients: block `blk` of a problem leaves
+// parts[(blk * 2 + {0,1}) * n + i]; mmda_ln_parts_finish adds the blocks in order (no atomics).
+template <int NV, int VW>
+__device__ __forceinline__ void ln_bwd_vec_body(const mmda_ln_bwd_args& a, int blk, int nblk, float* part, float* red_raw) {
+  typedef typename VecOf<VW>::T V;
+  V (*red)[4][NV * 64] = reinterpret_cast<V (*)[4][NV * 64]>(red_raw);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = a.n, ng = n / VW;
+  const V* gm = reinterpret_cast<const V*>(a.gamma);
+  V gam[NV], dg[NV], db[NV];
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    const int g = lane + 64 * q;
+    gam[q] = g < ng ? gm[g] : vzero<VW>();
+    dg[q] = vzero<VW>(); db[q] = vzero<VW>();
+  }
+  for (int row = blk * 4 + wave; row < a.rows; row += nblk * 4) {
+    const float mean = a.mean[row], rstd = a.rstd[row];
+    const V* x = reinterpret_cast<const V*>(a.x + (int64_t)row * n);
+    const V* dy = reinterpret_cast<const V*>(a.dy + (int64_t)row * n);
+    V xh[NV], gdy[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const int g = lane + 64 * q;
+      xh[q] = vzero<VW>(); gdy[q] = vzero<VW>();
+      if (g < ng) {
+        const V d = dy[g];
+        xh[q] = (x[g] - mean) * rstd;
+        gdy[q] = d * gam[q];
+        dg[q] += d * xh[q];
+        db[q] += d;
+        s1 += vsum<VW>(gdy[q]);
+        s2 += vsum<VW>(gdy[q] * xh[q]);
+      }
+    }
+    s1 = wave_sum(s1) / n;
+    s2 = wave_sum(s2) / n;
+    V* dx = reinterpret_cast<V*>(a.d_x + (int64_t)row * n);
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const int g = lane + 64 * q;
+      if (g < ng) {
+        V d = rstd * (gdy[q] - s1 - xh[q] * s2);
+        if (a.accumulate_dx) d += dx[g];
+        dx[g] = d;
+      }
+    }
+  }
+  if (!part) return;                                       // problem-uniform
+#pragma unroll
+  for (int q = 0; q < NV; ++q) { red[0][wave][q * 64 + lane] = dg[q]; red[1][wave][q * 64 + lane] = db[q]; }
+  __syncthreads();
+  for (int g = threadIdx.x; g < ng; g += 256) {
+    const V gs = (red[0][0][g] + red[0][1][g]) + (red[0][2][g] + red[0][3][g]);
+    const V bs = (red[1][0][g] + red[1][1][g]) + (red[1][2][g] + red[1][3][g]);
+    *reinterpret_cast<V*>(part + ((int64_t)blk * 2 + 0) * n + VW * g) = gs;
+    *reinterpret_cast<V*>(part + ((int64_t)blk * 2 + 1) * n + VW * g) = bs;
+  }
+}
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_vec_kernel(LnBwdMulti L) {
+  __shared__ __attribute__((aligned(16))) float red[2 * 4 * NV * 64 * 4];
+  int pi = 0;
+#pragma unroll
+  for (int k = 1; k < LN_MAXP; ++k)
+    if (k < L.n && (int)blockIdx.x >= L.start[k]) pi = k;
+  const mmda_ln_bwd_args& a = L.a[pi];
+  const int blk = (int)blockIdx.x - L.start[pi];
+  if (a.n & 3) ln_bwd_vec_body<NV, 2>(a, blk, L.nblk[pi], L.part[pi], red);      // problem-uniform
+  else ln_bwd_vec_body<NV, 4>(a, blk, L.nblk[pi], L.part[pi], red);
 }
 
 // dgamma / dbeta alone, parallel over column strips x row chunks: lane = column (coalesced 256-B rows), no wave reductions,
@@ -149,28 +318,39 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(float* dW, const int
   const int64_t id = ids[p];
   if (id < 0) return;                                    // (padding marker of the gathered lists; block-uniform)
   if (threadIdx.x == 0) earlier = 0;
-  __syncthreads();
-  for (int q = threadIdx.x; q < p; q += 256)
-    if (ids[q] == id) earlier = 1;                       // benign race: every writer stores 1
-  __syncthreads();
-  if (earlier) return;                                   // an earlier position owns this id (block-uniform)
   float acc[4] = {0.f, 0.f, 0.f, 0.f};                   // dims threadIdx.x + 256 j (dim <= 1024)
-  for (int w0 = p; w0 < rows; w0 += ES_WIN) {
+  for (int w0 = 0; w0 < rows; w0 += ES_WIN) {
     const int wn = min(ES_WIN, rows - w0);
-    for (int i = threadIdx.x; i < (wn + 31) / 32; i += 256) mask[i] = 0u;
+    const int nwords = (wn + 31) / 32;
+    for (int i = threadIdx.x; i < nwords; i += 256) mask[i] = 0u;
     __syncthreads();
+    // one pass over the window's ids, eight loads in flight per thread (one at a time is a cache latency per 256 ids)
+#pragma unroll 8
     for (int q = threadIdx.x; q < wn; q += 256)
       if (ids[w0 + q] == id) atomicOr(&mask[q >> 5], 1u << (q & 31));
     __syncthreads();
-    for (int i = 0; i < (wn + 31) / 32; ++i) {
-      unsigned m = mask[i];
-      while (m) {
-        const int q = w0 + 32 * i + __builtin_ctz(m);
-        m &= m - 1;
+    if (w0 <= p) {                                       // an earlier position with this id owns it
+      const int lim = min(p - w0, wn);                   // positions [w0, w0 + lim) lie before p
+      for (int i = threadIdx.x; i < (lim + 31) / 32; i += 256) {
+        unsigned m = mask[i];
+        if (32 * i + 32 > lim) m &= (1u << (lim - 32 * i)) - 1u;
+        if (m) earlier = 1;                              // benign race: every writer stores 1
+      }
+      __syncthreads();
+      if (earlier) return;                               // block-uniform
+    }
+    if (w0 + wn > p) {
+      for (int i = max(0, (p - w0) >> 5); i < nwords; ++i) {
+        unsigned m = mask[i];
+        while (m) {
+          const int q = w0 + 32 * i + __builtin_ctz(m);
+          m &= m - 1;
+          if (q < p) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int d = threadIdx.x + 256 * j;
-          if (d < dim) acc[j] += dX[(int64_t)q * dim + d];
+          for (int j = 0; j < 4; ++j) {
+            const int d = threadIdx.x + 256 * j;
+            if (d < dim) acc[j] += dX[(int64_t)q * dim + d];
+          }
         }
       }
     }
@@ -253,7 +433,7 @@ int ln_pg_finish(const LnBwdMulti& Lw, hipStream_t s) {
   int blocks = 0, n = 0;
   for (int k = 0; k < Lw.n; ++k) {
     if (!Lw.part[k]) continue;
-    F.a[n] = Lw.a[k]; F.nblk[n] = Lw.nblk[k]; F.part[n] = Lw.part[k]; F.start[n] = blocks; blocks += ceil_div(2 * Lw.a[k].n, 256); n++;
+    F.a[n] = Lw.a[k]; F.nblk[n] = Lw.nblk[k]; F.part[n] = Lw.part[k]; F.start[n] = blocks; blocks += ceil_div(2 * Lw.a[k].n, 16); n++;
   }
   if (n == 0) return MMDA_OK;
   F.n = n;
@@ -282,6 +462,28 @@ extern "C" int mmda_layernorm_fwd_multi(const mmda_ln_args* a, int n, void* stre
     if (blocks == 0) continue;
     int nq = 1;
     for (int k = 0; k < L.n; ++k) nq = max(nq, ceil_div(L.a[k].n, 64));
+    bool vec = nq > 2;                                   // (the 128-wide LayerNorms of the fusion block stay on the scalar form)
+    for (int k = 0; k < L.n; ++k) {
+      const mmda_ln_args& q = L.a[k];
+      const int vw = (q.n & 3) ? 2 : 4;                 // bytes per group 8 / 16: every row start must be that aligned
+      vec = vec && (q.n & 1) == 0 && ceil_div(q.n, vw * 64) <= LNV_MAX && !q.res && q.act == MMDA_ACT_NONE && q.permute_S <= 0 &&
+            ((((uintptr_t)q.x | (uintptr_t)q.y | (uintptr_t)q.gamma | (uintptr_t)q.beta) & (4 * vw - 1)) == 0) &&
+            (!q.y_bf16 || ((q.ld_bf16 & 7) == 0 && ((uintptr_t)q.y_bf16 & 7) == 0 && ceil_div(q.ld_bf16, vw * 64) <= LNV_MAX));
+    }
+    static const int ln_vec_on = getenv("MMDA_LN_VEC") ? atoi(getenv("MMDA_LN_VEC")) : 1;
+    if (vec && ln_vec_on) {
+      int nv = 1;                                        // groups per lane: the widest problem in ITS group size (bf16 copy included)
+      for (int k = 0; k < L.n; ++k) {
+        const int vw = (L.a[k].n & 3) ? 2 : 4;
+        nv = max(nv, ceil_div(max(L.a[k].n, L.a[k].y_bf16 ? L.a[k].ld_bf16 : 0), vw * 64));
+      }
+      if (nv <= 1) hipLaunchKernelGGL(ln_fwd_vec_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
+      else if (nv <= 2) hipLaunchKernelGGL(ln_fwd_vec_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
+      else if (nv <= 3) hipLaunchKernelGGL(ln_fwd_vec_kernel<3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
+      else hipLaunchKernelGGL(ln_fwd_vec_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
+      MMDA_CHECK_LAUNCH("mmda_layernorm_fwd(vec)");
+      continue;
+    }
     if (nq <= 2) hipLaunchKernelGGL(ln_fwd_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
     else if (nq <= 4) hipLaunchKernelGGL(ln_fwd_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
     else if (nq <= 10) hipLaunchKernelGGL(ln_fwd_kernel<10>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
@@ -325,6 +527,62 @@ extern "C" int mmda_layernorm_bwd_multi(const mmda_ln_bwd_args* a, int n, void* 
 }
 extern "C" int mmda_layernorm_bwd(const mmda_ln_bwd_args* a, void* stream) { return mmda_layernorm_bwd_multi(a, a ? 1 : -1, stream); }
 
+// Internal (misa.hip): the backward of up to LN_MAXP plain LayerNorms with the gamma / beta gradients left as per-block partials in a
+// caller-owned buffer (`parts`, mmda_ln_parts_floats floats) -- the d_x launch on the critical stream computes them on the way (it
+// reads dy and x anyway), and mmda_ln_parts_finish adds them up on whatever stream the caller likes (behind an event).  Replaces
+// the separate column-strip pass over dy and x (mmda_layernorm_param_grads: 100 us at B = 256) when the 16-byte form applies.
+namespace {
+bool ln_bwd_vec_applies(const mmda_ln_bwd_args& q) {
+  const int vw = (q.n & 3) ? 2 : 4;
+  return (q.n & 1) == 0 && ceil_div(q.n, vw * 64) <= LNV_MAX && !q.res && !q.d_res && q.act == MMDA_ACT_NONE && q.permute_S <= 0 && q.d_x &&
+         ((((uintptr_t)q.x | (uintptr_t)q.dy | (uintptr_t)q.gamma | (uintptr_t)q.d_x) & (4 * vw - 1)) == 0);
+}
+int ln_parts_blocks(const mmda_ln_bwd_args& q) { int nb = ceil_div(q.rows, 16); return nb > 512 ? 512 : (nb < 1 ? 1 : nb); }
+}  // namespace
+bool mmda_ln_bwd_parts_applies(const mmda_ln_bwd_args* a, int n) {
+  static const int ln_vec_on = getenv("MMDA_LN_VEC") ? atoi(getenv("MMDA_LN_VEC")) : 1;
+  if (!ln_vec_on || !a || n <= 0 || n > LN_MAXP) return false;
+  for (int i = 0; i < n; ++i)
+    if (ln_bwd_check(a + i) || !ln_bwd_vec_applies(a[i])) return false;
+  return true;
+}
+int64_t mmda_ln_parts_floats(const mmda_ln_bwd_args* a, int n) {
+  int64_t f = 0;
+  for (int i = 0; i < n; ++i) f += (int64_t)ln_parts_blocks(a[i]) * 2 * a[i].n;
+  return f;
+}
+static void ln_parts_layout(const mmda_ln_bwd_args* a, int n, float* parts, LnBwdMulti& L, int& blocks) {
+  L.n = 0; blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const int nb = ln_parts_blocks(a[i]);
+    L.a[L.n] = a[i]; L.start[L.n] = blocks; L.nblk[L.n] = nb; L.part[L.n] = parts; parts += (int64_t)nb * 2 * a[i].n;
+    blocks += nb; L.n++;
+  }
+  for (int k = L.n; k <= LN_MAXP; ++k) L.start[k] = blocks;
+  for (int k = L.n; k < LN_MAXP; ++k) { L.a[k] = L.a[0]; L.nblk[k] = 1; L.part[k] = L.part[0]; }
+}
+int mmda_ln_bwd_parts(const mmda_ln_bwd_args* a, int n, float* parts, void* stream) {
+  if (!mmda_ln_bwd_parts_applies(a, n) || !parts) return MMDA_EINVAL;
+  LnBwdMulti L;
+  int blocks = 0;
+  ln_parts_layout(a, n, parts, L, blocks);
+  int ng = 1;
+  for (int k = 0; k < L.n; ++k) ng = max(ng, ceil_div(L.a[k].n, ((L.a[k].n & 3) ? 2 : 4) * 64));
+  if (ng <= 1) hipLaunchKernelGGL(ln_bwd_vec_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
+  else if (ng <= 2) hipLaunchKernelGGL(ln_bwd_vec_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
+  else if (ng <= 3) hipLaunchKernelGGL(ln_bwd_vec_kernel<3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
+  else hipLaunchKernelGGL(ln_bwd_vec_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
+  MMDA_CHECK_LAUNCH("mmda_ln_bwd_parts");
+  return MMDA_OK;
+}
+int mmda_ln_parts_finish(const mmda_ln_bwd_args* a, int n, float* parts, void* stream) {
+  if (!a || n <= 0 || n > LN_MAXP || !parts) return MMDA_EINVAL;
+  LnBwdMulti L;
+  int blocks = 0;
+  ln_parts_layout(a, n, parts, L, blocks);
+  return ln_pg_finish(L, (hipStream_t)stream);
+}
+
 extern "C" int mmda_layernorm_param_grads(const mmda_ln_bwd_args* a, int n, void* stream) {
   if (!a || n < 0) return MMDA_EINVAL;
   for (int i = 0; i < n; ++i)
@@ -362,6 +620,10 @@ extern "C" int mmda_embed_gather(const float* W, const int64_t* ids, int rows, i
 extern "C" int mmda_embed_scatter_add(float* dW, const int64_t* ids, int rows, int dim, const float* dX, void* stream) {
   if (!dW || !ids || !dX || rows < 0 || dim <= 0 || dim > 1024) return MMDA_EINVAL;
   if (rows == 0) return MMDA_OK;
+  // long lists: sort-based list-order sums (dist.hip) -- the scan below costs rows^2 / 256 id compares (B=256, T=50: 158 us against
+  // 9 us at B=32).  MMDA_SCATTER_SORT_MIN moves the limit.
+  static const int sort_min = getenv("MMDA_SCATTER_SORT_MIN") ? atoi(getenv("MMDA_SCATTER_SORT_MIN")) : 3072;
+  if (rows >= sort_min) return mmda_embed_scatter_sorted(dW, ids, rows, dim, dX, stream);
   hipLaunchKernelGGL(embed_scatter_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, dW, ids, rows, dim, dX);
   MMDA_CHECK_LAUNCH("mmda_embed_scatter_add");
   return MMDA_OK;
