@@ -130,6 +130,7 @@ typedef struct mmda_convert_job {
   int src_bf16;                      /* 1: `src` points at bf16 elements (ld in elements): re-layout (transpose / pad) without conversion */
 } mmda_convert_job;
 int mmda_convert_bf16(const mmda_convert_job* jobs, int n, void* stream);
+int mmda_debug_gemm_dma_mode(int mode);      /* tools/ only: bit 0 = the LDS-DMA kernel skips its MFMA work, bit 1 = its DMA (wrong results) */
 
 /* ---------------------------------------------------------------------------------------------- block-scaled fp8 GEMM (MX)
  * The two feed-forward products of the fusion transformer layer (linear1 128 -> 2048, linear2 2048 -> 128; reference

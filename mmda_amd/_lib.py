@@ -121,6 +121,7 @@ SIGNATURES = {
     "mmda_last_error": (C.c_char_p, []),
     "mmda_abi_version": (_I, []),
     "mmda_scratch_release": (_I, []),
+    "mmda_debug_gemm_dma_mode": (_I, [_I]),
     "mmda_gemm": (_I, [C.POINTER(GemmArgs), _P]),
     "mmda_gemm_grouped": (_I, [C.POINTER(GemmArgs), _I, _P]),
     "mmda_gemm_bf16_grouped": (_I, [C.POINTER(GemmBf16Args), _I, _P]),

@@ -407,29 +407,152 @@ __global__ __launch_bounds__(256, T == 64 ? 4 : 2) void gemm_bf16_kernel(Bf16Gro
 // global memory: the select is on the source ADDRESS, nothing touches the data.  The bias gradient (column sums of A) is one extra
 // MFMA per A fragment against an all-ones B fragment in the waves of the one column tile that holds column N.
 __device__ __attribute__((aligned(16))) unsigned int g_zero_chunk[4] = {0u, 0u, 0u, 0u};
+__device__ int g_dma_dbg = 0;      // tools only (mmda_debug_gemm_dma_mode): bit 0 = no MFMA work, bit 1 = no DMA after the prologue
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
-  static_assert(N == 0 || N == 8 || N == 16, "vmcnt immediates used by the DMA pipeline");
+  static_assert(N == 0 || N == 6 || N == 8 || N == 12 || N == 16, "vmcnt immediates used by the DMA pipeline");
   if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
 }
 
-template <bool TN, int NS>
+// Epilogue of a TM x 128 tile held by TM / 32 waves (wm = w >> 1 row blocks of 64, wn = w & 1 column halves): the twin of
+// gemm_bf16_epilogue for the DMA kernel's two tile heights (same staging through LDS, same slab / bias / gate-interleave handling).
+template <int TM>
+__device__ __forceinline__ void gemm_dma_epilogue(const mmda_gemm_bf16_args& g, f32x4 (&acc)[4][4], float* Cs, int row0, int col0,
+                                                  int splitk, int sp, float* slab, int ldn, bool tile_has_ones) {
+  constexpr int W = 4, TNn = 128, NTHR = TM * 2;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const int M = g.M, N = g.N;
+  const float alpha = g.alpha == 0.f ? 1.f : g.alpha;
+  const bool to_slab = splitk > 1;                       // block-uniform
+  if (!to_slab && tile_has_ones && wn == (N - col0) / 64) {
+    // the column n == N holds sum_k A[m,k]: bias gradient(s).  One tile per row block holds that column: a single writer per entry.
+    const int j = ((N - col0) % 64) / 16;
+    if ((lane & 15) == (N - col0) % 16) {
+#pragma unroll
+      for (int i = 0; i < W; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = row0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+          float v = 0.f;
+#pragma unroll
+          for (int jj = 0; jj < W; ++jj) v = (jj == j) ? acc[i][jj][r] : v;
+          if (m < M) {
+            const int mo = g.perm_m_H > 0 ? gate_orig(m, g.perm_m_H) : m;
+            g.bias_grad[mo] += v;
+            if (g.bias_grad2) g.bias_grad2[mo] += v;
+          }
+        }
+    }
+  }
+  const bool vec_out = to_slab || ((g.ldc & 3) == 0 && ((uintptr_t)g.C & 15) == 0 && (N & 3) == 0);      // block-uniform
+  if (vec_out) {
+    constexpr int LDC = TNn + 4;                         // floats per staged row
+    constexpr int RP = 64;                               // rows per pass: one wave row block (33 KB of the ring)
+    constexpr int C4 = TNn / 4;                          // float4 per staged row
+    const int c4 = tid % C4;
+    const int n = col0 + c4 * 4;
+    const bool n_ok = n < (to_slab ? ldn : N);
+    const float scale = to_slab ? 1.f : alpha;
+    float* const out_base = to_slab ? slab + (int64_t)sp * M * ldn : g.C;
+    const int out_ld = to_slab ? ldn : g.ldc;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    if (!to_slab && (g.bias || g.bias2)) {
+      const int nn = min(n, N - 4);
+      int nb0 = nn, nbs = 1;
+      if (g.perm_n_H > 0) { const int G = 4 * g.perm_n_H, d = nn / G; nb0 = d * G + ((nn - d * G) >> 2); nbs = g.perm_n_H; }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (g.bias) bsum[e] += g.bias[nb0 + e * nbs];
+        if (g.bias2) bsum[e] += g.bias2[nb0 + e * nbs];
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < TM / RP; ++p) {
+      __syncthreads();                                   // operand tiles (first pass) / previous pass are no longer read
+      if (wm == p) {                                     // wave-uniform: this pass is this wave's row block
+#pragma unroll
+        for (int i = 0; i < W; ++i)
+#pragma unroll
+          for (int j = 0; j < W; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              Cs[(i * 16 + (lane >> 4) * 4 + r) * LDC + wn * 64 + j * 16 + (lane & 15)] = scale * acc[i][j][r];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < RP * C4 / NTHR; ++q) {
+        const int lr = (q * NTHR + tid) / C4;
+        const int m = row0 + p * RP + lr;
+        if (m < M && n_ok) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[lr * LDC + c4 * 4]) + bsum;
+          const int mo = (!to_slab && g.perm_m_H > 0) ? gate_orig(m, g.perm_m_H) : m;
+          float* dst = out_base + (int64_t)mo * out_ld + n;
+          if (!to_slab && g.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
+          *reinterpret_cast<f32x4*>(dst) = v;
+        }
+      }
+    }
+    return;
+  }
+  // Scalar path (unaligned rows)
+#pragma unroll
+  for (int i = 0; i < W; ++i) {
+    float oldc[W][4];
+    const bool rmw = g.accumulate;                             // block-uniform
+#pragma unroll
+    for (int j = 0; j < W; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nc = min(col0 + wn * 64 + j * 16 + (lane & 15), N - 1);
+        int mc = min(row0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r, M - 1);
+        if (g.perm_m_H > 0) mc = gate_orig(mc, g.perm_m_H);
+        oldc[j][r] = rmw ? g.C[(int64_t)mc * g.ldc + nc] : 0.f;
+      }
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      const int n = col0 + wn * 64 + j * 16 + (lane & 15);
+      const bool n_ok = n < N;
+      const int nc = min(n, N - 1);
+      float bsum = 0.f;
+      const int nb = g.perm_n_H > 0 ? gate_orig(nc, g.perm_n_H) : nc;
+      if (g.bias) bsum += g.bias[nb];
+      if (g.bias2) bsum += g.bias2[nb];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = row0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+        if (!n_ok || m >= M) continue;
+        const int64_t ci = (int64_t)(g.perm_m_H > 0 ? gate_orig(m, g.perm_m_H) : m) * g.ldc + n;
+        g.C[ci] = alpha * acc[i][j][r] + bsum + oldc[j][r];
+      }
+    }
+  }
+}
+
+// TM x 128 output tile, TM / 32 waves of 64 x 64 (TM = 128: 4 waves, 32 KB per stage, two workgroups per CU at NS = 2;
+// TM = 256: 8 waves, 48 KB per stage, ONE workgroup per CU with NS = 3 -- 1.33x the FLOPs per byte moved into LDS and three k-tiles
+// deep, for the long-K problems: what bounds the 128-row form is the DMA latency times the bytes the LDS can hold in flight).
+template <bool TN, int NS, int TM>
 __device__ __forceinline__ void gemm_bf16_dma_tile(const mmda_gemm_bf16_args& g, int splitk, int bx, int by, int sp, unsigned char* lds,
                                                    float* slab, int ldn) {
-  constexpr int T = 128, W = 4;
-  constexpr int OPB = T * TK * 2;                      // bytes of one operand's k-tile image (16 KB)
-  constexpr int STAGE = 2 * OPB;
+  constexpr int W = 4, NW = TM / 32;
+  constexpr int OPA = TM * TK * 2, OPB = 128 * TK * 2;  // bytes of the operands' k-tile images
+  constexpr int STAGE = OPA + OPB;
+  constexpr int CA = 4, CB = 16 / NW;                  // DMA instructions per wave, operand and k-tile
+  constexpr int ACPR = TM / 8;                         // tn: 16-byte chunks per k-row of the A image
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 1, wn = w & 1;
-  const int row0 = by * T, col0 = bx * T;
+  const int row0 = by * TM, col0 = bx * 128;
   const int M = g.M, N = g.N, K = g.K;
   const int Kp = (K + 7) & ~7;
   const unsigned short* A = reinterpret_cast<const unsigned short*>(g.A);
   const unsigned short* Bm = reinterpret_cast<const unsigned short*>(g.B);
-  const bool tile_has_ones = g.bias_grad != nullptr && col0 <= N && N < col0 + T;       // block-uniform
+  const bool tile_has_ones = g.bias_grad != nullptr && col0 <= N && N < col0 + 128;     // block-uniform
   const bool my_ones = tile_has_ones && wn == (N - col0) / 64;                          // wave-uniform
 
   f32x4 acc[W][W], accb[W];
@@ -440,23 +563,34 @@ __device__ __forceinline__ void gemm_bf16_dma_tile(const mmda_gemm_bf16_args& g,
     for (int j = 0; j < W; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  // ---- source addressing of this thread's 4 + 4 chunks per k-tile.  DMA instruction j of wave w fills LDS bytes
-  // [(4 w + j) * 1024, +1024) of an operand image: lane l writes slot s = (4 w + j) * 64 + l.  Element offsets are 32-bit (the host
+  // ---- source addressing of this thread's CA + CB chunks per k-tile.  DMA instruction j of wave w fills LDS bytes
+  // [(C w + j) * 1024, +1024) of an operand image: lane l writes slot s = (C w + j) * 64 + l.  Element offsets are 32-bit (the host
   // checks the operand sizes).
-  int offA[4], offB[4];
-  int kofs[4];                                         // nt: first k of the chunk within the tile; tn: k-row within the tile
+  int offA[CA], offB[CB];
+  int kofA[CA], kofB[CB];                              // nt: first k of the chunk within the tile; tn: k-row within the tile
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int s = (4 * w + j) * 64 + lane;
+  for (int j = 0; j < CA; ++j) {
+    const int s = (CA * w + j) * 64 + lane;
+    if (TN) {
+      const int kr = s / ACPR, c = (s % ACPR) ^ (2 * (kr & 7));
+      kofA[j] = kr;
+      offA[j] = kr * g.lda + row0 + c * 8;
+    } else {
+      const int r = s >> 3, c = (s & 7) ^ ((r >> 1) & 7);
+      kofA[j] = c * 8;
+      offA[j] = min(row0 + r, M - 1) * g.lda + c * 8;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < CB; ++j) {
+    const int s = (CB * w + j) * 64 + lane;
     if (TN) {
       const int kr = s >> 4, c = (s & 15) ^ (2 * (kr & 7));
-      kofs[j] = kr;
-      offA[j] = kr * g.lda + row0 + c * 8;
+      kofB[j] = kr;
       offB[j] = kr * g.ldb + col0 + c * 8;
     } else {
       const int r = s >> 3, c = (s & 7) ^ ((r >> 1) & 7);
-      kofs[j] = c * 8;
-      offA[j] = min(row0 + r, M - 1) * g.lda + c * 8;
+      kofB[j] = c * 8;
       offB[j] = min(col0 + r, N - 1) * g.ldb + c * 8;
     }
   }
@@ -484,25 +618,27 @@ __device__ __forceinline__ void gemm_bf16_dma_tile(const mmda_gemm_bf16_args& g,
   auto issue = [&](int kt, int stage) {                // kt >= nk: a tile of zeros nobody reads (keeps the vmcnt arithmetic uniform)
     const int k0 = kt * TK;
     const bool live = kt < nk;
-    const unsigned dA = lds0 + stage * STAGE + (4 * w) * 1024;
+    const unsigned dA = lds0 + stage * STAGE + (CA * w) * 1024;
+    const unsigned dB = lds0 + stage * STAGE + OPA + (CB * w) * 1024;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int oa, ob;
-      bool oka, okb;
-      if (TN) {
-        oa = offA[j] + k0 * g.lda; ob = offB[j] + k0 * g.ldb;
-        const bool kin = live & (k0 + kofs[j] < K);
-        oka = kin & (oa <= limA); okb = kin & (ob <= limB);
-      } else {
-        oa = offA[j] + k0; ob = offB[j] + k0;
-        oka = okb = live & (k0 + kofs[j] < Kp);
-      }
+    for (int j = 0; j < CA; ++j) {
+      int oa;
+      bool oka;
+      if (TN) { oa = offA[j] + k0 * g.lda; oka = live & (k0 + kofA[j] < K) & (oa <= limA); }
+      else { oa = offA[j] + k0; oka = live & (k0 + kofA[j] < Kp); }
       const unsigned short* pa = A + oa;
-      const unsigned short* pb = Bm + ob;
       pa = oka ? pa : zero;
-      pb = okb ? pb : zero;
       dma16(pa, dA + j * 1024);
-      dma16(pb, dA + OPB + j * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+      int ob;
+      bool okb;
+      if (TN) { ob = offB[j] + k0 * g.ldb; okb = live & (k0 + kofB[j] < K) & (ob <= limB); }
+      else { ob = offB[j] + k0; okb = live & (k0 + kofB[j] < Kp); }
+      const unsigned short* pb = Bm + ob;
+      pb = okb ? pb : zero;
+      dma16(pb, dB + j * 1024);
     }
   };
 
@@ -511,7 +647,7 @@ __device__ __forceinline__ void gemm_bf16_dma_tile(const mmda_gemm_bf16_args& g,
   const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
   auto compute = [&](int stage) {
     const unsigned char* As = lds + stage * STAGE;
-    const unsigned char* Bs = As + OPB;
+    const unsigned char* Bs = As + OPA;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 a[W], b[W];
@@ -522,9 +658,9 @@ __device__ __forceinline__ void gemm_bf16_dma_tile(const mmda_gemm_bf16_args& g,
 #pragma unroll
         for (int i = 0; i < W; ++i) {
           const int ca = (wm * 64 + i * 16) >> 3, cb = (wn * 64 + i * 16) >> 3;
-          const unsigned char* pa = As + k * 256 + (((ca + (tp >> 1)) ^ sw) << 4) + 8 * (tp & 1);
+          const unsigned char* pa = As + k * (2 * TM) + (((ca + (tp >> 1)) ^ sw) << 4) + 8 * (tp & 1);
           const unsigned char* pb = Bs + k * 256 + (((cb + (tp >> 1)) ^ sw) << 4) + 8 * (tp & 1);
-          const v4s a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)pa), a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(pa + 16 * 256));
+          const v4s a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)pa), a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(pa + 16 * 2 * TM));
           const v4s b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)pb), b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(pb + 16 * 256));
           a[i] = bf16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
           b[i] = bf16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
@@ -548,17 +684,18 @@ __device__ __forceinline__ void gemm_bf16_dma_tile(const mmda_gemm_bf16_args& g,
     }
   };
 
+  const int dbg = g_dma_dbg;
 #pragma unroll
   for (int u = 0; u < NS - 1; ++u) issue(kt0 + u, u);
   for (int kt = kt0; kt < nk; kt += NS) {
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
       if (kt + u < nk) {                                 // block-uniform
-        wait_vmcnt<8 * (NS - 2)>();                      // this wave's part of tile kt + u has landed
+        wait_vmcnt<(CA + CB) * (NS - 2)>();              // this wave's part of tile kt + u has landed
         __builtin_amdgcn_s_barrier();                    // ... everybody's has; and everybody is done reading tile kt + u - 1
         asm volatile("" ::: "memory");
-        issue(kt + u + NS - 1, (u + NS - 1) % NS);
-        compute(u);
+        if (!(dbg & 2)) issue(kt + u + NS - 1, (u + NS - 1) % NS);
+        if (!(dbg & 1)) compute(u);
       }
     }
   }
@@ -573,12 +710,13 @@ __device__ __forceinline__ void gemm_bf16_dma_tile(const mmda_gemm_bf16_args& g,
           if (j == jo) acc[i][j] = accb[i];
     }
   }
-  gemm_bf16_epilogue<T>(g, acc, reinterpret_cast<float*>(lds), row0, col0, splitk, sp, slab, ldn, tile_has_ones);
+  if (TM == 128) gemm_bf16_epilogue<128>(g, acc, reinterpret_cast<float*>(lds), row0, col0, splitk, sp, slab, ldn, tile_has_ones);
+  else gemm_dma_epilogue<TM>(g, acc, reinterpret_cast<float*>(lds), row0, col0, splitk, sp, slab, ldn, tile_has_ones);
 }
 
-template <int NS>
-__global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void gemm_bf16_dma_kernel(Bf16Group G) {
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * 2 * 128 * TK * 2];      // the ONLY LDS object of the kernel
+template <int NS, int TM>
+__global__ __launch_bounds__(TM * 2, (TM == 128 && NS == 2) ? 2 : 1) void gemm_bf16_dma_kernel(Bf16Group G) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * (TM + 128) * TK * 2];      // the ONLY LDS object of the kernel
   int pi = 0;
 #pragma unroll
   for (int k = 1; k < GROUP_MAX; ++k)
@@ -591,8 +729,8 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void gemm_bf16_dma_kernel(Bf1
   if (idx >= q + (x < r ? 1 : 0)) return;
   const int local = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
   const int bx = local % G.tx[pi], by = (local / G.tx[pi]) % G.ty[pi], sp = local / (G.tx[pi] * G.ty[pi]);
-  if (g.tn) gemm_bf16_dma_tile<true, NS>(g, splitk, bx, by, sp, lds, G.slab[pi], G.ldn[pi]);      // block-uniform
-  else gemm_bf16_dma_tile<false, NS>(g, splitk, bx, by, sp, lds, G.slab[pi], G.ldn[pi]);
+  if (g.tn) gemm_bf16_dma_tile<true, NS, TM>(g, splitk, bx, by, sp, lds, G.slab[pi], G.ldn[pi]);      // block-uniform
+  else gemm_bf16_dma_tile<false, NS, TM>(g, splitk, bx, by, sp, lds, G.slab[pi], G.ldn[pi]);
 }
 
 __global__ __launch_bounds__(256) void convert_kernel(ConvLaunch L) {
@@ -637,21 +775,32 @@ extern "C" int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, vo
   int call_rows = 0;
   for (int i = 0; i < n; ++i) call_rows = max(call_rows, args[i].tn ? args[i].K : args[i].M);
   const bool dma_call = dma_on && call_rows >= dma_min_rows;
+  static const int dma_tall = getenv("MMDA_GEMM_DMA_TALL") ? atoi(getenv("MMDA_GEMM_DMA_TALL")) : 1;
+  static const int tall_stages = getenv("MMDA_GEMM_DMA_TALL_STAGES") ? atoi(getenv("MMDA_GEMM_DMA_TALL_STAGES")) : 3;
   auto class_of = [&](const mmda_gemm_bf16_args& a) {
     const int Ne = a.N + (a.bias_grad ? 1 : 0);
     if (dma_call && a.M >= dma_min && Ne >= dma_min) {
       bool ok = true;
       if (a.tn) ok = !(a.lda & 7) && !(a.ldb & 7) && !(((uintptr_t)a.A | (uintptr_t)a.B) & 15) && ((double)a.K + 64.0) * (double)max(a.lda, a.ldb) < 2.0e9;
+      // 256-row tiles (class 3) for the long k-walks of a tall output: K >= 1024, M >= 512 (input gradients: K = 8H; weight gradients:
+      // K = T * B).  The short-K forward products stay on the 128-row form: they are a prologue and an epilogue around five to ten
+      // k-tiles, and two workgroups per CU overlap those where one cannot.  MMDA_GEMM_DMA_TALL=0 switches the class off.
+      if (ok && dma_tall && a.K >= 1024 && a.M >= 512) return 3;
       if (ok) return 2;
     }
     return ceil_div(Ne, 128) * ceil_div(a.M, 128) >= t128_min ? 1 : 0;
   };
   // ---- plan: per class, the problems in launch order and their split-K
   struct Plan { std::vector<int> order; std::vector<int> sks; };
-  Plan plan[3];
-  auto tiles_of = [&](const mmda_gemm_bf16_args& a, int T) { return ceil_div(a.N + (a.bias_grad ? 1 : 0), T) * ceil_div(a.M, T); };
-  for (int ci = 0; ci < 3; ++ci) {
-    const int T = ci == 0 ? 64 : 128;
+  constexpr int NCLASS = 4;
+  Plan plan[NCLASS];
+  // (T: the class id stands for its tile -- 64 x 64, 128 x 128, 128 x 128, 256 x 128 rows x columns)
+  auto tiles_of = [&](const mmda_gemm_bf16_args& a, int ci) {
+    const int tm = ci == 0 ? 64 : (ci == 3 ? 256 : 128), tn = ci == 0 ? 64 : 128;
+    return ceil_div(a.N + (a.bias_grad ? 1 : 0), tn) * ceil_div(a.M, tm);
+  };
+  for (int ci = 0; ci < NCLASS; ++ci) {
+    const int T = ci;
     std::vector<int>& order = plan[ci].order;
     std::vector<int>& sks = plan[ci].sks;
     sks.assign(n, 1);
@@ -666,8 +815,8 @@ extern "C" int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, vo
     }
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return args[x].K > args[y].K; });
     // workgroups of this class the chip holds at once
-    const int resident = ci == 0 ? 1024 : (ci == 1 ? 512 : (dma_stages == 2 ? 512 : 256));
-    const bool crowded = all_tiles >= (ci == 2 ? resident : 512);
+    const int resident = ci == 0 ? 1024 : (ci == 1 ? 512 : (ci == 3 ? 256 : (dma_stages == 2 ? 512 : 256)));
+    const bool crowded = all_tiles >= (ci >= 2 ? resident : 512);
     int64_t work2 = 0;                                    // class 2: k-tiles of the whole launch
     for (int i : order) work2 += (int64_t)tiles_of(args[i], T) * ceil_div(args[i].K, TK);
     // pass 1: the split of every problem on its own
@@ -677,7 +826,7 @@ extern "C" int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, vo
       const int nk = ceil_div(a.K, TK);
       const double out_mb = (double)a.M * a.N * 4.0 / 1048576.0;
       int sk = 1;
-      if (ci == 2) {
+      if (ci >= 2) {
         // the DMA kernel: a workgroup's time is its k-tiles (~1 us each: the latency of the tile in flight), so the launch is cut
         // into pieces of equal length -- target = the k-tiles per workgroup at which the whole launch fills the resident slots once --
         // and a problem is split where its k-walk is longer than that (the weight gradients of a large batch, K = T * B, beside
@@ -717,7 +866,7 @@ extern "C" int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, vo
       const int sl = slots >= 0 ? slots : resident;
       auto total = [&]() { int64_t t = 0; for (int i : order) t += (int64_t)tiles_of(args[i], T) * sks[i]; return t; };
       int64_t tot = total();
-      while (ci != 2 && sl > 0 && tot > sl && tot < 2 * (int64_t)sl) {
+      while (ci < 2 && sl > 0 && tot > sl && tot < 2 * (int64_t)sl) {
         int best = -1;
         for (int i : order) if (sks[i] > 1 && (best < 0 || sks[i] > sks[best] || (sks[i] == sks[best] && tiles_of(args[i], T) > tiles_of(args[best], T)))) best = i;
         if (best < 0) break;
@@ -735,7 +884,7 @@ extern "C" int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, vo
   // ---- slabs of the split problems: one scratch request for the whole call
   std::vector<int64_t> slab_off(n, -1);
   int64_t slab_floats = 0;
-  for (int ci = 0; ci < 3; ++ci)
+  for (int ci = 0; ci < NCLASS; ++ci)
     for (int i : plan[ci].order)
       if (plan[ci].sks[i] > 1) {
         const mmda_gemm_bf16_args& a = args[i];
@@ -750,9 +899,10 @@ extern "C" int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, vo
   }
   // ---- launches (the DMA class first: it holds the largest problems), one reduce launch behind them all
   std::vector<SplitKJob> jobs;
-  for (int cc = 0; cc < 3; ++cc) {
-    const int ci = cc == 0 ? 2 : cc - 1;
-    const int T = ci == 0 ? 64 : 128;
+  for (int cc = 0; cc < NCLASS; ++cc) {
+    const int ci = cc == 0 ? 3 : (cc == 1 ? 2 : cc - 2);
+    const int T = ci == 0 ? 64 : 128;                      // tile columns; rows: 256 for class 3
+    const int TMr = ci == 3 ? 256 : T;
     const std::vector<int>& order = plan[ci].order;
     const std::vector<int>& sks = plan[ci].sks;
     bool any_tn = false;
@@ -765,9 +915,12 @@ extern "C" int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, vo
       if (blocks == 0) { G.n = 0; return MMDA_OK; }
       for (int k = G.n; k <= GROUP_MAX; ++k) G.start[k] = blocks;
       for (int k = G.n; k < GROUP_MAX; ++k) { G.p[k] = G.p[0]; G.tx[k] = G.ty[k] = G.splitk[k] = 1; G.tile[k] = T; G.slab[k] = nullptr; G.ldn[k] = 0; }
-      if (ci == 2) {
-        if (dma_stages == 3) hipLaunchKernelGGL((gemm_bf16_dma_kernel<3>), dim3(blocks), dim3(256), 0, s, G);
-        else hipLaunchKernelGGL((gemm_bf16_dma_kernel<2>), dim3(blocks), dim3(256), 0, s, G);
+      if (ci == 3) {
+        if (tall_stages == 2) hipLaunchKernelGGL((gemm_bf16_dma_kernel<2, 256>), dim3(blocks), dim3(512), 0, s, G);
+        else hipLaunchKernelGGL((gemm_bf16_dma_kernel<3, 256>), dim3(blocks), dim3(512), 0, s, G);
+      } else if (ci == 2) {
+        if (dma_stages == 3) hipLaunchKernelGGL((gemm_bf16_dma_kernel<3, 128>), dim3(blocks), dim3(256), 0, s, G);
+        else hipLaunchKernelGGL((gemm_bf16_dma_kernel<2, 128>), dim3(blocks), dim3(256), 0, s, G);
       } else if (form == 0) {
         if (T == 128) hipLaunchKernelGGL((gemm_bf16_kernel<128, false>), dim3(blocks), dim3(256), 0, s, G);
         else hipLaunchKernelGGL((gemm_bf16_kernel<64, false>), dim3(blocks), dim3(256), 0, s, G);
@@ -786,7 +939,7 @@ extern "C" int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, vo
       G.p[k] = a;
       const int Ne = a.N + (a.bias_grad ? 1 : 0);
       G.tile[k] = T;
-      G.tx[k] = ceil_div(Ne, T); G.ty[k] = ceil_div(a.M, T);
+      G.tx[k] = ceil_div(Ne, T); G.ty[k] = ceil_div(a.M, TMr);
       const int tiles = G.tx[k] * G.ty[k];
       const int sk = sks[i];
       G.splitk[k] = sk;
@@ -808,6 +961,10 @@ extern "C" int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, vo
   }
   if (!jobs.empty()) { const int rc = mmda_splitk_reduce(jobs.data(), (int)jobs.size(), s); if (rc) return rc; }
   return MMDA_OK;
+}
+
+extern "C" int mmda_debug_gemm_dma_mode(int mode) {       // tools/ only: ablate the DMA kernel's k-loop (results are then wrong)
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_dma_dbg), &mode, sizeof(int)) == hipSuccess ? MMDA_OK : MMDA_ELAUNCH;
 }
 
 extern "C" int mmda_convert_bf16(const mmda_convert_job* jobs, int n, void* stream) {
