@@ -35,16 +35,16 @@ __device__ __forceinline__ void gemm_body(const mmda_gemm_args& g, int splitk, u
 
   // per-thread staging coordinates (fixed across k-tiles)
   int a_r[8], a_k[8], b_r[8], b_k[8];
-  int64_t a_row_off[8];
+  int64_t a_row_off_c[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     int e = tid + 256 * i;
     if (g.transA) { a_r[i] = e & 63; a_k[i] = e >> 6; } else { a_r[i] = e >> 5; a_k[i] = e & 31; }
     if (g.transB) { b_r[i] = e >> 5; b_k[i] = e & 31; } else { b_r[i] = e & 63; b_k[i] = e >> 6; }
     int m = row0 + a_r[i];
-    int64_t src = m;
-    if (g.gather && m < M) src = g.gather[m];
-    a_row_off[i] = src;
+    int64_t src = min(m, M - 1);
+    if (g.gather) src = g.gather[min(m, M - 1)];
+    a_row_off_c[i] = src;                               // (clamped: rows past M load a valid row and are zeroed at the LDS store)
   }
 
   f32x4 acc[2][2];
@@ -53,35 +53,43 @@ __device__ __forceinline__ void gemm_body(const mmda_gemm_args& g, int splitk, u
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // Register staging.  Every load is UNCONDITIONAL from a clamped (always valid) address and the zero fill of the out-of-range
+  // elements happens when the value is stored to LDS: a load under a lane-dependent branch costs a full `s_waitcnt vmcnt(0)` each --
+  // sixteen serialised memory latencies per k-tile (the fusion block's weight-gradient launch took 232 us at B = 256 that way).
   float rap[PF][8], rbp[PF][8];
-  auto load_tile = [&](float (&ra)[8], float (&rb)[8], int k0) {
+  unsigned okp[PF];                                     // bit i: A element i in range; bit 8 + i: B element i; bit 16 + i: B element i is the ones column
+  auto load_tile = [&](float (&ra)[8], float (&rb)[8], unsigned& ok, int k0) {
+    ok = 0u;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      int m = row0 + a_r[i], k = k0 + a_k[i];
-      float v = 0.f;
-      if (m < M && k < K) {
-        int64_t off = g.transA ? (int64_t)k * g.lda + m : a_row_off[i] * g.lda + k;
-        v = A[off];
-        if (A2) v += A2[off];
-      }
+      const int m = row0 + a_r[i], k = k0 + a_k[i];
+      const bool va = m < M && k < K;
+      const int kc = max(0, min(k, K - 1));
+      const int64_t off = g.transA ? (int64_t)kc * g.lda + min(m, M - 1) : a_row_off_c[i] * g.lda + kc;
+      float v = A[off];
+      if (A2) v += A2[off];                              // (kernel-uniform)
       ra[i] = v;
-      int n = col0 + b_r[i];
-      k = k0 + b_k[i];
-      float u = 0.f;
-      if (n < N && k < K) u = g.transB ? Bm[(int64_t)n * g.ldb + k] : Bm[(int64_t)k * g.ldb + n];
-      if (g.bias_grad && n == N && k < K) u = 1.0f;          // virtual all-ones column: its output is the bias gradient
-      rb[i] = u;
+      ok |= va ? (1u << i) : 0u;
+      const int n = col0 + b_r[i];
+      const int kb = k0 + b_k[i];
+      const bool vb = n < N && kb < K;
+      const int nc = min(n, N - 1), kbc = max(0, min(kb, K - 1));
+      rb[i] = g.transB ? Bm[(int64_t)nc * g.ldb + kbc] : Bm[(int64_t)kbc * g.ldb + nc];
+      ok |= vb ? (1u << (8 + i)) : 0u;
+      ok |= (g.bias_grad && n == N && kb < K) ? (1u << (16 + i)) : 0u;      // virtual all-ones column: its output is the bias gradient
     }
   };
-  auto store_tile = [&](const float (&ra)[8], const float (&rb)[8]) {
+  auto store_tile = [&](const float (&ra)[8], const float (&rb)[8], unsigned ok) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
+      const float av = (ok >> i) & 1u ? ra[i] : 0.f;
+      const float bv = (ok >> (16 + i)) & 1u ? 1.0f : ((ok >> (8 + i)) & 1u ? rb[i] : 0.f);
       if (MODE == MMDA_BF16) {
-        As_h[a_r[i] * LDS_BF16_LD + a_k[i]] = f2bf(ra[i]);
-        Bs_h[b_r[i] * LDS_BF16_LD + b_k[i]] = f2bf(rb[i]);
+        As_h[a_r[i] * LDS_BF16_LD + a_k[i]] = f2bf(av);
+        Bs_h[b_r[i] * LDS_BF16_LD + b_k[i]] = f2bf(bv);
       } else {
-        As_f[a_r[i] * LDS_F32_LD + a_k[i]] = ra[i];
-        Bs_f[b_r[i] * LDS_F32_LD + b_k[i]] = rb[i];
+        As_f[a_r[i] * LDS_F32_LD + a_k[i]] = av;
+        Bs_f[b_r[i] * LDS_F32_LD + b_k[i]] = bv;
       }
     }
   };
@@ -99,24 +107,24 @@ __device__ __forceinline__ void gemm_body(const mmda_gemm_args& g, int splitk, u
   if (PF > 1) {
 #pragma unroll
     for (int p = 0; p < PF; ++p)
-      if (kt0 + p < nk) load_tile(rap[p], rbp[p], (kt0 + p) * BK);
+      if (kt0 + p < nk) load_tile(rap[p], rbp[p], okp[p], (kt0 + p) * BK);
   } else {
-    load_tile(rap[0], rbp[0], kt0 * BK);
+    load_tile(rap[0], rbp[0], okp[0], kt0 * BK);
   }
 #pragma unroll 1
   for (int kt = kt0; kt < nk; ++kt) {
     __syncthreads();            // previous tile's fragment reads are done
     if (PF > 1) {
       const int p = kt - kt0;
-      if (p == 0) store_tile(rap[0], rbp[0]);
-      else if (p == 1) store_tile(rap[PF > 1 ? 1 : 0], rbp[PF > 1 ? 1 : 0]);
-      else if (p == 2) store_tile(rap[PF > 2 ? 2 : 0], rbp[PF > 2 ? 2 : 0]);
-      else store_tile(rap[PF > 3 ? 3 : 0], rbp[PF > 3 ? 3 : 0]);
+      if (p == 0) store_tile(rap[0], rbp[0], okp[0]);
+      else if (p == 1) store_tile(rap[PF > 1 ? 1 : 0], rbp[PF > 1 ? 1 : 0], okp[PF > 1 ? 1 : 0]);
+      else if (p == 2) store_tile(rap[PF > 2 ? 2 : 0], rbp[PF > 2 ? 2 : 0], okp[PF > 2 ? 2 : 0]);
+      else store_tile(rap[PF > 3 ? 3 : 0], rbp[PF > 3 ? 3 : 0], okp[PF > 3 ? 3 : 0]);
     } else {
-      store_tile(rap[0], rbp[0]);
+      store_tile(rap[0], rbp[0], okp[0]);
     }
     __syncthreads();
-    if (PF == 1 && kt + 1 < nk) load_tile(rap[0], rbp[0], (kt + 1) * BK);   // global loads fly under the MFMAs below
+    if (PF == 1 && kt + 1 < nk) load_tile(rap[0], rbp[0], okp[0], (kt + 1) * BK);   // global loads fly under the MFMAs below
     const int fr = lane & 15, fq = lane >> 4;
     if (MODE == MMDA_BF16) {
       bf16x8 a[2], b[2];

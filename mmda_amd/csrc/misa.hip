@@ -9,6 +9,7 @@ bool mmda_ln_bwd_parts_applies(const mmda_ln_bwd_args* a, int n);
 int64_t mmda_ln_parts_floats(const mmda_ln_bwd_args* a, int n);
 int mmda_ln_bwd_parts(const mmda_ln_bwd_args* a, int n, float* parts, void* stream);
 int mmda_ln_parts_finish(const mmda_ln_bwd_args* a, int n, float* parts, void* stream);
+int mmda_embed_scatter_add_masked(float* dW, const int64_t* ids, int rows, int dim, const float* dX, const int* lengths, int B, void* stream);
 
 #include <map>
 #include <string>
@@ -1691,7 +1692,7 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
       }
     } else if (!x.rc) {
       // text: gradient w.r.t. the embedding rows, scattered densely into embed.weight.grad (sparse=False)
-      x.rc = mmda_embed_scatter_add(GG(m->embed), t_ids, R, c.d_t, WS(m->mod[0].d_x), stream);
+      x.rc = mmda_embed_scatter_add_masked(GG(m->embed), t_ids, R, c.d_t, WS(m->mod[0].d_x), lengths, B, stream);
     }
     if (x.rc) return x.rc;
   }

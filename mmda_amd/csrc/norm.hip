@@ -6,6 +6,7 @@
 #include "splitk.h"
 
 int mmda_embed_scatter_sorted(float* dW, const int64_t* ids, int n, int D, const float* rows, void* stream);   // dist.hip
+int mmda_embed_scatter_add_masked(float* dW, const int64_t* ids, int rows, int dim, const float* dX, const int* lengths, int B, void* stream);
 
 namespace {
 
@@ -307,59 +308,97 @@ __global__ void embed_gather_kernel(const float* __restrict__ W, const int64_t* 
 }
 
 // dW[ids[p]] += dX[p] for every position p, deterministically: one workgroup per position; the workgroup of the FIRST position that
-// holds an id owns that id -- it marks every position with the same id in an LDS bit mask (one pass over the id list), adds their
-// rows in position order and adds the sum to the table row (single writer: no atomics, identical bits on every run; float atomics
-// gave the rows of repeated ids in arrival order).  Windows of 32768 positions keep the mask at 4 KB for any list length.
-constexpr int ES_WIN = 32768;
-__global__ __launch_bounds__(256) void embed_scatter_kernel(float* dW, const int64_t* __restrict__ ids, int rows, int dim, const float* __restrict__ dX) {
-  __shared__ unsigned mask[ES_WIN / 32];
+// holds an id owns that id -- it marks every position with the same id in an LDS bit mask (one pass over the id list), compacts the
+// marks into an ordered list, and its four waves add the rows of four contiguous quarters of that list in position order (eight row
+// loads in flight per lane and dimension group), the quarters' sums are added in order and the total goes to the table row (single
+// writer: no atomics, identical bits on every run; float atomics gave the rows of repeated ids in arrival order).  Lists of up to
+// ES_MAX positions (longer ones take the sort-based path of dist.hip).  `lengths` (optional, with B): position p = t * B + b is padding
+// when t >= lengths[b] -- its row is exactly zero (no gradient flows through padding) and it is skipped, as owner and as contributor:
+// a ragged batch holds the pad id hundreds of times.
+constexpr int ES_MAX = 4096;
+__global__ __launch_bounds__(256) void embed_scatter_kernel(float* dW, const int64_t* __restrict__ ids, int rows, int dim, const float* __restrict__ dX,
+                                                            const int* __restrict__ lengths, int B) {
+  __shared__ unsigned mask[ES_MAX / 32];
+  __shared__ unsigned short list[ES_MAX];
+  __shared__ int base[ES_MAX / 32 + 1];
   __shared__ int earlier;
+  __shared__ float part[3][1024];
   const int p = blockIdx.x;
   const int64_t id = ids[p];
-  if (id < 0) return;                                    // (padding marker of the gathered lists; block-uniform)
+  auto padded = [&](int q) { return lengths != nullptr && (q / B) >= lengths[q % B]; };
+  if (id < 0 || padded(p)) return;                       // block-uniform
+  const int nwords = (rows + 31) / 32;
   if (threadIdx.x == 0) earlier = 0;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};                   // dims threadIdx.x + 256 j (dim <= 1024)
-  for (int w0 = 0; w0 < rows; w0 += ES_WIN) {
-    const int wn = min(ES_WIN, rows - w0);
-    const int nwords = (wn + 31) / 32;
-    for (int i = threadIdx.x; i < nwords; i += 256) mask[i] = 0u;
-    __syncthreads();
-    // one pass over the window's ids, eight loads in flight per thread (one at a time is a cache latency per 256 ids)
+  for (int i = threadIdx.x; i < nwords; i += 256) mask[i] = 0u;
+  __syncthreads();
+  // one pass over the ids, eight loads in flight per thread
 #pragma unroll 8
-    for (int q = threadIdx.x; q < wn; q += 256)
-      if (ids[w0 + q] == id) atomicOr(&mask[q >> 5], 1u << (q & 31));
-    __syncthreads();
-    if (w0 <= p) {                                       // an earlier position with this id owns it
-      const int lim = min(p - w0, wn);                   // positions [w0, w0 + lim) lie before p
-      for (int i = threadIdx.x; i < (lim + 31) / 32; i += 256) {
-        unsigned m = mask[i];
-        if (32 * i + 32 > lim) m &= (1u << (lim - 32 * i)) - 1u;
-        if (m) earlier = 1;                              // benign race: every writer stores 1
-      }
-      __syncthreads();
-      if (earlier) return;                               // block-uniform
+  for (int q = threadIdx.x; q < rows; q += 256)
+    if (ids[q] == id && !padded(q)) atomicOr(&mask[q >> 5], 1u << (q & 31));
+  __syncthreads();
+  for (int i = threadIdx.x; i < (p + 31) / 32; i += 256) {      // an earlier position with this id owns it
+    unsigned m = mask[i];
+    if (32 * i + 32 > p) m &= (1u << (p - 32 * i)) - 1u;
+    if (m) earlier = 1;                                  // benign race: every writer stores 1
+  }
+  __syncthreads();
+  if (earlier) return;                                   // block-uniform
+  // ordered list of the positions >= p that hold the id
+  if (threadIdx.x == 0) {
+    int c = 0;
+    for (int i = p >> 5; i < nwords; ++i) {
+      base[i] = c;
+      unsigned m = mask[i];
+      if (i == (p >> 5)) m &= ~((1u << (p & 31)) - 1u);
+      c += __builtin_popcount(m);
     }
-    if (w0 + wn > p) {
-      for (int i = max(0, (p - w0) >> 5); i < nwords; ++i) {
-        unsigned m = mask[i];
-        while (m) {
-          const int q = w0 + 32 * i + __builtin_ctz(m);
-          m &= m - 1;
-          if (q < p) continue;
+    base[nwords] = c;
+  }
+  __syncthreads();
+  const int total = base[nwords];
+  for (int i = (p >> 5) + threadIdx.x; i < nwords; i += 256) {
+    unsigned m = mask[i];
+    if (i == (p >> 5)) m &= ~((1u << (p & 31)) - 1u);
+    int o = base[i];
+    while (m) { list[o++] = (unsigned short)(32 * i + __builtin_ctz(m)); m &= m - 1; }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int per = (total + 3) / 4;
+  const int q0 = min(total, wave * per), q1 = min(total, q0 + per);
+  for (int d0 = 0; d0 < dim; d0 += 256) {                // dimension groups of 256: lane handles d0 + lane + 64 j, j < 4
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int q = q0; q < q1; q += 8) {
+      float v[8][4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int d = threadIdx.x + 256 * j;
-            if (d < dim) acc[j] += dX[(int64_t)q * dim + d];
-          }
+      for (int u = 0; u < 8; ++u) {
+        const int64_t r = list[min(q + u, q1 - 1)];      // (clamped: no load under a branch; the surplus is masked below)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int d = d0 + lane + 64 * j;
+          v[u][j] = dX[r * dim + min(d, dim - 1)];
         }
       }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (q + u < q1) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] += v[u][j];
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) part[wave - 1][lane + 64 * j] = acc[j];
     }
     __syncthreads();
-  }
+    if (wave == 0) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int d = threadIdx.x + 256 * j;
-    if (d < dim) dW[id * (int64_t)dim + d] += acc[j];
+      for (int j = 0; j < 4; ++j) {
+        const int d = d0 + lane + 64 * j;
+        if (d < dim) dW[id * (int64_t)dim + d] += ((acc[j] + part[0][lane + 64 * j]) + part[1][lane + 64 * j]) + part[2][lane + 64 * j];
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -622,9 +661,17 @@ extern "C" int mmda_embed_scatter_add(float* dW, const int64_t* ids, int rows, i
   if (rows == 0) return MMDA_OK;
   // long lists: sort-based list-order sums (dist.hip) -- the scan below costs rows^2 / 256 id compares (B=256, T=50: 158 us against
   // 9 us at B=32).  MMDA_SCATTER_SORT_MIN moves the limit.
-  static const int sort_min = getenv("MMDA_SCATTER_SORT_MIN") ? atoi(getenv("MMDA_SCATTER_SORT_MIN")) : 3072;
+  return mmda_embed_scatter_add_masked(dW, ids, rows, dim, dX, nullptr, 0, stream);
+}
+
+// (internal, misa.hip) the same with the batch's lengths: positions p = t * B + b with t >= lengths[b] are padding and are skipped
+int mmda_embed_scatter_add_masked(float* dW, const int64_t* ids, int rows, int dim, const float* dX, const int* lengths, int B, void* stream) {
+  if (!dW || !ids || !dX || rows < 0 || dim <= 0 || dim > 1024 || (lengths && B <= 0)) return MMDA_EINVAL;
+  if (rows == 0) return MMDA_OK;
+  static const int sort_min_env = getenv("MMDA_SCATTER_SORT_MIN") ? atoi(getenv("MMDA_SCATTER_SORT_MIN")) : 3072;
+  const int sort_min = sort_min_env > ES_MAX ? ES_MAX + 1 : sort_min_env;
   if (rows >= sort_min) return mmda_embed_scatter_sorted(dW, ids, rows, dim, dX, stream);
-  hipLaunchKernelGGL(embed_scatter_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, dW, ids, rows, dim, dX);
+  hipLaunchKernelGGL(embed_scatter_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, dW, ids, rows, dim, dX, lengths, B);
   MMDA_CHECK_LAUNCH("mmda_embed_scatter_add");
   return MMDA_OK;
 }
