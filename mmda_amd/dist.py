@@ -129,7 +129,20 @@ class DataParallelSync:
         if self.sparse_embedding is False or model is None or dense_floats >= flat_grads.numel():
             return False
         hooks = hasattr(model, "embedding_grad_rows") and hasattr(model, "set_embedding_grad_rows")
-        return hooks and (flat_grads.is_cuda or self.sparse_embedding is True)
+        if not hooks:
+            return False
+        if self.sparse_embedding is True:
+            return True
+        if not flat_grads.is_cuda:
+            return False
+        # None = decide by volume: the (ids, rows) form moves world * T*B rows to every rank, the dense form V rows through the all-reduce
+        # (MOSEI, V = 20 000, 8 ranks: B = 32 -> 12 800 gathered rows: sparse; B = 256 -> 102 400: dense).  Every rank decides alike: the
+        # row count is the padded (T, B) of the batch, agreed on beforehand when shapes may differ (equal_shapes or the count exchange).
+        rows_per_rank = getattr(model, "embedding_rows_per_step", lambda: None)()
+        vocab_rows = getattr(model, "embedding_table_rows", lambda: None)()
+        if rows_per_rank is None or vocab_rows is None or not self.equal_shapes:
+            return True
+        return self.world * int(rows_per_rank) < int(vocab_rows)
 
     def _exchange_embedding_rows(self, model) -> None:
         """Every rank's (ids, rows) all-gathered (rank-major list), then the deterministic segment sum of that list into the dense
@@ -144,9 +157,17 @@ class DataParallelSync:
                 pad = cap - ids.numel()
                 ids = torch.cat([ids, ids.new_full((pad,), -1)])
                 rows = torch.cat([rows, rows.new_zeros(pad, rows.shape[1])])
+        # ONE all-gather: the ids ride along as an extra fp32 column (exact below 2^24 rows; -1 = padding) -- a second collective
+        # costs its launch latency (~15 us over RCCL), which at these sizes is as much as the transfer itself
+        d = rows.shape[1]
+        if ids.numel() > 0 and int(getattr(model, "embedding_table_rows", lambda: 0)() or 0) < (1 << 24):
+            packed = torch.cat([rows, ids.to(rows.dtype).unsqueeze(1)], dim=1)            # (cap, d_t + 1)
+            allp = self._all_gather(packed).reshape(-1, d + 1)
+            model.set_embedding_grad_rows(allp[:, d].to(torch.int64).contiguous(), allp[:, :d].contiguous())
+            return
         all_ids = self._all_gather(ids)               # (world, cap)
         all_rows = self._all_gather(rows)             # (world, cap, d_t)
-        model.set_embedding_grad_rows(all_ids.reshape(-1), all_rows.reshape(-1, rows.shape[1]))
+        model.set_embedding_grad_rows(all_ids.reshape(-1), all_rows.reshape(-1, d))
 
     def sync(self, flat_grads: torch.Tensor, dense_floats: int, model=None) -> float:
         """Exchange the gradient bucket in place (sum over ranks); returns the scale (1/world) the optimizer applies.

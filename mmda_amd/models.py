@@ -511,6 +511,14 @@ class MISA(nn.Module):
         ids = torch.where(pad, torch.full_like(t, -1), t)
         return ids.reshape(R), self._ws_view("d_x_t", (R, self._layout["embed.weight"][1][1]))
 
+    def embedding_rows_per_step(self):
+        """T * B of the last step: the rows the (ids, rows) form of the embedding gradient holds (None before the first step)."""
+        return None if not getattr(self, "_last", None) else int(self._last["t"].numel())
+
+    def embedding_table_rows(self):
+        """V: the rows a dense exchange of embed.weight.grad moves."""
+        return int(self._layout["embed.weight"][1][0])
+
     def scatter_embedding_rows(self, ids: torch.Tensor, rows: torch.Tensor):
         """embed.weight.grad[ids] += rows with the native atomic scatter-add (summation order not fixed; ids < 0 not allowed)."""
         if ids.numel() == 0:
