@@ -2311,13 +2311,16 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
                                                             : lstm_fwd_wave_kernel<10, true, MMDA_CELL_LSTM, false, 0>)                         \
                                               : lstm_fwd_wave_kernel<10, false, MMDA_CELL_LSTM, false>)                                           \
                               : (L.gate_minor ? lstm_fwd_cluster_kernel<10, true> : lstm_fwd_cluster_kernel<10, false>);                 \
-    /* (the attribute is set once per kernel function and size, not per launch) */                               \
-    static std::vector<std::pair<const void*, size_t>> attr_done;                                                \
-    const std::pair<const void*, size_t> akey{reinterpret_cast<const void*>(kfn), lds_launch};                   \
-    if (std::find(attr_done.begin(), attr_done.end(), akey) == attr_done.end()) {                                \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                              (int)lds_launch) != hipSuccess) { (void)hipGetLastError(); }                       \
-      attr_done.push_back(akey);                                                                                 \
+    /* The attribute holds ONE value per kernel function (the last set wins): keep the LARGEST size ever asked of a function and  \
+     * set it again only when a larger one appears -- B = 32 (160 KB), then B = 64 (32 KB), then B = 32 again must still find 160 KB */ \
+    static std::vector<std::pair<const void*, size_t>> attr_max;                                                 \
+    {                                                                                                            \
+      const void* kf = reinterpret_cast<const void*>(kfn);                                                       \
+      auto it = std::find_if(attr_max.begin(), attr_max.end(), [&](const std::pair<const void*, size_t>& e) { return e.first == kf; }); \
+      if (it == attr_max.end() || it->second < lds_launch) {                                                     \
+        if (hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_launch) != hipSuccess) { (void)hipGetLastError(); } \
+        if (it == attr_max.end()) attr_max.push_back({kf, lds_launch}); else it->second = lds_launch;           \
+      }                                                                                                          \
     }                                                                                                            \
     hipLaunchKernelGGL(kfn, grid, block, lds_launch, s, L);                                                      \
   } while (0)

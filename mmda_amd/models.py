@@ -572,8 +572,18 @@ class MISA(nn.Module):
         """Raises MMDAError if a recurrence ever gave up waiting for its cluster (every result since then is invalid).
         One synchronous device->host read: Solver calls it once per epoch / evaluation pass and before saving a checkpoint."""
         if self.cluster_aborted():
-            raise _lib.MMDAError("a resident-weights recurrence timed out waiting for its workgroup cluster"
-                                 + (f" ({where})" if where else "") + ": results since then are invalid")
+            # The hand-off tags every published bf16 value with its epoch in a spare bit: a NaN / an overflowing activation reads as a tag
+            # that never matches, so a DIVERGED run ends here too (the reference would print NaN losses).  Say which one it was.
+            nonfinite = False
+            try:
+                L = self._ws_view("losses", (8,)).tolist()
+                nonfinite = any(x != x or abs(x) == float("inf") for x in L[:6]) or not bool(torch.isfinite(self._P).all())
+            except Exception:
+                pass
+            what = ("non-finite values reached a recurrence (diverged run: NaN / inf in the losses or parameters), which its data-tagged "
+                    "hand-off reports as a cluster time-out" if nonfinite else
+                    "a resident-weights recurrence timed out waiting for its workgroup cluster")
+            raise _lib.MMDAError(what + (f" ({where})" if where else "") + ": results since then are invalid")
 
     def set_recurrence(self, resident_weights: bool):
         """bf16 recurrences: W_hh resident in LDS across a workgroup cluster (default) or streamed from L2 per step."""

@@ -55,20 +55,76 @@ class _FlatOptimizer(torch.optim.Optimizer):
         if m is None:
             return super().state_dict()
         groups = [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]
-        out = {"mmda_flat": True, "step": int(m._step), "param_groups": groups}
+        # the moment buckets are raw images of the flat bucket: its (name, offset, shape) layout travels with them, so that a checkpoint
+        # written under another bucket order (another configuration or build) is re-ordered by name on load instead of loading wrongly
+        layout = [[k, int(off), [int(x) for x in shape]] for k, (off, shape) in m._layout.items()]
+        out = {"mmda_flat": 2, "step": int(m._step), "param_groups": groups, "layout": layout}
         out.update({k: v.detach().cpu().clone() for k, v in self._flat_state().items()})
         return out
 
     def load_state_dict(self, sd):
-        if not (isinstance(sd, dict) and sd.get("mmda_flat")):
-            return super().load_state_dict(sd)
         m = self._flat()
+        if not (isinstance(sd, dict) and sd.get("mmda_flat")):
+            if m is not None:
+                # a torch-format state (the reference writes one, solver.py:220): the attached fused step never reads self.state, so
+                # the moments would be dropped silently -- scatter them into the flat buckets by parameter order instead
+                return self._load_torch_state(sd, m)
+            return super().load_state_dict(sd)
         if m is None:
             raise _lib.MMDAError("load_state_dict of a flat optimizer state needs the optimizer attached to a MISA model on the GPU")
         for g, saved in zip(self.param_groups, sd["param_groups"]):
             g.update(saved)
         m._step = int(sd["step"]); self._t = m._step
-        self._load_flat_state(sd)
+        mine = {k: (int(off), tuple(int(x) for x in shape)) for k, (off, shape) in m._layout.items()}
+        saved = sd.get("layout")
+        if saved is None:                                   # version 1: no layout recorded -- only safe when nothing else can differ
+            for v in self._flat_state().values():
+                for k, t in sd.items():
+                    if torch.is_tensor(t) and t.numel() != v.numel():
+                        raise _lib.MMDAError("flat optimizer state of another size (and without a layout map): cannot be loaded")
+            return self._load_flat_state(sd)
+        theirs = {k: (int(off), tuple(shape)) for k, off, shape in saved}
+        if theirs == mine:
+            return self._load_flat_state(sd)
+        if set(theirs) != set(mine) or any(theirs[k][1] != mine[k][1] for k in mine):
+            raise _lib.MMDAError("flat optimizer state belongs to a model with other parameters / shapes")
+        # same parameters, another bucket order: move every tensor's moments to its offset here
+        remapped = {}
+        for name, img in sd.items():
+            if not torch.is_tensor(img) or name not in self._flat_state():
+                continue
+            out = torch.zeros_like(img)
+            for k, (off, shape) in mine.items():
+                n = 1
+                for x in shape:
+                    n *= x
+                o2 = theirs[k][0]
+                out[off:off + n] = img[o2:o2 + n]
+            remapped[name] = out
+        self._load_flat_state(dict(sd, **remapped))
+
+    def _load_torch_state(self, sd, m):
+        names = [k for k, _ in m.named_parameters()]
+        params = [p for g in self.param_groups for p in g["params"]]
+        if len(sd.get("param_groups", [{}])[0].get("params", [])) != len(params):
+            raise _lib.MMDAError("torch-format optimizer state with another number of parameters")
+        by_id = {id(p): k for k, p in m.named_parameters()}
+        flat = self._flat_state()
+        keymap = {"exp_avg": "exp_avg", "exp_avg_sq": "exp_avg_sq", "square_avg": "square_avg"}
+        step = 0
+        for idx, p in zip(sd["param_groups"][0]["params"], params):
+            st = sd["state"].get(idx)
+            if not st:
+                continue
+            off, shape = m._layout[by_id[id(p)]]
+            for src, dst in keymap.items():
+                if src in st and dst in flat:
+                    flat[dst][off:off + p.numel()].copy_(st[src].reshape(-1).to(flat[dst].device))
+            step = max(step, int(st.get("step", 0)))
+        for g, saved in zip(self.param_groups, sd["param_groups"]):
+            g.update({k: v for k, v in saved.items() if k != "params"})
+        m._step = step; self._t = step
+        del names
 
 
 class Adam(_FlatOptimizer):

@@ -206,3 +206,49 @@ def test_written_but_unread_attributes_are_materialisable():
         assert got.shape == (5, 4)
         assert float((got - (x @ W.t() + bias)).abs().max()) < 1e-5, name
     assert float((m.utt_t.cpu() - (o.utt_private_t + o.utt_shared_t)).abs().max()) < 1e-5
+
+
+def test_flat_optimizer_checkpoint_carries_its_layout_and_takes_torch_states(monkeypatch):
+    """checkpoints/optim_{name}.std (solver.py:220) of the attached fused optimizer holds raw images of the moment buckets: the
+    (name, offset, shape) layout travels with them.  A checkpoint written under ANOTHER bucket order loads by name (not silently
+    wrong), one of another model raises, and a torch-format state -- what the reference itself writes -- is scattered into the flat
+    buckets by parameter order instead of being dropped."""
+    from mmda_amd import _lib
+    s, cfg, P0, train, _ = _solver(monkeypatch)
+    s.train_epoch()
+    sd = s.optimizer.state_dict()
+    assert sd["mmda_flat"] == 2 and len(sd["layout"]) == len(s.model._layout)
+    M0, V0 = (x.detach().cpu().clone() for x in s.model.flat_buckets()[2:])
+    # (1) the same state under a reversed bucket order
+    imgs = {k: torch.zeros_like(v) for k, v in sd.items() if torch.is_tensor(v)}
+    new_lay, off = [], 0
+    for name, o, shape in reversed(sd["layout"]):
+        n = int(np.prod(shape))
+        for k in imgs:
+            imgs[k][off:off + n] = sd[k][o:o + n]
+        new_lay.append([name, off, shape]); off += n
+    s2, _, _, _, _ = _solver(monkeypatch)
+    s2.model.train_step(*[train[0][k].to(DEV) if k != "l" else train[0][k] for k in ("t", "v", "a", "l", "emo")], lr=0.0, clip=1.0)
+    s2.optimizer.load_state_dict(dict(sd, layout=new_lay, **imgs))
+    M2, V2 = (x.detach().cpu() for x in s2.model.flat_buckets()[2:])
+    for name, (o, shape) in s2.model._layout.items():
+        n = int(np.prod(shape))
+        assert torch.equal(M2[o:o + n], M0[o:o + n]) and torch.equal(V2[o:o + n], V0[o:o + n]), name
+    assert s2.model._step == s.model._step
+    # (2) another model's parameters
+    with pytest.raises(_lib.MMDAError):
+        s2.optimizer.load_state_dict(dict(sd, layout=[[n + "_x", o, sh] for n, o, sh in sd["layout"]]))
+    # (3) a torch-format state: per-parameter exp_avg / exp_avg_sq in parameter order
+    params = [p for g in s2.optimizer.param_groups for p in g["params"]]
+    g = torch.Generator().manual_seed(3)
+    state = {i: {"step": torch.tensor(7.0), "exp_avg": torch.randn(p.shape, generator=g), "exp_avg_sq": torch.rand(p.shape, generator=g)}
+             for i, p in enumerate(params)}
+    tsd = {"state": state, "param_groups": [{"lr": 1e-4, "betas": (0.9, 0.999), "eps": 1e-8, "params": list(range(len(params)))}]}
+    s2.optimizer.load_state_dict(tsd)
+    M3, V3 = (x.detach().cpu() for x in s2.model.flat_buckets()[2:])
+    by_id = {id(p): k for k, p in s2.model.named_parameters()}
+    for i, p in enumerate(params):
+        o, shape = s2.model._layout[by_id[id(p)]]
+        assert torch.equal(M3[o:o + p.numel()], state[i]["exp_avg"].reshape(-1)), by_id[id(p)]
+        assert torch.equal(V3[o:o + p.numel()], state[i]["exp_avg_sq"].reshape(-1)), by_id[id(p)]
+    assert s2.model._step == 7
