@@ -142,8 +142,10 @@ def main():
     if rank == 0 and not os.environ.get("MMDA_BENCH_NO_KERNEL_TIMING"):
         # HIP events around the four recurrent launches of every 8th timed step (25 samples at the default 200 steps): the eight
         # event records cost ~35 us per step, which the metric should not carry on every step.  A short run (the driver's 20 steps)
-        # samples five of its steps, never every one.
-        stride = 8 if args.steps >= 64 else max(1, (args.steps + 4) // 5)
+        # samples four of its steps, never every one.
+        # A short run samples FOUR of its steps (four samples per launch).  (mmda_misa_timing_rotate spreads the same number of event
+        # pairs over more steps -- one launch per sampled step -- at the same total cost; off here.)
+        stride = 8 if args.steps >= 64 else max(1, -(-args.steps // 4))
         _lib.check(lib.mmda_misa_timing_stride(model._h, stride), "timing_stride")
         _lib.check(lib.mmda_misa_timing_begin(model._h, (args.steps + stride - 1) // stride), "timing_begin")
     barrier()

@@ -523,6 +523,9 @@ int mmda_misa_train_step(mmda_misa* m, const int64_t* t_ids, const float* v, con
 /* record the recurrent kernels' event pairs only on every stride-th step (default 1; set before mmda_misa_timing_begin, whose
  * max_steps then counts RECORDED steps): eight event records per step cost ~35 us of a 1.4 ms step */
 int mmda_misa_timing_stride(mmda_misa* m, int stride);
+/* on != 0: a sampled step brackets ONE of the four recurrent launches (they take turns): two event records (~9 us) instead of eight;
+ * mmda_misa_timing_collect then returns per-launch means over the steps that sampled that launch and, in *steps, the fewest samples behind a mean */
+int mmda_misa_timing_rotate(mmda_misa* m, int on);
 int mmda_misa_timing_begin(mmda_misa* m, int max_steps);
 int mmda_misa_timing_collect(mmda_misa* m, float mean_ms[4], int* steps);
 int mmda_misa_timing_end(mmda_misa* m);

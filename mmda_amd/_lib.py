@@ -210,6 +210,7 @@ SIGNATURES = {
     "mmda_misa_zero_act_grads": (_I, [_P, _P]),
     "mmda_misa_adam_step": (_I, [_P, _F, _F, _F, _I, _P]),
     "mmda_misa_timing_stride": (_I, [_P, _I]),
+    "mmda_misa_timing_rotate": (_I, [_P, _I]),
     "mmda_misa_timing_begin": (_I, [_P, _I]),
     "mmda_misa_timing_collect": (_I, [_P, C.POINTER(C.c_float * 4), C.POINTER(_I)]),
     "mmda_misa_timing_end": (_I, [_P]),

@@ -774,7 +774,11 @@ extern "C" int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, vo
   static const int dma_min_rows = getenv("MMDA_GEMM_DMA_MIN_ROWS") ? atoi(getenv("MMDA_GEMM_DMA_MIN_ROWS")) : 8192;
   int call_rows = 0;
   for (int i = 0; i < n; ++i) call_rows = max(call_rows, args[i].tn ? args[i].K : args[i].M);
-  const bool dma_call = dma_on && call_rows >= dma_min_rows;
+  // (experiment switch MMDA_GEMM_DMA_FWD=1: calls of forward products only -- nothing accumulates -- take the DMA class at any size)
+  static const int dma_fwd = getenv("MMDA_GEMM_DMA_FWD") ? atoi(getenv("MMDA_GEMM_DMA_FWD")) : 0;
+  bool fwd_only = n > 0;
+  for (int i = 0; i < n; ++i) fwd_only = fwd_only && !args[i].accumulate && !args[i].tn && !args[i].bias_grad;
+  const bool dma_call = dma_on && (call_rows >= dma_min_rows || (dma_fwd && fwd_only));
   static const int dma_tall = getenv("MMDA_GEMM_DMA_TALL") ? atoi(getenv("MMDA_GEMM_DMA_TALL")) : 1;
   static const int tall_stages = getenv("MMDA_GEMM_DMA_TALL_STAGES") ? atoi(getenv("MMDA_GEMM_DMA_TALL_STAGES")) : 3;
   auto class_of = [&](const mmda_gemm_bf16_args& a) {

@@ -110,6 +110,8 @@ struct mmda_misa {
   std::vector<hipEvent_t> ev;      // [step][slot][start/stop]
   int ev_steps = 0, ev_fwd = 0, ev_bwd = 0;
   int ev_stride = 1, ev_seen_f = 0, ev_seen_b = 0;   // record every ev_stride-th step (the event pairs cost ~35 us per step)
+  int ev_rotate = 0;                                 // 1: a sampled step brackets ONE of the four recurrent launches (sample index % 4): ~9 us
+  std::vector<char> ev_done;                         // (step, slot) was recorded
 };
 
 namespace {
@@ -410,7 +412,9 @@ void sk_launch(Ctx& c, const mmda_skinny_args* p, int n) {
 void ev_rec(mmda_misa* m, int step, int slot, int which, void* stream) {
   if (m->ev.empty() || step >= m->ev_steps) return;
   if ((slot < 2 ? m->ev_seen_f : m->ev_seen_b) % m->ev_stride) return;
+  if (m->ev_rotate && slot != (step & 3)) return;
   (void)hipEventRecord(m->ev[(step * 4 + slot) * 2 + which], (hipStream_t)stream);
+  if (which == 1 && (size_t)(step * 4 + slot) < m->ev_done.size()) m->ev_done[step * 4 + slot] = 1;
 }
 
 // Fork: work issued on the returned stream starts after everything already on `main_stream` and runs beside what follows
@@ -1724,6 +1728,12 @@ extern "C" int mmda_misa_timing_begin(mmda_misa* m, int max_steps) {
   for (auto& e : m->ev)
     if (hipEventCreate(&e) != hipSuccess) return MMDA_ELAUNCH;
   m->ev_steps = max_steps;
+  m->ev_done.assign((size_t)max_steps * 4, 0);
+  return MMDA_OK;
+}
+extern "C" int mmda_misa_timing_rotate(mmda_misa* m, int on) {
+  if (!m) return MMDA_EINVAL;
+  m->ev_rotate = on ? 1 : 0;
   return MMDA_OK;
 }
 extern "C" int mmda_misa_timing_collect(mmda_misa* m, float mean_ms[4], int* steps) {
@@ -1731,15 +1741,18 @@ extern "C" int mmda_misa_timing_collect(mmda_misa* m, float mean_ms[4], int* ste
   int n = m->ev_fwd < m->ev_bwd ? m->ev_fwd : m->ev_bwd;
   if (n > m->ev_steps) n = m->ev_steps;
   double acc[4] = {0, 0, 0, 0};
+  int cnt[4] = {0, 0, 0, 0};
   for (int s = 0; s < n; ++s)
     for (int k = 0; k < 4; ++k) {
+      if ((size_t)(s * 4 + k) >= m->ev_done.size() || !m->ev_done[s * 4 + k]) continue;      // (rotation: one launch per sampled step)
       float ms = 0.f;
       if (hipEventSynchronize(m->ev[(s * 4 + k) * 2 + 1]) != hipSuccess) return MMDA_ELAUNCH;
       if (hipEventElapsedTime(&ms, m->ev[(s * 4 + k) * 2], m->ev[(s * 4 + k) * 2 + 1]) != hipSuccess) return MMDA_ELAUNCH;
-      acc[k] += ms;
+      acc[k] += ms; cnt[k]++;
     }
-  for (int k = 0; k < 4; ++k) mean_ms[k] = n > 0 ? (float)(acc[k] / n) : 0.f;
-  if (steps) *steps = n;
+  int least = n;
+  for (int k = 0; k < 4; ++k) { mean_ms[k] = cnt[k] > 0 ? (float)(acc[k] / cnt[k]) : 0.f; least = cnt[k] < least ? cnt[k] : least; }
+  if (steps) *steps = least;                            // samples behind every mean (the least-sampled launch)
   return MMDA_OK;
 }
 

@@ -104,10 +104,12 @@ def test_convert_bf16_16_byte_form(rows, cols):
 
 
 @pytest.mark.parametrize("M,N,K", [(1600, 2400, 300), (1600, 1200, 300), (128, 128, 64), (33, 70, 35), (7, 12, 768), (1600, 140, 40),
-                                   (300, 128, 1600)])
+                                   (300, 128, 1600), (8320, 2400, 300), (8200, 600, 1100), (8200, 300, 2400)])
 def test_gemm_bf16_operands_nt_bias(M, N, K):
     """C = A B^T + b + b2 on bf16 K-major operands: exact against fp32 matmul of the same bf16-rounded values (up to fp32
-    summation order), so the bar is the fp32 one."""
+    summation order), so the bar is the fp32 one.  The shapes with >= 8192 rows take the LDS-DMA pipelined kernel (round 3): 128 x 128
+    tiles for the short-K forward shape, 256 x 128 tiles (K >= 1024) for the input-gradient shapes, rows / columns / depth off the
+    tile grid."""
     from mmda_amd import ops
     torch.manual_seed(4)
     A = torch.randn(M, K); W = torch.randn(N, K) / math.sqrt(K); b = torch.randn(N); b2 = torch.randn(N)
@@ -161,6 +163,28 @@ def test_gemm_bf16_tn_form_weight_gradient(M, N, K, lda, ldb, a0, b0):
     tol = 3e-5 * float(want.abs().max()) * max(1.0, (K / 1600) ** 0.5)
     assert float((out.cpu() - want).abs().max()) < tol, (M, N, K)
     assert float((bg.cpu() - Af.sum(0)).abs().max()) < 3e-5 * float(Af.sum(0).abs().max()) * max(1.0, (K / 1600) ** 0.5)
+
+
+def test_gemm_bf16_split_k_is_bitwise_reproducible():
+    """Split-K combines through per-slice slabs summed in slice order by a reduce launch (splitk.hip), not through float atomics: the
+    weight-gradient launch of an LSTM layer (tn form, bias-gradient column, accumulate; long K, few tiles -> split) twice on the same
+    inputs gives the same bits -- in the register-staged kernel (K = 1600) and in the LDS-DMA kernel (K = 12800)."""
+    from mmda_amd import ops
+    torch.manual_seed(77)
+    for K in (1600, 12800):
+        A = (torch.randn(K, 2400) * 0.5).to(torch.bfloat16).to(dev()); Bm = (torch.randn(K, 304) * 0.5).to(torch.bfloat16).to(dev())
+        H = (torch.randn(K, 600) * 0.5).to(torch.bfloat16).to(dev())
+        outs = []
+        for _ in range(2):
+            C = torch.ones(2400, 300, device=dev()); C2 = torch.ones(1200, 300, device=dev()); bg = torch.zeros(2400, device=dev())
+            ops.gemm_bf16_grouped([dict(A=A, B=Bm, M=2400, N=300, K=K, tn=True, out=C, accumulate=True, bias_grad=bg),
+                                   dict(A=A[:, 1200:], B=H[:, 300:], M=1200, N=300, K=K, tn=True, out=C2, accumulate=True)])
+            outs.append((C.clone(), C2.clone(), bg.clone()))
+        for x, y in zip(*outs):
+            assert torch.equal(x, y)
+        ref = 1 + A.float().t() @ Bm.float()[:, :300]
+        assert float((outs[0][0] - ref).abs().max()) < 3e-5 * float(ref.abs().max()) * max(1.0, (K / 1600) ** 0.5)
+        assert relerr(outs[0][2], A.float().sum(0)) < TOL["fp32"]
 
 
 def test_gemm_bf16_gate_interleave():
