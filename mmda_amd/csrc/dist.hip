@@ -15,11 +15,14 @@ namespace {
 
 constexpr int CHUNK = 64;          // run boundaries = segment boundaries U multiples of CHUNK in the sorted list
 
-__global__ void seg_keys_kernel(const int64_t* __restrict__ ids, int n, unsigned* keys, int* vals) {
+__global__ void seg_keys_kernel(const int64_t* __restrict__ ids, int n, unsigned* keys, int* vals, const int* __restrict__ lengths, int B) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   const int64_t id = ids[p];
-  keys[p] = id < 0 ? 0xFFFFFFFFu : (unsigned)id;      // negative ids (padding) sort to the end and are skipped
+  // negative ids (padding markers of the gathered lists) and, with `lengths`, the positions p = t * B + b past a sample's length
+  // (their rows are exactly zero) sort to the end and are skipped
+  const bool pad = id < 0 || (lengths != nullptr && (p / B) >= lengths[p % B]);
+  keys[p] = pad ? 0xFFFFFFFFu : (unsigned)id;
   vals[p] = p;
 }
 
@@ -91,7 +94,8 @@ extern "C" int64_t mmda_embed_segment_sum_work_bytes(int n, int D) {
   return (int64_t)seg_layout(n, D).total;
 }
 
-static int seg_sum(float* dW, const int64_t* ids, int n, int D, const float* rows, void* work, int64_t work_bytes, void* stream, int accumulate);
+static int seg_sum(float* dW, const int64_t* ids, int n, int D, const float* rows, void* work, int64_t work_bytes, void* stream, int accumulate,
+                   const int* lengths = nullptr, int B = 0);
 
 extern "C" int mmda_embed_segment_sum(float* dW, const int64_t* ids, int n, int D, const float* rows, void* work, int64_t work_bytes,
                                       void* stream) {
@@ -100,16 +104,17 @@ extern "C" int mmda_embed_segment_sum(float* dW, const int64_t* ids, int n, int 
 
 // dW[ids[p]] += rows[p] by the same machinery (stable sort, list-order sums), work buffer from the stream's scratch: what
 // mmda_embed_scatter_add runs for long lists, where its one-workgroup-per-position scan (O(n^2 / 256) id compares) loses
-int mmda_embed_scatter_sorted(float* dW, const int64_t* ids, int n, int D, const float* rows, void* stream) {
+int mmda_embed_scatter_sorted(float* dW, const int64_t* ids, int n, int D, const float* rows, const int* lengths, int B, void* stream) {
   if (n == 0) return MMDA_OK;
   const int64_t bytes = (int64_t)seg_layout(n, D).total;
   float* work = mmda_scratch_get((hipStream_t)stream, (size_t)bytes + 256);
   if (!work) return MMDA_ELAUNCH;
   void* w = (void*)(((uintptr_t)work + 255) & ~(uintptr_t)255);
-  return seg_sum(dW, ids, n, D, rows, w, bytes, stream, 1);
+  return seg_sum(dW, ids, n, D, rows, w, bytes, stream, 1, lengths, B);
 }
 
-static int seg_sum(float* dW, const int64_t* ids, int n, int D, const float* rows, void* work, int64_t work_bytes, void* stream, int accumulate) {
+static int seg_sum(float* dW, const int64_t* ids, int n, int D, const float* rows, void* work, int64_t work_bytes, void* stream, int accumulate,
+                   const int* lengths, int B) {
   if (!dW || !ids || !rows || !work || n < 0 || D <= 0) return MMDA_EINVAL;
   if (n == 0) return MMDA_OK;
   const SegLayout L = seg_layout(n, D);
@@ -119,7 +124,7 @@ static int seg_sum(float* dW, const int64_t* ids, int n, int D, const float* row
   unsigned* kin = (unsigned*)(w + L.keys_in); unsigned* kout = (unsigned*)(w + L.keys_out);
   int* vin = (int*)(w + L.vals_in); int* vout = (int*)(w + L.vals_out);
   float* part = (float*)(w + L.part);
-  hipLaunchKernelGGL(seg_keys_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, ids, n, kin, vin);
+  hipLaunchKernelGGL(seg_keys_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, ids, n, kin, vin, lengths, B);
   MMDA_CHECK_LAUNCH("mmda_embed_segment_sum/keys");
   size_t cb = L.cub_bytes;
   // LSD radix sort: stable, so equal ids keep their list order (the order every rank sums them in)

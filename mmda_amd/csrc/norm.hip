@@ -5,7 +5,7 @@
 #include "rowlocal.h"
 #include "splitk.h"
 
-int mmda_embed_scatter_sorted(float* dW, const int64_t* ids, int n, int D, const float* rows, void* stream);   // dist.hip
+int mmda_embed_scatter_sorted(float* dW, const int64_t* ids, int n, int D, const float* rows, const int* lengths, int B, void* stream);   // dist.hip
 int mmda_embed_scatter_add_masked(float* dW, const int64_t* ids, int rows, int dim, const float* dX, const int* lengths, int B, void* stream);
 
 namespace {
@@ -670,7 +670,7 @@ int mmda_embed_scatter_add_masked(float* dW, const int64_t* ids, int rows, int d
   if (rows == 0) return MMDA_OK;
   static const int sort_min_env = getenv("MMDA_SCATTER_SORT_MIN") ? atoi(getenv("MMDA_SCATTER_SORT_MIN")) : 3072;
   const int sort_min = sort_min_env > ES_MAX ? ES_MAX + 1 : sort_min_env;
-  if (rows >= sort_min) return mmda_embed_scatter_sorted(dW, ids, rows, dim, dX, stream);
+  if (rows >= sort_min) return mmda_embed_scatter_sorted(dW, ids, rows, dim, dX, lengths, B, stream);
   hipLaunchKernelGGL(embed_scatter_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, dW, ids, rows, dim, dX, lengths, B);
   MMDA_CHECK_LAUNCH("mmda_embed_scatter_add");
   return MMDA_OK;
