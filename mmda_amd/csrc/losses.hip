@@ -618,13 +618,28 @@ __global__ __launch_bounds__(1024) void cmd_stream_kernel(const float* __restric
   const int cc = min(c, D - 1);
   const bool c_ok = c < D;
   const float invB = 1.f / B;
+  // Every pass walks the rows in blocks of 64 (eight per thread) with the loads of ALL tensors of a block in flight together: the
+  // inputs sit in L2, a pass is a chain of load latencies, and one tensor at a time at eight loads deep took 54 us at B = 256.  (The
+  // additions of a tensor still run in row order: the same bits as before.)
+  auto rows8 = [&](int r0, float (&v)[3][8]) {
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    float s = 0.f;
-    if (t < pl.nt && c_ok)
-#pragma unroll 8
-      for (int r = rg; r < B; r += 8) s += x[(int64_t)t * stride + (int64_t)r * D + cc];
-    P1[(rg * 3 + t) * 128 + c] = s;
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        v[t][j] = x[(int64_t)(t < pl.nt ? t : 0) * stride + (int64_t)min(r0 + 8 * j, B - 1) * D + cc];      // (clamped: no load under a branch)
+  };
+  {
+    float s[3] = {0.f, 0.f, 0.f};
+    for (int r0 = rg; r0 < B; r0 += 64) {
+      float v[3][8];
+      rows8(r0, v);
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[t] += (r0 + 8 * j < B && t < pl.nt && c_ok) ? v[t][j] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) P1[(rg * 3 + t) * 128 + c] = s[t];
   }
   __syncthreads();
   float mom[3][5];
@@ -635,18 +650,28 @@ __global__ __launch_bounds__(1024) void cmd_stream_kernel(const float* __restric
     for (int g = 0; g < 8; ++g) s += P1[(g * 3 + t) * 128 + c];
     mom[t][0] = s * invB;
   }
+  {
+    float q[3][4];
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    float q2 = 0.f, q3 = 0.f, q4 = 0.f, q5 = 0.f;
-    if (t < pl.nt && c_ok)
-#pragma unroll 8
-      for (int r = rg; r < B; r += 8) {
-        const float d = x[(int64_t)t * stride + (int64_t)r * D + cc] - mom[t][0];
-        const float d2 = d * d;
-        q2 += d2; q3 += d2 * d; q4 += d2 * d2; q5 += d2 * d2 * d;
-      }
-    P2[((rg * 3 + t) * 4 + 0) * 128 + c] = q2; P2[((rg * 3 + t) * 4 + 1) * 128 + c] = q3;
-    P2[((rg * 3 + t) * 4 + 2) * 128 + c] = q4; P2[((rg * 3 + t) * 4 + 3) * 128 + c] = q5;
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) q[t][k] = 0.f;
+    for (int r0 = rg; r0 < B; r0 += 64) {
+      float v[3][8];
+      rows8(r0, v);
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float d = (r0 + 8 * j < B && t < pl.nt && c_ok) ? v[t][j] - mom[t][0] : 0.f;
+          const float d2 = d * d;
+          q[t][0] += d2; q[t][1] += d2 * d; q[t][2] += d2 * d2; q[t][3] += d2 * d2 * d;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) P2[((rg * 3 + t) * 4 + k) * 128 + c] = q[t][k];
   }
   __syncthreads();
 #pragma unroll
@@ -704,18 +729,25 @@ __global__ __launch_bounds__(1024) void cmd_stream_kernel(const float* __restric
       }
     }
   const float gs = scale * vscale / B;
+  for (int r0 = rg; r0 < B; r0 += 64) {
+    float v[3][8], old[3][8];
+    rows8(r0, v);
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    if (!(t < pl.nt && c_ok)) continue;
-#pragma unroll 8
-    for (int r = rg; r < B; r += 8) {
-      const int64_t o = (int64_t)t * stride + (int64_t)r * D + c;
-      const float d = x[o] - mom[t][0];
-      const float d2 = d * d;
-      const float g = U[t][0] + U[t][1] * 2.f * d + U[t][2] * 3.f * (d2 - mom[t][1]) + U[t][3] * 4.f * (d2 * d - mom[t][2]) +
-                      U[t][4] * 5.f * (d2 * d2 - mom[t][3]);
-      dx[o] += gs * g;
-    }
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        old[t][j] = dx[(int64_t)(t < pl.nt ? t : 0) * stride + (int64_t)min(r0 + 8 * j, B - 1) * D + cc];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (!(r0 + 8 * j < B && t < pl.nt && c_ok)) continue;
+        const float d = v[t][j] - mom[t][0];
+        const float d2 = d * d;
+        const float g = U[t][0] + U[t][1] * 2.f * d + U[t][2] * 3.f * (d2 - mom[t][1]) + U[t][3] * 4.f * (d2 * d - mom[t][2]) +
+                        U[t][4] * 5.f * (d2 * d2 - mom[t][3]);
+        dx[(int64_t)t * stride + (int64_t)(r0 + 8 * j) * D + c] = old[t][j] + gs * g;
+      }
   }
 }
 
