@@ -824,6 +824,7 @@ extern "C" int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, vo
     int64_t work2 = 0;                                    // class 2: k-tiles of the whole launch
     for (int i : order) work2 += (int64_t)tiles_of(args[i], T) * ceil_div(args[i].K, TK);
     // pass 1: the split of every problem on its own
+    static const int split_min_nk = getenv("MMDA_GEMM_SPLIT_MIN_NK") ? atoi(getenv("MMDA_GEMM_SPLIT_MIN_NK")) : 128;
     for (int i : order) {
       const mmda_gemm_bf16_args& a = args[i];
       const int tiles = tiles_of(a, T);
@@ -842,22 +843,25 @@ extern "C" int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, vo
         while (sk > 1 && sk * out_mb > 32.0) --sk;
         if (sk > 32) sk = 32;
         if (sk < 1) sk = 1;
-      } else if (tiles < 256 && nk >= 8) {
-        // split-K combines through slabs (one fp32 partial tile per slice, written once and read once by the reduce launch): split
-        // only while the added bytes stay small (<= 6 MB) and every slice keeps >= 4 k-tiles
+      } else if (tiles < 1024 && nk >= 128) {
+        // Register-staged classes: split only a very long k-walk (K >= 8192: the small-modality weight gradients of a large batch, a
+        // handful of tiles walking T * B rows) on fewer workgroups than the chip holds; every k-tile is one memory latency, so the walk
+        // is cut until the slots are full.  Below that nothing is split any more: with the slices combined through slabs and a reduce
+        // launch (round 3) instead of float atomics, a split costs the MOSEI-sized problems more than its parallelism returns --
+        // measured, alternating runs (step, ms; split / no split): B=16 0.621 / 0.612, B=32 0.665 / 0.652, B=64 0.846 / 0.842,
+        // B=128 1.206 / 1.196.  MMDA_GEMM_SPLIT_MIN_NK moves the limit (8: round 2's policy).
+        static const int long_k = getenv("MMDA_GEMM_LONGK_SPLIT") ? atoi(getenv("MMDA_GEMM_LONGK_SPLIT")) : 1;
+        sk = long_k ? ceil_div(1024, tiles) : 1;
+        while (sk > 1 && (nk / sk < 16 || sk * out_mb > 24.0)) --sk;
+      } else if (split_min_nk < 128 && tiles < 256 && nk >= split_min_nk) {
         sk = ceil_div(512, tiles);
         if (sk > nk / 4) sk = nk / 4;
         while (sk > 1 && sk * out_mb > 6.0) --sk;
         if (sk > 16) sk = 16;
         if (sk < 1) sk = 1;
-      } else if (tiles < 1024 && nk >= 64) {
-        // a long k-walk (the weight-gradient GEMMs of a large batch: K = T * B) on fewer workgroups than the chip holds (four per CU):
-        // every k-tile is one memory latency, so the walk is cut until the slots are full -- while the combine stays a small
-        // part of the walk it shortens
-        static const int long_k = getenv("MMDA_GEMM_LONGK_SPLIT") ? atoi(getenv("MMDA_GEMM_LONGK_SPLIT")) : 1;
-        sk = long_k ? ceil_div(1024, tiles) : 1;
-        while (sk > 1 && (nk / sk < 16 || sk * out_mb > 24.0)) --sk;
       }
+      static const int max_split = getenv("MMDA_GEMM_MAX_SPLIT") ? atoi(getenv("MMDA_GEMM_MAX_SPLIT")) : 0;      // experiment switch
+      if (max_split > 0 && sk > max_split) sk = max_split;
       // a fresh (non-accumulated) output gains from a split only with a long K loop in a launch that would otherwise leave the chip
       // underfilled
       if (sk > 1 && !a.accumulate && (crowded || nk < 16)) sk = 1;

@@ -1048,7 +1048,9 @@ extern "C" int mmda_loss_misc(const float* scores, const float* tcp, const float
   a.conf_grads = conf_grads && d_scores && d_tcp; a.conf_scale = conf_scale; a.with_conf = with_conf;
   a.recon = recon; a.orig = orig; a.n_recon = n_recon; a.recon_inv_n = 1.0f / (float)n_recon; a.recon_scale = recon_scale;
   a.d_recon = d_recon; a.d_orig = d_orig; a.L = L; a.dw = diff_w; a.sw = sim_w; a.rw = recon_w; a.cw = conf_w; a.use_conf = use_conf;
-  int rb = (int)((n_recon + 255) / 256); if (rb > 64) rb = 64;
+  // (eight elements per thread at least: the last workgroup adds the partials one after the other, and 3 x 32 x 128 elements do not
+  //  need 64 of them)
+  int rb = (int)((n_recon + 2047) / 2048); if (rb > 64) rb = 64; if (rb < 1) rb = 1;
   a.recon_blocks = rb;
   const int blocks = 1 + (with_conf ? ncls : 0) + rb;
   a.parts = mmda_scratch_get((hipStream_t)stream, sizeof(float) * blocks);
