@@ -1033,11 +1033,25 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(CLaunch L) {
 // producer, sums them in fp32 straight in fragment order and runs the lane-local cell backward: no workgroup barrier, no
 // LDS staging of gathered data, no transposition on the consumer side.
 // HDH / D16: compile-time knowledge of "d_hseq is given" (layer 1) and "dG leaves as bf16 only" (0 / 1; 2 = decided at run time)
-template <int NTM, bool GM, int CELL, bool DBG, int HDH = 2, int D16 = 2>
+// PAIR = 1 (four waves per block, large batches): the two waves of a block that share an m-tile -- hidden tiles 2q and 2q + 1 -- add
+// their partial dh tiles in LDS before anything leaves the CU: wave 2q keeps the even consumer tiles, wave 2q + 1 the odd ones, each
+// hands the other half of its fp32 accumulators over through 10 KB of LDS (16-byte writes, an epoch word, a bounded spin), adds the
+// partner's half and publishes ONE bf16 partial per (consumer tile, producer PAIR).  The exchange image then holds (nHT + 1) / 2
+// producers per consumer: half the publish stores and half the gather loads per wave and step.  At B = 256 four waves share a CU's
+// address unit and a step is paced by its ~45 vector-memory instructions per wave (4.5 us per step against the forward kernel's
+// 2.75 at 26): this takes 19 + 19 of them down to 10 + 10.  (A hidden tile without a partner -- the last of an odd count -- keeps
+// and publishes everything itself, as pair nHT / 2.)
+template <int NTM, bool GM, int CELL, bool DBG, int HDH = 2, int D16 = 2, int PAIR = 0>
 __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __builtin_amdgcn_s_setprio(3);
   const int role = L.blk2role[blockIdx.x];
+  // PAIR: LDS = [4 x 2 KB wave-private dG tiles | 4 x 10 KB hand-over regions | 4 epoch words]
+  volatile unsigned* lflag = reinterpret_cast<volatile unsigned*>(smem + 4 * 2048 + 4 * 10240);
+  if (PAIR) {
+    if ((threadIdx.x & 63) == 0) lflag[threadIdx.x >> 6] = L.epoch_base;      // (LDS is not cleared between launches)
+    __syncthreads();                                     // every wave of the block passes here, also the ones that leave below
+  }
   if (role < 0) return;
   Where wh;
   wh.di = 0;
@@ -1065,6 +1079,12 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
   const unsigned G4 = 4u * H;
   constexpr bool gm = GM;
   unsigned short* Tr = reinterpret_cast<unsigned short*>(smem) + wave * 1024;     // 16 x 64 bf16, wave-private
+  // producer index of this wave in the exchange image, and the number of producers a consumer gathers from
+  const int hp = PAIR ? (ht >> 1) : ht;
+  const int nP = PAIR ? (nHT + 1) / 2 : nHT;
+  const bool has_partner = PAIR && ((ht ^ 1) < nHT);     // (wpb == 4: the partner is wave ^ 2 of this block)
+  f32x4* xmine = reinterpret_cast<f32x4*>(smem + 4 * 2048 + wave * 10240) + lane;              // + slot * 64
+  const f32x4* xpart = reinterpret_cast<const f32x4*>(smem + 4 * 2048 + (wave ^ 2) * 10240) + lane;
 
   unsigned char* abort_w = D.xchg;
   unsigned char* flags = D.xchg + xchg_flags_off() + ((size_t)(dir * ngt + wh.grp) * NC) * FLAG_STRIDE;
@@ -1197,9 +1217,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
   const unsigned img_b = (unsigned)(nHT * 2) * RS;
   const __amdgpu_buffer_rsrc_t xr = make_rsrc(Xb, slot_b + img_b);
   const unsigned gat_base = (unsigned)(ht * 2 + mt) * RS + (unsigned)lane * 8u;          // + producer * 512
-  const unsigned pub_base = (unsigned)mt * RS + (unsigned)(ht * 64 + lane) * 8u;         // + consumer tile nt * pub_stride
+  const unsigned pub_base = (unsigned)mt * RS + (unsigned)(hp * 64 + lane) * 8u;         // + consumer tile nt * pub_stride
   const unsigned gat_base2 = (unsigned)(ht * 2 + mt) * RS + (unsigned)lane * 16u;        // + producer pair * 1024
-  const unsigned pub_base2 = (unsigned)mt * RS + (unsigned)(ht >> 1) * 1024u + (unsigned)lane * 16u + (unsigned)(ht & 1) * 8u;
+  const unsigned pub_base2 = (unsigned)mt * RS + (unsigned)(hp >> 1) * 1024u + (unsigned)lane * 16u + (unsigned)(hp & 1) * 8u;
   const unsigned pub_stride = 2u * RS;
   bool paired = false;                                  // arrangement of the image the NEXT gather reads (= what the last publish used)
 
@@ -1236,9 +1256,14 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
   // 1, before and while the placement is being checked --, 1 = XCD-local and paired for sure, 2 = write-through and unpaired for sure)
   // are compile-time tags: the steady-state steps carry no step-number or form branches (each one, taken or not, splits the wave's
   // instruction schedule; see the forward kernel).
-  auto do_step = [&](int step, auto first_tag, auto fm_tag) {
+  // ROLE (PAIR kernels; compile-time: the accumulators a wave keeps are static registers): 0 = even tile of a pair (keeps the even
+  // consumer tiles), 1 = odd tile (keeps the odd ones), 2 = no partner (keeps everything; also every wave of a PAIR = 0 kernel)
+  auto do_step = [&](int step, auto first_tag, auto fm_tag, auto role_tag) {
     constexpr bool FIRST = decltype(first_tag)::value;
     constexpr int FM = decltype(fm_tag)::value;
+    constexpr int ROLE = decltype(role_tag)::value;
+    constexpr int NGQ = PAIR ? NTM / 4 : NTM / 2;        // 16-byte gather loads (two producers each)
+    constexpr int NGP = PAIR ? NTM / 2 : NTM;            // 8-byte gather loads (one producer each)
     const unsigned epoch = L.epoch_base + (unsigned)step + 1u;
     float dh_rec[4] = {0.f, 0.f, 0.f, 0.f};
     if (!FIRST) {
@@ -1249,16 +1274,16 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
       STAMP(0);
       const unsigned par = (need & 1u) * slot_b;
       if (FM == 0 ? paired : FM == 1) {                  // wave-uniform (compile-time in the steady state)
-        u32x4 gq[NTM / 2];
+        u32x4 gq[NGQ];
 #pragma unroll
-        for (int q = 0; q < NTM / 2; ++q)
-          gq[q] = __builtin_amdgcn_raw_buffer_load_b128(xr, gat_base2 + (2 * q < nHT ? par + (unsigned)q * 1024u : FAR), 0, 16);
+        for (int q = 0; q < NGQ; ++q)
+          gq[q] = __builtin_amdgcn_raw_buffer_load_b128(xr, gat_base2 + (2 * q < nP ? par + (unsigned)q * 1024u : FAR), 0, 16);
         flush(step - 1);
         load_raw(step + 1);                              // consumed by derive() at the end of this step
         STAMP(1);
 #pragma unroll
-        for (int q = 0; q < NTM / 2; ++q) {              // same summation order as the unpaired form: producer 2q, then 2q + 1
-          const bool two = 2 * q + 1 < nHT;              // the upper half of an odd count's last pair was written by nobody
+        for (int q = 0; q < NGQ; ++q) {                  // same summation order as the unpaired form: producer 2q, then 2q + 1
+          const bool two = 2 * q + 1 < nP;               // the upper half of an odd count's last pair was written by nobody
           const unsigned b0 = two ? gq[q][2] : 0u, b1 = two ? gq[q][3] : 0u;
           dh_rec[0] += __builtin_bit_cast(float, gq[q][0] << 16);
           dh_rec[1] += __builtin_bit_cast(float, gq[q][0] & 0xffff0000u);
@@ -1270,15 +1295,15 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
           dh_rec[3] += __builtin_bit_cast(float, b1 & 0xffff0000u);
         }
       } else {
-        u32x2 gv[NTM];
+        u32x2 gv[NGP];
 #pragma unroll
-        for (int p = 0; p < NTM; ++p)
-          gv[p] = __builtin_amdgcn_raw_buffer_load_b64(xr, gat_base + (p < nHT ? par + (unsigned)p * 512u : FAR), 0, 16);
+        for (int p = 0; p < NGP; ++p)
+          gv[p] = __builtin_amdgcn_raw_buffer_load_b64(xr, gat_base + (p < nP ? par + (unsigned)p * 512u : FAR), 0, 16);
         flush(step - 1);
         load_raw(step + 1);                              // consumed by derive() at the end of this step
         STAMP(1);
 #pragma unroll
-        for (int p = 0; p < NTM; ++p) {
+        for (int p = 0; p < NGP; ++p) {
           dh_rec[0] += __builtin_bit_cast(float, gv[p][0] << 16);
           dh_rec[1] += __builtin_bit_cast(float, gv[p][0] & 0xffff0000u);
           dh_rec[2] += __builtin_bit_cast(float, gv[p][1] << 16);
@@ -1330,19 +1355,41 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
 #pragma unroll
       for (int nt = 0; nt < NTM; ++nt) accs[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wreg[nt][1], accs[nt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+      if (PAIR && ROLE < 2) {
+        // hand the partner the tiles IT keeps (consumer tiles of the other parity), take its half of mine: fp32, through LDS
+#pragma unroll
+        for (int j = 0; j < NTM / 2; ++j) xmine[j * 64] = accs[2 * j + (1 - ROLE)];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) lflag[wave] = epoch;
+        bool got = false;
+        for (unsigned spins = 0; spins < (SPIN_LIMIT << 2); ++spins) {
+          if ((int)(lflag[wave ^ 2] - epoch) >= 0) { got = true; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (!got) { alive = false; if (lane == 0) st_flag(abort_w, 1u); return; }
+#pragma unroll
+        for (int j = 0; j < NTM / 2; ++j) accs[2 * j + ROLE] += xpart[j * 64];
+      }
       // the tile-dependent part of the offset is wave-uniform (scalar select, one vector add); tiles past nHT go out of range
       const bool fst = FM == 0 ? fast : FM == 1;
+      constexpr int NPUB = (PAIR && ROLE < 2) ? NTM / 2 : NTM;       // tiles this wave publishes: its parity's, or all
       if (fst) {
 #pragma unroll
-        for (int nt = 0; nt < NTM; ++nt) {
-          const u32x2 pk = {pack_bf16x2(accs[nt][0], accs[nt][1]), pack_bf16x2(accs[nt][2], accs[nt][3])};
+        for (int j = 0; j < NPUB; ++j) {
+          constexpr int dummy = 0; (void)dummy;
+          const int nt = (PAIR && ROLE < 2) ? 2 * j + ROLE : j;
+          const f32x4 av = accs[(PAIR && ROLE < 2) ? 2 * j + ROLE : j];
+          const u32x2 pk = {pack_bf16x2(av[0], av[1]), pack_bf16x2(av[2], av[3])};
           const unsigned so = nt < nHT ? par + (unsigned)nt * pub_stride : FAR;
           __builtin_amdgcn_raw_buffer_store_b64(pk, xr, pub_base2 + so, 0, 0);
         }
       } else {
 #pragma unroll
-        for (int nt = 0; nt < NTM; ++nt) {
-          const u32x2 pk = {pack_bf16x2(accs[nt][0], accs[nt][1]), pack_bf16x2(accs[nt][2], accs[nt][3])};
+        for (int j = 0; j < NPUB; ++j) {
+          const int nt = (PAIR && ROLE < 2) ? 2 * j + ROLE : j;
+          const f32x4 av = accs[(PAIR && ROLE < 2) ? 2 * j + ROLE : j];
+          const u32x2 pk = {pack_bf16x2(av[0], av[1]), pack_bf16x2(av[2], av[3])};
           const unsigned so = nt < nHT ? par + (unsigned)nt * pub_stride : FAR;
           __builtin_amdgcn_raw_buffer_store_b64(pk, xr, pub_base + so, 0, 16);
         }
@@ -1363,10 +1410,19 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_wave_kernel(CLaunch L) {
     typedef std::integral_constant<int, 0> FmVar;
     typedef std::integral_constant<int, 1> FmLocal;
     typedef std::integral_constant<int, 2> FmThrough;
-    if (T > 0) { do_step(0, TrueT{}, FmVar{}); step = 1; }
-    if (T > 1 && alive) { do_step(1, FalseT{}, FmVar{}); step = 2; }
-    if (fast) { for (; step < T && alive; ++step) do_step(step, FalseT{}, FmLocal{}); }
-    else { for (; step < T && alive; ++step) do_step(step, FalseT{}, FmThrough{}); }
+    auto walk = [&](auto role_tag) {
+      if (T > 0) { do_step(0, TrueT{}, FmVar{}, role_tag); step = 1; }
+      if (T > 1 && alive) { do_step(1, FalseT{}, FmVar{}, role_tag); step = 2; }
+      if (fast) { for (; step < T && alive; ++step) do_step(step, FalseT{}, FmLocal{}, role_tag); }
+      else { for (; step < T && alive; ++step) do_step(step, FalseT{}, FmThrough{}, role_tag); }
+    };
+    if constexpr (PAIR != 0) {
+      if (!has_partner) walk(std::integral_constant<int, 2>{});      // wave-uniform
+      else if (ht & 1) walk(std::integral_constant<int, 1>{});
+      else walk(std::integral_constant<int, 0>{});
+    } else {
+      walk(std::integral_constant<int, 2>{});
+    }
     if (alive && T > 0) flush(T - 1);
   }
   if (DBG && L.dbg && tid == 0)
@@ -2273,7 +2329,12 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
     // members of a cluster must all be resident at once -- a launch that wants most of the 256 CUs keeps the small allocation, so
     // that its blocks can share CUs if something else (another process on the GPU) holds some.
     const bool reserve = wpb == 1 && grid_blocks <= 160;
-    const size_t lds_launch = fwd_wave ? (reserve ? (size_t)(lds_kb < 32 ? 32 : lds_kb > 160 ? 160 : lds_kb) * 1024 : (quad ? (size_t)QUAD_LDS : (size_t)4 * 2048)) : lds;
+    // backward, four waves per block (large batches): the two waves of an m-tile pre-reduce their partial dh tiles in LDS and publish
+    // one partial per producer PAIR (lstm_bwd_wave_kernel<..., PAIR = 1>): 4 x 2 KB + 4 x 10 KB + the epoch words.  MMDA_LSTM_PAIR=0: off.
+    static const int pair_on = getenv("MMDA_LSTM_PAIR") ? atoi(getenv("MMDA_LSTM_PAIR")) : 1;
+    const bool pair_bwd = pair_on && bwd && fwd_wave && !quad && wpb == 4 && L.gate_minor && !gru && g_dbg == nullptr;
+    const size_t lds_launch = fwd_wave ? (reserve ? (size_t)(lds_kb < 32 ? 32 : lds_kb > 160 ? 160 : lds_kb) * 1024
+                                                  : (quad ? (size_t)QUAD_LDS : (pair_bwd ? (size_t)(4 * 2048 + 4 * 10240 + 64) : (size_t)4 * 2048))) : lds;
     dim3 grid(grid_blocks), block(quad ? 256 : (fwd_wave ? 64 * wpb : 256));
     // the cycle stamps of tools/diag_lstm_phases.py live in a kernel instance of their own (gate-minor LSTM only): even a never-taken
     // branch per phase costs the production kernels scheduling freedom
@@ -2301,8 +2362,10 @@ int mmda_lstm_cluster_launch(int n, const mmda_lstm_desc* descs, int B, int T, c
              : dbgk ? (bwd ? lstm_bwd_wave_kernel<20, true, MMDA_CELL_LSTM, true> : lstm_fwd_wave_kernel<10, true, MMDA_CELL_LSTM, true>)          \
              : gru ? (bwd ? (L.gate_minor ? lstm_bwd_wave_kernel<20, true, MMDA_CELL_GRU, false> : lstm_bwd_wave_kernel<20, false, MMDA_CELL_GRU, false>) \
                           : (L.gate_minor ? lstm_fwd_wave_kernel<10, true, MMDA_CELL_GRU, false> : lstm_fwd_wave_kernel<10, false, MMDA_CELL_GRU, false>)) \
-             : bwd ? (fwd_wave ? (L.gate_minor ? (spec == 1 ? lstm_bwd_wave_kernel<20, true, MMDA_CELL_LSTM, false, 0, 1>                        \
-                                                 : spec == 2 ? lstm_bwd_wave_kernel<20, true, MMDA_CELL_LSTM, false, 1, 1>                        \
+             : bwd ? (fwd_wave ? (L.gate_minor ? (spec == 1 ? (pair_bwd ? lstm_bwd_wave_kernel<20, true, MMDA_CELL_LSTM, false, 0, 1, 1>          \
+                                                                        : lstm_bwd_wave_kernel<20, true, MMDA_CELL_LSTM, false, 0, 1>)            \
+                                                 : spec == 2 ? (pair_bwd ? lstm_bwd_wave_kernel<20, true, MMDA_CELL_LSTM, false, 1, 1, 1>         \
+                                                                        : lstm_bwd_wave_kernel<20, true, MMDA_CELL_LSTM, false, 1, 1>)            \
                                                              : lstm_bwd_wave_kernel<20, true, MMDA_CELL_LSTM, false>)                             \
                                                : lstm_bwd_wave_kernel<20, false, MMDA_CELL_LSTM, false>)                                           \
                     : bwd_regs ? (L.gate_minor ? lstm_bwd_cluster_kernel<10, true> : lstm_bwd_cluster_kernel<10, false>)                \

@@ -9,6 +9,8 @@ to bf16 (round-to-nearest-even, ``Tensor.bfloat16()``) at exactly the points the
             gates = pre[t] + bf16(h_{t-1}) . bf16(W_hh)^T               (lstm_cluster.hip / lstm.hip; h, c themselves stay fp32)
   backward  dG_t in fp32 from the fp32 stash, then                      (lstm_bwd_wave_kernel)
             dh_{t-1} = sum over 16-unit hidden tiles of bf16( bf16(dG_t)[tile's gate rows] . bf16(W_hh)[those rows] )
+                       (``tile_partials=32``: over 32-unit tile PAIRS -- the large-batch form of the kernel adds two tiles'
+                        fp32 products in LDS before it rounds)
                        -- every producer wave publishes its partial as bf16; ``tile_partials=False`` gives the streaming
                           kernel's single fp32 sum (lstm.hip)
             dX = bf16(dG) . bf16(W_ih);  dW_ih = bf16(dG)^T . bf16(x);  dW_hh = bf16(dG)^T . bf16(hseq shifted);
@@ -37,10 +39,13 @@ def _q(x: torch.Tensor, on: bool) -> torch.Tensor:
     return x.bfloat16().float() if on else x
 
 
-def _tile_partial_sum(dg: torch.Tensor, w_hh_q: torch.Tensor, ng: int, H: int, rounding: bool) -> torch.Tensor:
+def _tile_partial_sum(dg: torch.Tensor, w_hh_q: torch.Tensor, ng: int, H: int, rounding: bool, width: int = TILE) -> torch.Tensor:
     """dh = dG (B, ng*H) . W_hh (ng*H, H), summed the way lstm_bwd_wave_kernel sums it: the product over the gate rows of each
-    16-unit hidden tile is rounded to bf16 (the producer wave's published partial), the partials are added in fp32."""
+    16-unit hidden tile is rounded to bf16 (the producer wave's published partial), the partials are added in fp32.
+    width = 32: the PAIR form of the kernel (four waves per block, B > 128): two neighbouring 16-unit tiles add their fp32 products
+    in LDS before the rounding, so one bf16 partial covers 32 hidden units."""
     B = dg.shape[0]
+    TILE = width                                             # (shadows the module constant on purpose: same code, wider tiles)
     nt = (H + TILE - 1) // TILE
     Hp = nt * TILE
     d3 = dg.view(B, ng, H)
@@ -153,7 +158,7 @@ class _BiRnn(torch.autograd.Function):
                     dG[t] = torch.cat((di, df, dg_, do), 1)
                     dgq = _q(dG[t], rounding)
                     if tile_partials and rounding:
-                        dh_rec = _tile_partial_sum(dgq, wq, 4, H, True)
+                        dh_rec = _tile_partial_sum(dgq, wq, 4, H, True, TILE if tile_partials is True else int(tile_partials))
                     else:
                         dh_rec = dgq @ wq
                 else:
@@ -170,7 +175,7 @@ class _BiRnn(torch.autograd.Function):
                     # recurrent product: rows r, z of W_hh see d(pre_r), d(pre_z); rows n see dq
                     dgh = _q(torch.cat((dr, dz, dq), 1), rounding)
                     if tile_partials and rounding:
-                        dh_rec = _tile_partial_sum(dgh, wq, 3, H, True)
+                        dh_rec = _tile_partial_sum(dgh, wq, 3, H, True, TILE if tile_partials is True else int(tile_partials))
                     else:
                         dh_rec = dgh @ wq
             dGq = _q(dG, rounding).reshape(T * B, ng * H)

@@ -319,7 +319,9 @@ def test_c3_c4_shapes_bf16_match_the_emulating_oracle(name):
     L = model.read_losses()
     for k in ("cls", "diff", "sim", "recon", "conf", "total"):
         assert abs(L[k] - float(z["loss::" + k])) < 1e-2 * abs(float(z["loss::" + k])), k
-    oq, Lq, Gq = emu.loss_and_grads(P, cfg, batch, rounding=True, tile_partials=True)
+    # (B = 256 runs the PAIR form of the backward recurrence -- four waves per block, two hidden tiles' partial dh added in LDS before
+    #  the bf16 rounding: the oracle rounds per 32-unit pair there; LSTM text/acoustic/visual alike)
+    oq, Lq, Gq = emu.loss_and_grads(P, cfg, batch, rounding=True, tile_partials=32 if meta["B"] > 128 else True)
     assert rel(pub["scores"], oq.scores) < 1e-3
     model._assign_grad_views()
     for k, (l2, cos) in _grad_rel_l2(model, Gq, cfg, set(meta["none_grads"])).items():
