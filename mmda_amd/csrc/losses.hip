@@ -711,7 +711,7 @@ __global__ __launch_bounds__(1024) void cmd_stream_kernel(const float* __restric
       nrm[p][k] = sqrtf(N2[p * 5 + k] + N2[16 + p * 5 + k]);
       if (p < pl.np && k < nmom) total += nrm[p][k];
     }
-  if (tid == 0 && loss) atomicAdd(loss, total * vscale);
+  if (tid == 0 && loss && blockIdx.x == 0) atomicAdd(loss, total * vscale);      // (single adder: every workgroup holds the same total)
   if (!dx) return;
   float U[3][5];
 #pragma unroll
@@ -729,6 +729,35 @@ __global__ __launch_bounds__(1024) void cmd_stream_kernel(const float* __restric
       }
     }
   const float gs = scale * vscale / B;
+  if (gridDim.x > 1) {
+    // One workgroup per tensor (large batches): every workgroup walked the moments of all tensors -- a single workgroup pulls its
+    // inputs through ONE CU at ~45 GB/s, which made the whole kernel 57 us at B = 256 -- and now writes the gradient of its own.
+    const int t = blockIdx.x;
+    if (!(t < pl.nt && c_ok)) return;
+    float ut[5], mt[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      ut[k] = t == 0 ? U[0][k] : (t == 1 ? U[1][k] : U[2][k]);
+      mt[k] = t == 0 ? mom[0][k] : (t == 1 ? mom[1][k] : mom[2][k]);
+    }
+    for (int r0 = rg; r0 < B; r0 += 64) {
+      float v[8], old[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int64_t o = (int64_t)t * stride + (int64_t)min(r0 + 8 * j, B - 1) * D + cc;
+        v[j] = x[o]; old[j] = dx[o];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (r0 + 8 * j >= B) continue;
+        const float d = v[j] - mt[0];
+        const float d2 = d * d;
+        const float g = ut[0] + ut[1] * 2.f * d + ut[2] * 3.f * (d2 - mt[1]) + ut[3] * 4.f * (d2 * d - mt[2]) + ut[4] * 5.f * (d2 * d2 - mt[3]);
+        dx[(int64_t)t * stride + (int64_t)(r0 + 8 * j) * D + c] = old[j] + gs * g;
+      }
+    }
+    return;
+  }
   for (int r0 = rg; r0 < B; r0 += 64) {
     float v[3][8], old[3][8];
     rows8(r0, v);
@@ -999,7 +1028,7 @@ extern "C" int mmda_loss_cmd_pairs(const float* x, int64_t stride, int nt, int n
   }
   if (nt <= 3 && D <= 128) {
     const size_t lds_fast = sizeof(float) * (8 * 3 * 128 + 8 * 3 * 4 * 128 + 32);
-    hipLaunchKernelGGL(cmd_stream_kernel, dim3(1), dim3(1024), lds_fast, (hipStream_t)stream, x, stride, B, D, scale, value_scale, loss,
+    hipLaunchKernelGGL(cmd_stream_kernel, dim3(dx ? nt : 1), dim3(1024), lds_fast, (hipStream_t)stream, x, stride, B, D, scale, value_scale, loss,
                        dx, pl, n_moments);
     MMDA_CHECK_LAUNCH("mmda_loss_cmd");
     return MMDA_OK;
