@@ -181,7 +181,7 @@ typedef struct mmda_skinny_args {
 } mmda_skinny_args;
 int mmda_gemm_skinny(const mmda_skinny_args* args, int n, void* stream);
 
-/* fp32 transposes, up to 16 per launch: dst[c * ldd + r] = src[r * ld + c] for r < rows, c < cols. */
+/* fp32 transposes, up to 20 per launch: dst[c * ldd + r] = src[r * ld + c] for r < rows, c < cols. */
 typedef struct mmda_transpose_job { const float* src; int rows, cols, ld; float* dst; int ldd; } mmda_transpose_job;
 int mmda_transpose_f32(const mmda_transpose_job* jobs, int n, void* stream);
 
@@ -221,7 +221,7 @@ typedef struct mmda_ln_args {
   int permute_S, permute_B;                     /* 0,0 = no permutation */
   float eps;
   mmda_act_params actp;                         /* act = MMDA_ACT_PRELU / MMDA_ACT_RRELU only */
-  void* y_bf16; int ld_bf16;                    /* optional second output: y as bf16 (rows, ld_bf16), columns n..ld_bf16-1 zero -- the
+  void* y_bf16; int ld_bf16;                    /* optional second output (then y may be NULL): y as bf16 (rows, ld_bf16), columns n..ld_bf16-1 zero -- the
                                                  * K-major operand copy the next layer's input GEMM reads (no conversion launch between) */
 } mmda_ln_args;
 int mmda_layernorm_fwd(const mmda_ln_args* a, void* stream);
@@ -265,6 +265,11 @@ int mmda_lstm_pack_whh_multi(int mode, int n, const int* H, const float* const* 
  * and weights; as two launches on two streams they cost a fork and a cross-stream wait in front of the first recurrent kernel. */
 int mmda_lstm_pack_whh_and_convert(int n, const int* H, const float* const* whh, void* const* packed_fwd, void* const* packed_bwd,
                                    void* const* packed_c, const mmda_convert_job* jobs, int njobs, void* stream);
+/* ... and up to 20 fp32 transposes (mmda_transpose_f32) in the same launch: the K-major copies of the fusion block's weights that
+ * the backward pass reads depend on the weights only, and a launch of their own costs a stream 7 - 15 us for 6 MB of traffic. */
+int mmda_lstm_pack_convert_transpose(int n, const int* H, const float* const* whh, void* const* packed_fwd, void* const* packed_bwd,
+                                     void* const* packed_c, const mmda_convert_job* jobs, int njobs, const mmda_transpose_job* tjobs,
+                                     int ntjobs, void* stream);
 
 typedef struct mmda_lstm_desc {
   int H;

@@ -153,6 +153,8 @@ SIGNATURES = {
     "mmda_lstm_pack_whh_cluster": (_I, [_I, _P, _P, _P]),
     "mmda_lstm_pack_whh_and_convert": (_I, [_I, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                             C.POINTER(C.c_void_p), C.POINTER(ConvertJob), _I, _P]),
+    "mmda_lstm_pack_convert_transpose": (_I, [_I, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                              C.POINTER(C.c_void_p), C.POINTER(ConvertJob), _I, C.POINTER(TransposeJob), _I, _P]),
     "mmda_lstm_fwd": (_I, [_I, _I, C.POINTER(LstmDesc), _I, _I, _P, _P]),
     "mmda_lstm_bwd": (_I, [_I, _I, C.POINTER(LstmDesc), _I, _I, _P, _P]),
     "mmda_gru_pad_params": (_I, [C.POINTER(GruPadJob), _I, _P]),

@@ -49,6 +49,9 @@ struct FusedFwdA {
   float* ctx; float* probs; float p_tf; uint64_t seed; int site_attn;
   const float* out_w; const float* out_b; float* attn_out;        // (hs, hs), hs, (6 B, hs)
   mmda_ln_args ln1;               // rows = 6 B: x = x6, res = attn_out
+  // optional (training step): the reconstruction loss's gradient seeds, written where recon is produced instead of by the loss launch
+  // behind the forward pass -- d_recon = 2 (recon - orig) recon_g, d_orig = -d_recon (stores: the buffers need not be cleared)
+  const float* orig; float* d_recon; float* d_orig; float recon_inv_n, recon_scale;
 };
 // forward stretch C: hfused = LayerNorm 2 (x1 + dropout(f2)) permuted to (B, 6 hs) -> logits = hfused W_head^T + b -> heads
 struct FusedFwdC {
@@ -57,6 +60,8 @@ struct FusedFwdC {
   const float* ffn_parts; int n_parts; const float* b2; float* f2;      // optional: f2 = sum of the partials (slice order) + b2, first
   const float* hfused; const float* head_w; const float* head_b; float* logits;      // (B, 6 hs), (6 + ncls, 6 hs), 6 + ncls, (B, 6 + ncls)
   float threshold; float* tcp; float* scores; float* labels; float p_cls; uint64_t seed; int site_cls;
+  // optional (training step): the classification loss's gradient seed d_scores = (s - y) / max(s (1 - s), 1e-12) / B, stored here
+  const float* emo; float* d_scores;
 };
 // The feed-forward pair of the transformer layer (linear1 hs -> F with relu + dropout, linear2 F -> hs) as ONE launch per direction,
 // split over the HIDDEN units: workgroup (row block, slice j) takes S of the F hidden units of 192 rows through both products -- it needs

@@ -332,7 +332,17 @@ __global__ __launch_bounds__(FR_THREADS) void fused_fwd_a_kernel(FusedFwdA P) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = 4 * g + i;
-      if (r < nmod) P.recon[((int64_t)(r / nb) * B + b0 + (r % nb)) * hs + col] = acc[i] + P.rec_b[(r / nb) * hs + col];
+      if (r < nmod) {
+        const int64_t o = ((int64_t)(r / nb) * B + b0 + (r % nb)) * hs + col;
+        const float rv = acc[i] + P.rec_b[(r / nb) * hs + col];
+        P.recon[o] = rv;
+        if (P.d_recon) {                                                // (the expression of misc_losses_kernel, losses.hip)
+          const float d = rv - P.orig[o];
+          const float gr = 2.f * d * P.recon_inv_n * P.recon_scale;
+          P.d_recon[o] = gr;
+          P.d_orig[o] = 0.f - gr;
+        }
+      }
     }
   }
   // ---- qkv = x6 W_in^T + b_in: token-row tile, 3 hs = 384 output columns = three passes of the eight waves
@@ -415,6 +425,10 @@ __global__ __launch_bounds__(FR_THREADS) void fused_fwd_c_kernel(FusedFwdC P) {
         const float sc = sigmoidf_(z * drop_mul(P.p_cls, P.seed, P.site_cls, (uint64_t)(b * P.ncls + k)));
         P.scores[b * P.ncls + k] = sc;
         P.labels[b * P.ncls + k] = sc > P.threshold ? 1.f : 0.f;
+        if (P.d_scores) {                                               // (the expression of misc_losses_kernel, losses.hip)
+          const float yv = P.emo[b * P.ncls + k];
+          P.d_scores[b * P.ncls + k] = (sc - yv) / fmaxf(sc * (1.f - sc), 1e-12f) / B;
+        }
       }
     }
   }
@@ -566,13 +580,14 @@ int mmda_fused_ffn_bwd(const FusedFfnBwd* a, void* stream) {
 
 int mmda_fused_fwd_a(const FusedFwdA* a, void* stream) {
   if (!a || a->B <= 0 || a->nb <= 0 || a->nb > 2 || a->hs != 128 || a->nhead != 2 || a->ln1.n != 128) return MMDA_EINVAL;
+  if (a->d_recon && (!a->orig || !a->d_orig)) return MMDA_EINVAL;
   hipLaunchKernelGGL(fused_fwd_a_kernel, dim3(ceil_div(a->B, a->nb)), dim3(FR_THREADS), 0, (hipStream_t)stream, *a);
   MMDA_CHECK_LAUNCH("mmda_fused_fwd_a");
   return MMDA_OK;
 }
 
 int mmda_fused_fwd_c(const FusedFwdC* a, void* stream) {
-  if (!a || a->B <= 0 || a->nb <= 0 || a->hs != 128 || a->ln2.n != 128) return MMDA_EINVAL;
+  if (!a || a->B <= 0 || a->nb <= 0 || a->hs != 128 || a->ln2.n != 128 || (a->d_scores && !a->emo)) return MMDA_EINVAL;
   hipLaunchKernelGGL(fused_fwd_c_kernel, dim3(ceil_div(a->B, a->nb)), dim3(FR_THREADS), 0, (hipStream_t)stream, *a);
   MMDA_CHECK_LAUNCH("mmda_fused_fwd_c");
   return MMDA_OK;

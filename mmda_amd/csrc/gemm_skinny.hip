@@ -13,6 +13,7 @@
 //     alpha, bias, accumulate, activation, dropout, relu-gate, sigmoid-backward factor, second destination.
 // Up to 8 independent problems per launch.  Deterministic: no atomics, fixed reduction order.
 #include "common.h"
+#include "transpose_tile.h"
 #include <stdlib.h>
 
 namespace {
@@ -269,30 +270,11 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyLaunch L) {
   skinny_epilogue(g, m, n, raw);
 }
 
-// fp32 transposes (up to 16 per launch): dst[c][r] = src[r][c] through 32 x 33 LDS tiles, coalesced on both sides.  Used once per
+// fp32 transposes (up to 20 per launch, transpose_tile.h): dst[c][r] = src[r][c] through 32 x 33 LDS tiles, coalesced on both sides.  Used once per
 // step (side stream) for the K-major copies of the fusion block's weights that its input-gradient GEMMs read.
-struct TrLaunch { mmda_transpose_job j[16]; int start[17]; int tx[16]; int n; };
 __global__ __launch_bounds__(256) void transpose_kernel(TrLaunch L) {
   __shared__ float tile[32][33];
-  int pi = 0;
-#pragma unroll
-  for (int k = 1; k < 16; ++k)
-    if (k < L.n && (int)blockIdx.x >= L.start[k]) pi = k;
-  const mmda_transpose_job& J = L.j[pi];
-  const int local = blockIdx.x - L.start[pi];
-  const int bx = local % L.tx[pi], by = local / L.tx[pi];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = by * 32 + ty + 8 * i, c = bx * 32 + tx;
-    tile[ty + 8 * i][tx] = (r < J.rows && c < J.cols) ? J.src[(int64_t)min(r, J.rows - 1) * J.ld + min(c, J.cols - 1)] : 0.f;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = bx * 32 + ty + 8 * i, r = by * 32 + tx;
-    if (c < J.cols && r < J.rows) J.dst[(int64_t)c * J.ldd + r] = tile[tx][ty + 8 * i];
-  }
+  transpose_block(L, (int)blockIdx.x, tile);
 }
 
 }  // namespace
@@ -343,20 +325,11 @@ extern "C" int mmda_gemm_skinny(const mmda_skinny_args* args, int n, void* strea
 
 extern "C" int mmda_transpose_f32(const mmda_transpose_job* jobs, int n, void* stream) {
   if (!jobs || n < 0) return MMDA_EINVAL;
-  for (int base = 0; base < n; base += 16) {
+  for (int base = 0; base < n; base += TR_MAX) {
     TrLaunch L;
-    L.n = 0;
     int blocks = 0;
-    for (int i = base; i < n && i < base + 16; ++i) {
-      const mmda_transpose_job& j = jobs[i];
-      if (!j.src || !j.dst || j.rows < 0 || j.cols < 0 || j.ld < j.cols || j.ldd < j.rows) return MMDA_EINVAL;
-      if (j.rows == 0 || j.cols == 0) continue;
-      const int k = L.n++;
-      L.j[k] = j; L.tx[k] = ceil_div(j.cols, 32); L.start[k] = blocks;
-      blocks += L.tx[k] * ceil_div(j.rows, 32);
-    }
-    for (int k = L.n; k <= 16; ++k) L.start[k] = blocks;
-    for (int k = L.n; k < 16; ++k) { L.j[k] = L.j[0]; L.tx[k] = 1; }
+    const int rc = tr_build(jobs + base, (n - base) < TR_MAX ? (n - base) : TR_MAX, L, blocks);
+    if (rc) return rc;
     if (blocks == 0) continue;
     hipLaunchKernelGGL(transpose_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L);
     MMDA_CHECK_LAUNCH("mmda_transpose_f32");

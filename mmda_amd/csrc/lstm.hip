@@ -13,6 +13,7 @@
 // walks t = T-1..0 from a zero state, so it effectively starts at len_b-1 (packed-sequence semantics).
 #include "common.h"
 #include "convert_tile.h"
+#include "transpose_tile.h"
 
 namespace {
 
@@ -153,10 +154,13 @@ __global__ void pack_multi_kernel(PackMulti P) { pack_block<MODE>(P, (int)blockI
 // The twelve W_hh packings of a step AND its first bf16 conversions (W_ih of both layers, the layer-1 inputs incl. the embedding
 // lookup) in ONE launch: blocks [0, pack_blocks) pack, the rest convert.  Both only depend on the step's inputs and weights, and as
 // two launches on two streams they cost the main stream a fork and a cross-stream wait in front of the first recurrent kernel.
-__global__ __launch_bounds__(256) void pack_convert_kernel(PackMulti P, ConvLaunch L, int pack_blocks) {
+// Blocks past the conversions transpose fp32 matrices (the fusion block's K-major weight copies for the backward pass).
+__global__ __launch_bounds__(256) void pack_convert_kernel(PackMulti P, ConvLaunch L, TrLaunch R, int pack_blocks, int conv_end) {
   __shared__ __attribute__((aligned(16))) unsigned short tile[64][66];
+  static_assert(sizeof(tile) >= sizeof(float) * 32 * 33, "the transpose tile is laid over the conversion tile");
   if ((int)blockIdx.x < pack_blocks) pack_block<MMDA_BF16>(P, (int)blockIdx.x);
-  else convert_block(L, (int)blockIdx.x - pack_blocks, tile);
+  else if ((int)blockIdx.x < conv_end) convert_block(L, (int)blockIdx.x - pack_blocks, tile);
+  else transpose_block(R, (int)blockIdx.x - conv_end, reinterpret_cast<float (*)[33]>(&tile[0][0]));
 }
 
 template <int MODE> __device__ __forceinline__ float sig_(float x) { return MODE == MMDA_BF16 ? sigmoid_fast(x) : sigmoidf_(x); }
@@ -572,20 +576,30 @@ int pack_build(int mode, int n, const int* H, const float* const* whh, void* con
 }
 }  // namespace
 
-extern "C" int mmda_lstm_pack_whh_and_convert(int n, const int* H, const float* const* whh, void* const* packed_fwd, void* const* packed_bwd,
-                                              void* const* packed_c, const mmda_convert_job* jobs, int njobs, void* stream) {
+extern "C" int mmda_lstm_pack_convert_transpose(int n, const int* H, const float* const* whh, void* const* packed_fwd,
+                                                void* const* packed_bwd, void* const* packed_c, const mmda_convert_job* jobs, int njobs,
+                                                const mmda_transpose_job* tjobs, int ntjobs, void* stream) {
   if (!jobs || njobs < 0 || njobs > CONV_MAX) return MMDA_EINVAL;
   PackMulti P;
-  int pblocks = 0, cblocks = 0;
+  int pblocks = 0, cblocks = 0, tblocks = 0;
   int rc = pack_build(MMDA_BF16, n, H, whh, packed_fwd, packed_bwd, packed_c, P, pblocks);
   if (rc) return rc;
   ConvLaunch L;
   rc = conv_build(jobs, njobs, L, cblocks);
   if (rc) return rc;
-  if (pblocks + cblocks == 0) return MMDA_OK;
-  hipLaunchKernelGGL(pack_convert_kernel, dim3(pblocks + cblocks), dim3(256), 0, (hipStream_t)stream, P, L, pblocks);
-  MMDA_CHECK_LAUNCH("mmda_lstm_pack_whh_and_convert");
+  TrLaunch R;
+  rc = tr_build(tjobs, ntjobs, R, tblocks);
+  if (rc) return rc;
+  if (pblocks + cblocks + tblocks == 0) return MMDA_OK;
+  hipLaunchKernelGGL(pack_convert_kernel, dim3(pblocks + cblocks + tblocks), dim3(256), 0, (hipStream_t)stream, P, L, R, pblocks,
+                     pblocks + cblocks);
+  MMDA_CHECK_LAUNCH("mmda_lstm_pack_convert_transpose");
   return MMDA_OK;
+}
+
+extern "C" int mmda_lstm_pack_whh_and_convert(int n, const int* H, const float* const* whh, void* const* packed_fwd, void* const* packed_bwd,
+                                              void* const* packed_c, const mmda_convert_job* jobs, int njobs, void* stream) {
+  return mmda_lstm_pack_convert_transpose(n, H, whh, packed_fwd, packed_bwd, packed_c, jobs, njobs, nullptr, 0, stream);
 }
 
 extern "C" int mmda_lstm_pack_whh_multi(int mode, int n, const int* H, const float* const* whh, void* const* packed_fwd,

@@ -69,6 +69,7 @@ struct mmda_misa {
   float* ws = nullptr; int64_t ws_floats = 0; int B = 0, T = 0;
   std::map<std::string, int64_t> tens;
   int64_t zero_begin = 0, zero_end = 0;      // activation-gradient region that is zeroed per step
+  int64_t zero_cls = 0, zero_recon = 0;      // ... its tail: d_scores from zero_cls, d_orig + d_recon from zero_recon (see loss seeds)
   int64_t gpad_begin = 0, gpad_end = 0;      // GRU: four-slot weight gradients (zeroed at set_workspace, re-zeroed by the unpad kernel)
   int64_t z, pmean, prstd, orig, x6, rsum, recon, dom_z, dom_h, dom, qkv, probs, ctx, attn_out, ln1_mean, ln1_rstd, x1, f1, f2,
       ln2_mean, ln2_rstd, hfused, logits, tcp, scores, labels, losses, diff_work, touched, ffn_parts, pg_parts, ln_parts;
@@ -102,6 +103,14 @@ struct mmda_misa {
   // train_step: the losses that read only the private/shared representations (diff, CMD) are issued by forward() on the side
   // stream as soon as those exist, beside the transformer layer and the heads; mmda_misa_losses() then adds the rest
   int eager_losses = 0, eager_done = 0;
+  // Loss seeds (training step, fused row-local stretches): the forward stretches store the gradient seeds of the reconstruction loss
+  // (d_recon, d_orig) and -- without ConfidNet, whose loss adds into the same buffer -- of the classification loss (d_scores) where
+  // they produce recon / scores, so the launch that computes cls / conf / recon and the weighted total has no gradient to seed and
+  // leaves the critical path between the forward and the backward pass (14 us at B=32): it runs on the side stream beside the
+  // layer-2 backward recurrence.  Values are bit-identical to the loss launch's (same expressions on the same operands).
+  const float* emo_eager = nullptr;          // labels of the step in flight (train_step)
+  int seed_recon = 0, seed_cls = 0;          // this step's forward wrote those seeds
+  const float* misc_deferred = nullptr;      // labels: the loss-value launch is still to be issued (backward's first side fork)
   int ldR = 0;
   // cluster-exchange regions: at the front of the workspace, sized by B alone, so a change of T (every batch under the reference's
   // collate) neither moves nor clears them -- flags are monotonic epochs.  Cleared (on the caller's stream) only when the buffer
@@ -312,8 +321,11 @@ int64_t layout(mmda_misa* m, int B, int T, bool commit) {
   // ---- the loss sums and the activation gradients seeded by the losses (zeroed every step by ONE memset, contiguous)
   o->zero_begin = k.cur;
   o->losses = k.take(8);
-  o->d_scores = k.take((int64_t)B * c.ncls); o->d_tcp = k.take((int64_t)B * 6); o->d_x6 = k.take(6 * BH);
-  o->d_orig = k.take(3 * BH); o->d_recon = k.take(3 * BH); o->d_dom = k.take((int64_t)3 * B * 3);
+  o->d_tcp = k.take((int64_t)B * 6); o->d_x6 = k.take(6 * BH); o->d_dom = k.take((int64_t)3 * B * 3);
+  o->zero_cls = k.cur;                       // (a step whose forward stores these seeds itself clears up to here only)
+  o->d_scores = k.take((int64_t)B * c.ncls);
+  o->zero_recon = k.cur;
+  o->d_orig = k.take(3 * BH); o->d_recon = k.take(3 * BH);
   o->zero_end = k.cur;
   // ---- fully overwritten gradients
   o->d_logits = k.take((int64_t)B * NC); o->d_hfused = k.take(6 * BH); o->d_x1 = k.take(6 * BH); o->d_f2 = k.take(6 * BH);
@@ -639,10 +651,9 @@ extern "C" int mmda_misa_cluster_status(const mmda_misa* m, int* aborted_host) {
 namespace {
 // K-major (transposed) fp32 copies of the fusion block's weights for its input-gradient GEMMs in the backward pass; issued on a side
 // stream that the end of forward() joins
-int weight_transposes(mmda_misa* m, void* ss) {
+void weight_transpose_jobs(mmda_misa* m, std::vector<mmda_transpose_job>& tj) {
   const mmda_misa_config& c = m->cfg;
   const int hs_ = c.hidden, NC_ = 6 + c.ncls;
-  std::vector<mmda_transpose_job> tj;
   auto T_ = [&](int64_t src, int rows, int cols, int64_t dst) { tj.push_back(mmda_transpose_job{PP(src), rows, cols, cols, WS(dst), rows}); };
   T_(m->head_w, NC_, 6 * hs_, m->head_wT); T_(m->l2_w, hs_, FFN, m->l2_wT); T_(m->l1_w, FFN, hs_, m->l1_wT);
   T_(m->out_w, hs_, hs_, m->out_wT); T_(m->in_w, 3 * hs_, hs_, m->in_wT); T_(m->sh_w, hs_, hs_, m->sh_wT);
@@ -652,6 +663,10 @@ int weight_transposes(mmda_misa* m, void* ss) {
     T_(m->mod[i].pw, hs_, 4 * m->mod[i].H, m->pwT[i]);
   }
   if (!c.use_cmd_sim) { T_(m->d1_w, hs_, hs_, m->d1_wT); T_(m->d2_w, 3, hs_, m->d2_wT); }
+}
+int weight_transposes(mmda_misa* m, void* ss) {
+  std::vector<mmda_transpose_job> tj;
+  weight_transpose_jobs(m, tj);
   const int rc = mmda_transpose_f32(tj.data(), (int)tj.size(), ss);
   m->wT_valid = rc ? 0 : 1;
   m->wT_pending = 0;
@@ -691,7 +706,11 @@ int eager_side_losses(mmda_misa* m, void* stream, bool hseq2_t) {
   // (large batches: the loss chain on the side stream is the longer one by far -- the weight transposes go to the main stream)
   if (!rc && m->wT_pending) rc = weight_transposes(m, B >= 128 ? stream : ss);
   (void)hseq2_t;                   // (the backward pass's operand copies are made by backward() itself: backward_only_jobs)
-  if (!rc) rc = mmda_misa_zero_act_grads(m, ss);
+  if (!rc) {
+    // (the forward stretches on the main stream STORE the seeds they own: clearing those here would race with them)
+    const int64_t end = m->seed_cls ? m->zero_cls : m->seed_recon ? m->zero_recon : m->zero_end;
+    if (hipMemsetAsync(WS(m->zero_begin), 0, sizeof(float) * (end - m->zero_begin), (hipStream_t)ss) != hipSuccess) rc = MMDA_ELAUNCH;
+  }
   float* L = WS(m->losses);
   if (!rc) rc = mmda_loss_diff(WS(m->x6), BH, B, hs, c.diff_weight, L + 1, WS(m->d_x6), WS(m->diff_work), ss);
   if (!rc && c.use_cmd_sim) rc = mmda_loss_cmd(WS(m->x6 + 3 * BH), BH, B, hs, c.sim_weight, L + 2, WS(m->d_x6 + 3 * BH), ss);
@@ -867,8 +886,16 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
     if (merged) {
       mmda_convert_job cj[9];
       const int nj = first_jobs(true, !inf, cj);
-      x.rc = mmda_lstm_pack_whh_and_convert(12, Hs, Wp, Fp, Bp, want_c ? Cp : nullptr, cj, nj, stream);
-      m->wT_pending = want_wT ? 1 : 0;
+      // ... and the K-major copies of the fusion block's weights (backward pass) in the same launch: 6 MB of traffic that cost a
+      // launch of its own 7 - 9 us at the head of the loss chain (side stream, the longer of the two chains beside the fusion block)
+      // or, at B >= 128, 15 us with its gap on the main stream.  MMDA_WT_MERGE=0: on the first fork as before.
+      static const int wt_merge = getenv("MMDA_WT_MERGE") ? atoi(getenv("MMDA_WT_MERGE")) : 1;
+      std::vector<mmda_transpose_job> tj;
+      if (want_wT && wt_merge) weight_transpose_jobs(m, tj);
+      if (tj.size() > 20) tj.clear();
+      x.rc = mmda_lstm_pack_convert_transpose(12, Hs, Wp, Fp, Bp, want_c ? Cp : nullptr, cj, nj, tj.data(), (int)tj.size(), stream);
+      m->wT_pending = (want_wT && tj.empty()) ? 1 : 0;
+      if (!tj.empty()) m->wT_valid = x.rc ? 0 : 1;
     } else {
       void* ss = nullptr;
       x.rc = side_fork(m, stream, &ss);
@@ -953,6 +980,10 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
       //  the backward pass needs -- hseq, transposed inputs -- are made later on the side stream: backward_only_jobs)
       if (bfg)
         for (int i = 0; i < 3; ++i) { ln[i].y_bf16 = WS(m->mod[i].rnn[1].xb); ln[i].ld_bf16 = m->mod[i].rnn[1].ldD; }
+      // ... and ONLY as that copy where nothing reads the fp32 output: an evaluation pass, or a training step whose layer-2 weight
+      // gradients take the tn form (they read the bf16 copy; the nt form converts the fp32 output into a transposed copy)
+      if (bfg && (inf || (m->tn_wgrad & 2)))
+        for (int i = 0; i < 3; ++i) ln[i].y = nullptr;
       x.rc = mmda_layernorm_fwd_multi(ln, 3, stream);
     } else if (!x.rc && !m->eager_losses && ((bfg && !inf) || m->zero_grad_pending || m->wT_pending)) {
       // side stream, beside the fusion block: the gradient bucket is cleared (train_step) and hseq^T of layer 2 is made for its
@@ -987,11 +1018,15 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
                    MMDA_ACT_SIGMOID);
     g[3] = sk_nt(3 * B, hs, hs, WS(m->orig), hs, PP(m->sh_w), PP(m->sh_b), WS(m->x6 + 3 * BH), hs, MMDA_ACT_SIGMOID);
     sk_launch(x, g, 4);
-    if (!x.rc) x.rc = eager_side_losses(m, stream, bfg && !inf);
     // The row-local stretches as one launch each (fused_rows.hip): recon + qkv -> attention -> out-proj -> LayerNorm 1, and
     // LayerNorm 2 -> heads.  MMDA_ROW_FUSE=0: the launches they replace (4 and 3).
     static const int row_fuse_on = getenv("MMDA_ROW_FUSE") ? atoi(getenv("MMDA_ROW_FUSE")) : 1;
     const bool row_fuse = row_fuse_on && c.use_cmd_sim && hs == 128 && NHEAD == 2;
+    // loss seeds by the stretches (see mmda_misa::emo_eager); MMDA_LOSS_SEEDS=0: by the loss launch behind the forward pass, as before
+    static const int loss_seeds_on = getenv("MMDA_LOSS_SEEDS") ? atoi(getenv("MMDA_LOSS_SEEDS")) : 1;
+    m->seed_recon = (loss_seeds_on && row_fuse && m->eager_losses && m->emo_eager) ? 1 : 0;
+    m->seed_cls = (m->seed_recon && !c.use_confidNet) ? 1 : 0;
+    if (!x.rc) x.rc = eager_side_losses(m, stream, bfg && !inf);
     static const int fuse_nb_env = getenv("MMDA_ROW_FUSE_NB") ? atoi(getenv("MMDA_ROW_FUSE_NB")) : 1;      // samples per workgroup (B=32: 0.722 ms with 2, 0.712 with 1; B=256 equal)
     const int fuse_nb = ((B % 2) == 0 && fuse_nb_env == 2) ? 2 : 1;
     mmda_ln_args l1 = {};
@@ -1006,6 +1041,10 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
         f.in_w = PP(m->in_w); f.in_b = PP(m->in_b); f.qkv = WS(m->qkv);
         f.ctx = WS(m->ctx); f.probs = WS(m->probs); f.p_tf = p_tf; f.seed = seed; f.site_attn = SITE_ATTN;
         f.out_w = PP(m->out_w); f.out_b = PP(m->out_b); f.attn_out = WS(m->attn_out); f.ln1 = l1;
+        if (m->seed_recon) {
+          f.orig = WS(m->orig); f.d_recon = WS(m->d_recon); f.d_orig = WS(m->d_orig);
+          f.recon_inv_n = 1.0f / (float)(3 * BH); f.recon_scale = c.recon_weight;
+        }
         x.rc = mmda_fused_fwd_a(&f, stream);
       }
     } else {
@@ -1062,6 +1101,7 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
         f.hfused = WS(m->hfused); f.head_w = PP(m->head_w); f.head_b = PP(m->head_b); f.logits = WS(m->logits);
         f.threshold = c.threshold; f.tcp = WS(m->tcp); f.scores = WS(m->scores); f.labels = WS(m->labels);
         f.p_cls = p_cls; f.seed = seed; f.site_cls = SITE_CLS;
+        if (m->seed_cls) { f.emo = m->emo_eager; f.d_scores = WS(m->d_scores); }
         x.rc = mmda_fused_fwd_c(&f, stream);
       }
     } else {
@@ -1089,6 +1129,7 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
          BH, (int64_t)hs * hs, BH, hs);
     gemm(x, fmode, 0, 1, 3 * B, hs, hs, WS(m->orig), hs, PP(m->sh_w), hs, WS(m->x6 + 3 * BH), hs, PP(m->sh_b), nullptr, 0,
          MMDA_ACT_SIGMOID);
+    m->seed_recon = m->seed_cls = 0;
     if (!x.rc) x.rc = eager_side_losses(m, stream, bfg && !inf);
     // reconstruct (models.py:254-262)
     if (!x.rc) x.rc = mmda_add(WS(m->x6), WS(m->x6 + 3 * BH), WS(m->rsum), 3 * BH, stream);
@@ -1164,6 +1205,8 @@ extern "C" int mmda_misa_losses(mmda_misa* m, const float* emo, int with_grads, 
   float* L = WS(m->losses);
   const bool eager = m->eager_done && with_grads;        // forward() already cleared the region and ran diff (+ CMD) on the side stream
   m->eager_done = 0;
+  const bool s_recon = eager && m->seed_recon, s_cls = eager && m->seed_cls;      // seeds the forward stretches stored already
+  m->seed_recon = m->seed_cls = 0;
   if (eager) {
     rc = side_join(m, stream);                           // (forward() joined already; kept for callers that split the calls)
     if (rc) return rc;
@@ -1181,10 +1224,16 @@ extern "C" int mmda_misa_losses(mmda_misa* m, const float* emo, int with_grads, 
   if (rc) return rc;
   // cls, conf (computed every step like solver.py:168; it only seeds gradients with use_confidNet, solver.py:180-181), recon and
   // the weighted total in one launch
-  return mmda_loss_misc(WS(m->scores), WS(m->tcp), emo, B, c.ncls, with_grads ? WS(m->d_scores) : nullptr,
-                        with_grads ? WS(m->d_tcp) : nullptr, c.ncls == 6, with_grads && c.use_confidNet, c.conf_weight, WS(m->recon),
-                        WS(m->orig), 3 * BH, c.recon_weight, with_grads ? WS(m->d_recon) : nullptr, with_grads ? WS(m->d_orig) : nullptr,
-                        L, c.diff_weight, c.sim_weight, c.recon_weight, c.conf_weight, c.use_confidNet, stream);
+  if (s_recon && s_cls && c.use_cmd_sim) {
+    // no gradient left to seed: the launch only computes loss values -- issued by backward() on the side stream (train_step calls it next)
+    m->misc_deferred = emo;
+    return MMDA_OK;
+  }
+  return mmda_loss_misc(WS(m->scores), WS(m->tcp), emo, B, c.ncls, (with_grads && !s_cls) ? WS(m->d_scores) : nullptr,
+                        (with_grads && !s_cls) ? WS(m->d_tcp) : nullptr, c.ncls == 6, with_grads && c.use_confidNet, c.conf_weight,
+                        WS(m->recon), WS(m->orig), 3 * BH, c.recon_weight, (with_grads && !s_recon) ? WS(m->d_recon) : nullptr,
+                        (with_grads && !s_recon) ? WS(m->d_orig) : nullptr, L, c.diff_weight, c.sim_weight, c.recon_weight, c.conf_weight,
+                        c.use_confidNet, stream);
 }
 
 // =============================================================================================== backward
@@ -1480,6 +1529,13 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
     // weight-gradient GEMM of the block
     void* ss = nullptr;
     x.rc = side_fork(m, stream, &ss);
+    if (!x.rc && m->misc_deferred) {
+      // loss values of the step (the forward stretches stored every gradient seed: see mmda_misa::emo_eager)
+      x.rc = mmda_loss_misc(WS(m->scores), WS(m->tcp), m->misc_deferred, B, c.ncls, nullptr, nullptr, c.ncls == 6, 0, c.conf_weight,
+                            WS(m->recon), WS(m->orig), 3 * BH, c.recon_weight, nullptr, nullptr, WS(m->losses), c.diff_weight,
+                            c.sim_weight, c.recon_weight, c.conf_weight, c.use_confidNet, ss);
+      m->misc_deferred = nullptr;
+    }
     if (!x.rc && B <= SKINNY_MAX_B) x.rc = mmda_add(WS(m->x6), WS(m->x6 + 3 * BH), WS(m->rsum), 3 * BH, ss);
     if (!x.rc && pg_pending) {
       // gamma / beta gradients of the five LayerNorms the fused stretches walked: per-sample partials added in sample order
@@ -1771,10 +1827,11 @@ extern "C" int mmda_misa_train_step(mmda_misa* m, const int64_t* t_ids, const fl
   m->inference = 0;                                     // a training step always stashes
   m->zero_grad_pending = m->T > 0 ? 1 : 0;
   m->eager_losses = 1; m->eager_done = 0;
+  m->emo_eager = emo; m->misc_deferred = nullptr;
   int rc = m->zero_grad_pending ? MMDA_OK : mmda_misa_zero_grad(m, stream);
   if (rc) return rc;
   rc = mmda_misa_forward(m, t_ids, v, a, lengths, training, seed, stream);
-  m->eager_losses = 0;
+  m->eager_losses = 0; m->emo_eager = nullptr;
   if (rc) return rc;
   if (m->zero_grad_pending) return MMDA_ELAUNCH;        // forward() always reaches its fusion block
   rc = mmda_misa_losses(m, emo, 1, stream);

@@ -154,13 +154,13 @@ __device__ __forceinline__ void ln_fwd_vec_row(const mmda_ln_args& a, int row, i
   }
   const V* gm = reinterpret_cast<const V*>(a.gamma);
   const V* bt = reinterpret_cast<const V*>(a.beta);
-  V* y = reinterpret_cast<V*>(a.y + (int64_t)row * n);
+  V* y = a.y ? reinterpret_cast<V*>(a.y + (int64_t)row * n) : nullptr;
   unsigned short* yb = a.y_bf16 ? reinterpret_cast<unsigned short*>(a.y_bf16) + (int64_t)row * a.ld_bf16 : nullptr;
 #pragma unroll
   for (int q = 0; q < NV; ++q) {
     const int g = lane + 64 * q;
     V o = vzero<VW>();
-    if (g < ng) { o = (v[q] - mean) * rstd * gm[g] + bt[g]; y[g] = o; }
+    if (g < ng) { o = (v[q] - mean) * rstd * gm[g] + bt[g]; if (y) y[g] = o; }
     if (yb && VW * g < a.ld_bf16) {                                     // (ld_bf16 is a multiple of 8: whole groups; zero in the padding)
       if (VW == 4) {
         typedef unsigned u2v __attribute__((ext_vector_type(2)));
@@ -441,7 +441,7 @@ int ew_blocks(int64_t n) {
 
 namespace {
 int ln_check(const mmda_ln_args* a) {
-  if (!a->x || !a->y || !a->gamma || !a->beta || a->rows < 0 || a->n <= 0 || a->n > LN_MAXQ * 64) return MMDA_EINVAL;
+  if (!a->x || (!a->y && !a->y_bf16) || !a->gamma || !a->beta || a->rows < 0 || a->n <= 0 || a->n > LN_MAXQ * 64) return MMDA_EINVAL;      // (y may be NULL when only the bf16 copy is wanted)
   if (a->permute_S > 0 && (a->permute_B <= 0 || a->permute_S * a->permute_B != a->rows)) return MMDA_EINVAL;
   return MMDA_OK;
 }
@@ -506,7 +506,7 @@ extern "C" int mmda_layernorm_fwd_multi(const mmda_ln_args* a, int n, void* stre
       const mmda_ln_args& q = L.a[k];
       const int vw = (q.n & 3) ? 2 : 4;                 // bytes per group 8 / 16: every row start must be that aligned
       vec = vec && (q.n & 1) == 0 && ceil_div(q.n, vw * 64) <= LNV_MAX && !q.res && q.act == MMDA_ACT_NONE && q.permute_S <= 0 &&
-            ((((uintptr_t)q.x | (uintptr_t)q.y | (uintptr_t)q.gamma | (uintptr_t)q.beta) & (4 * vw - 1)) == 0) &&
+            ((((uintptr_t)q.x | (uintptr_t)q.y | (uintptr_t)q.gamma | (uintptr_t)q.beta) & (4 * vw - 1)) == 0) &&      // (a NULL y is aligned)
             (!q.y_bf16 || ((q.ld_bf16 & 7) == 0 && ((uintptr_t)q.y_bf16 & 7) == 0 && ceil_div(q.ld_bf16, vw * 64) <= LNV_MAX));
     }
     static const int ln_vec_on = getenv("MMDA_LN_VEC") ? atoi(getenv("MMDA_LN_VEC")) : 1;

@@ -101,7 +101,7 @@ __device__ __forceinline__ void ln_fwd_row(const mmda_ln_args& a, int row, int l
   for (int q = 0; q < NQ; ++q) {
     int i = lane + 64 * q;
     float y = 0.f;
-    if (i < n) { y = (v[q] - mean) * rstd * a.gamma[i] + a.beta[i]; a.y[orow * n + i] = y; }
+    if (i < n) { y = (v[q] - mean) * rstd * a.gamma[i] + a.beta[i]; if (a.y) a.y[orow * n + i] = y; }
     if (a.y_bf16 && i < a.ld_bf16) reinterpret_cast<unsigned short*>(a.y_bf16)[orow * a.ld_bf16 + i] = f2bf(y);      // (zero in the padding)
   }
 }
