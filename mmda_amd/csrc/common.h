@@ -142,3 +142,26 @@ __device__ __forceinline__ float act_bwd_p(int act, float x, const mmda_act_para
   if (!act_is_p(act)) return act_bwd(act, x);
   return x > 0.f ? 1.f : act_slope_p(act, p, idx);
 }
+
+// internal: mmda_clamp_adam whose launch does not complete before *wait_flag reaches wait_value (optim.hip)
+int mmda_clamp_adam_wait(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float clip,
+                         float grad_scale, int step, const unsigned* wait_flag, unsigned wait_value, unsigned* wait_err, void* stream);
+
+// ---- flag joins (misa.hip: side_flag_signal): a kernel of one stream waits, on the device, for a word that a one-thread launch behind
+// the last kernel of ANOTHER stream's chain sets to `value` -- instead of a stream-level event wait, which costs the waiting stream
+// 9 - 12 us of packet processing however early the other chain finished (tools/micro/fork_cost.hip).  Called by every thread of the
+// workgroup; thread 0 polls (bounded: a word that never arrives is reported through *err and the kernel goes on), a workgroup
+// barrier and an agent-scope acquire follow.  flag == nullptr: nothing to wait for (workgroup-uniform).
+__device__ __forceinline__ void flag_wait(const unsigned* flag, unsigned value, unsigned* err) {
+  if (!flag) return;
+  if (threadIdx.x == 0) {
+    int polls = 0;
+    while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - value) < 0) {
+      __builtin_amdgcn_s_sleep(16);
+      if (++polls > (1 << 21)) { if (err) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+

@@ -37,6 +37,8 @@ struct FusedBwdA {
   mmda_ln_bwd_args lnp[3];        // rows = B each
   float* pg_parts;                // (B, 5, 2, hs): slot 1: ln1, slots 2..4: the projection LayerNorms
   unsigned long long* dbg;        // diagnostics: cycle counter at each stage boundary of workgroup 0 (NULL in production)
+  // optional flag join (common.h: flag_wait): d_x6 holds the gradients of the batch-statistic losses, written by another stream
+  const unsigned* wait_flag; unsigned wait_value; unsigned* wait_err;
 };
 
 // forward stretch A: recon = (private + shared) W_rec^T + b and qkv = x6 W_in^T + b (both read x6 only) -> six-token attention ->

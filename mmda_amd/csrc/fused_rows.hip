@@ -181,6 +181,7 @@ __global__ __launch_bounds__(FR_THREADS) void fused_bwd_a_kernel(FusedBwdA P) {
   int stamp_i = 0;
   auto stamp = [&]() { if (P.dbg && blockIdx.x == 0 && threadIdx.x == 0) P.dbg[stamp_i] = __builtin_readcyclecounter(); ++stamp_i; };
   stamp();
+  flag_wait(P.wait_flag, P.wait_value, P.wait_err);
   // ---- d_x1 += sum of the feed-forward backward partials (slice order), for the token rows of these samples
   if (P.ffn_parts) {
     const int64_t MH = (int64_t)S6K * B * hs;

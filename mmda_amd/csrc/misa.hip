@@ -111,6 +111,16 @@ struct mmda_misa {
   const float* emo_eager = nullptr;          // labels of the step in flight (train_step)
   int seed_recon = 0, seed_cls = 0;          // this step's forward wrote those seeds
   const float* misc_deferred = nullptr;      // labels: the loss-value launch is still to be issued (backward's first side fork)
+  // Flag joins (training step; common.h: flag_wait): where the main stream needs a side-stream chain's results, the consuming KERNEL
+  // waits on the device for a word that a one-thread launch behind the chain sets, instead of the stream waiting for an event -- an
+  // event wait costs the main stream 9 - 12 us of packet processing even when the chain finished long ago (tools/micro/fork_cost.hip),
+  // twice per step.  Forward: the loss chain's gradients (d_x6) are first read by the LayerNorm-1 stretch of the backward pass
+  // (fused_bwd_a_kernel).  Backward: nothing on the main stream reads what the side stream's weight-gradient GEMMs and early
+  // optimizer pass write; the step's last optimizer launch simply does not complete before they have.  ev_join is still recorded
+  // behind each chain for the paths that cannot wait on the device.  MMDA_FLAG_JOIN=0: event joins as before.
+  unsigned* jflags = nullptr;                // device: [0] forward chain done, [1] backward chain done, [2] a wait timed out
+  unsigned jval[2] = {0u, 0u};
+  int flag_join_ok = 0, fj1 = 0, fj2 = 0;
   int ldR = 0;
   // cluster-exchange regions: at the front of the workspace, sized by B alone, so a change of T (every batch under the reference's
   // collate) neither moves nor clears them -- flags are monotonic epochs.  Cleared (on the caller's stream) only when the buffer
@@ -439,6 +449,8 @@ int side_fork(mmda_misa* m, void* main_stream, void** out) {
     if (hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess) return MMDA_ELAUNCH;
     if (hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess) return MMDA_ELAUNCH;
     if (hipEventCreateWithFlags(&m->ev_pack, hipEventDisableTiming) != hipSuccess) return MMDA_ELAUNCH;
+    if (hipMalloc(reinterpret_cast<void**>(&m->jflags), 64) != hipSuccess) { m->jflags = nullptr; return MMDA_ELAUNCH; }
+    if (hipMemset(m->jflags, 0, 64) != hipSuccess) return MMDA_ELAUNCH;
   }
   if (hipEventRecord(m->ev_fork, (hipStream_t)main_stream) != hipSuccess) return MMDA_ELAUNCH;
   if (hipStreamWaitEvent(m->side, m->ev_fork, 0) != hipSuccess) return MMDA_ELAUNCH;
@@ -453,6 +465,24 @@ int side_launch(mmda_misa* m, std::vector<mmda_gemm_args>& list, void* main_stre
   if (!rc) rc = mmda_gemm_grouped(list.data(), (int)list.size(), ss);
   list.clear();
   return rc;
+}
+__global__ void flag_set_kernel(unsigned* flag, unsigned value) {
+  __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the side stream's chain ends here for the main stream: word `idx` is set behind it (flag join); ev_join is recorded too
+int side_flag_signal(mmda_misa* m, int idx) {
+  if (!m->side || !m->jflags) return MMDA_EINVAL;
+  ++m->jval[idx];
+  hipLaunchKernelGGL(flag_set_kernel, dim3(1), dim3(1), 0, m->side, m->jflags + idx, m->jval[idx]);
+  MMDA_CHECK_LAUNCH("side_flag_signal");
+  if (hipEventRecord(m->ev_join, m->side) != hipSuccess) return MMDA_ELAUNCH;
+  m->side_pending = 0;
+  return MMDA_OK;
+}
+// a flag join whose consumer kernel will not run after all: the event recorded with it
+int flag_join_fallback(mmda_misa* m, void* main_stream) {
+  if (hipStreamWaitEvent((hipStream_t)main_stream, m->ev_join, 0) != hipSuccess) return MMDA_ELAUNCH;
+  return MMDA_OK;
 }
 int side_join(mmda_misa* m, void* main_stream) {
   if (!m->side_pending) return MMDA_OK;
@@ -533,6 +563,7 @@ extern "C" void mmda_misa_destroy(mmda_misa* m) {
   if (m->ev_pack) (void)hipEventDestroy(m->ev_pack);
   if (m->ev_early) (void)hipEventDestroy(m->ev_early);
   if (m->side) (void)hipStreamDestroy(m->side);
+  if (m->jflags) (void)hipFree(m->jflags);
   for (hipEvent_t e : m->ev) (void)hipEventDestroy(e);
   delete m;
 }
@@ -638,6 +669,11 @@ extern "C" int mmda_misa_cluster_status(const mmda_misa* m, int* aborted_host) {
   // reads the sticky abort words of the three exchange buffers (device->host copy: call it off the step path)
   if (!m || !m->ws || !aborted_host) return MMDA_EINVAL;
   *aborted_host = m->abort_sticky;          // seen in an exchange region that has since been cleared (B changed)
+  if (m->jflags) {                          // a flag join timed out (see mmda_misa::jflags)
+    unsigned w = 0;
+    if (hipMemcpy(&w, m->jflags + 2, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) return MMDA_ELAUNCH;
+    if (w) *aborted_host = 1;
+  }
   for (int i = 0; i < 3; ++i) {
     if (m->mod[i].xchg < 0) continue;
     unsigned w = 0;
@@ -1183,6 +1219,11 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
     x.rc = side_fork(m, stream, &ss);
     if (!x.rc) x.rc = weight_transposes(m, ss);
   }
+  if (!x.rc && m->flag_join_ok && m->seed_recon && m->seed_cls && m->side_pending && m->use_side && m->jflags) {
+    x.rc = side_flag_signal(m, 0);             // (see mmda_misa::jflags: fused_bwd_a_kernel waits for the loss chain)
+    m->fj1 = x.rc ? 0 : 1;
+    return x.rc;
+  }
   if (!x.rc) x.rc = side_join(m, stream);      // (the side stream finished long ago: this only orders later work behind it)
   return x.rc;
 }
@@ -1269,6 +1310,7 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
     // ... -> the projection LayerNorms.  MMDA_ROW_FUSE=0: the launches they replace (3 and 6).
     static const int row_fuse_on = getenv("MMDA_ROW_FUSE") ? atoi(getenv("MMDA_ROW_FUSE")) : 1;
     const bool row_fuse = row_fuse_on && wt && c.use_cmd_sim && hs == 128 && NHEAD == 2;
+    if (m->fj1 && !row_fuse) { x.rc = flag_join_fallback(m, stream); m->fj1 = 0; if (x.rc) return x.rc; }     // (no kernel here waits on the device)
     static const int fuse_nb_env = getenv("MMDA_ROW_FUSE_NB") ? atoi(getenv("MMDA_ROW_FUSE_NB")) : 1;      // samples per workgroup (B=32: 0.722 ms with 2, 0.712 with 1; B=256 equal)
     const int fuse_nb = ((B % 2) == 0 && fuse_nb_env == 2) ? 2 : 1;
     mmda_ln_bwd_args l2a = {};
@@ -1280,6 +1322,9 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
       FusedBwdC f = {};
       f.B = B; f.hs = hs; f.ncls = c.ncls; f.nb = fuse_nb;
       f.tcp = WS(m->tcp); f.scores = WS(m->scores); f.d_tcp = WS(m->d_tcp); f.d_scores = WS(m->d_scores); f.d_logits = WS(m->d_logits);
+      // flag join pending: d_tcp is all zeros (no ConfidNet gradients in that mode), but cleared by the side stream's chain, which
+      // this launch does not wait for -- NULL reads as zero
+      if (m->fj1) f.d_tcp = nullptr;
       f.p_cls = p_cls; f.seed = seed; f.site_cls = SITE_CLS; f.head_w = PP(m->head_w); f.d_hfused = WS(m->d_hfused); f.ln2 = l2a;
       f.pg_parts = WS(m->pg_parts);
       x.rc = mmda_fused_bwd_c(&f, stream);
@@ -1337,7 +1382,15 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
         lp.actp = act_params(m, training, seed, SITE_RRELU + i, true);
       }
       f.pg_parts = WS(m->pg_parts);
-      x.rc = mmda_fused_bwd_a(&f, stream);
+      if (m->fj1) {
+        // Waiting workgroups hold their CU's LDS (104 KB each): with one on every CU the side stream's kernels could not start, and
+        // the wait would never end -- on the device only while the stretch leaves most of the chip free; otherwise the event, here
+        // (two launches later than the end of the forward pass, where it used to be: the loss chain is the longer one at large B)
+        if (ceil_div(B, fuse_nb) <= 64) { f.wait_flag = m->jflags; f.wait_value = m->jval[0]; f.wait_err = m->jflags + 2; }
+        else x.rc = flag_join_fallback(m, stream);
+        m->fj1 = 0;
+      }
+      if (!x.rc) x.rc = mmda_fused_bwd_a(&f, stream);
       pg_pending = true;
       // the weight gradients of the stretch (deferred: one grouped launch on the side stream, as below)
       lin_dw(x, fmode, 6 * B, hs, hs, WS(m->d_attn_out), WS(m->ctx), GG(m->out_w), GG(m->out_b));
@@ -1439,6 +1492,7 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
     }
     sk_launch(x, g, 3);
   } else {
+    if (m->fj1) { x.rc = flag_join_fallback(m, stream); m->fj1 = 0; if (x.rc) return x.rc; }      // (cannot happen: the seeds need the fused stretches)
     // heads
     x.rc = mmda_heads_bwd(WS(m->tcp), WS(m->scores), WS(m->d_tcp), WS(m->d_scores), B, c.ncls, WS(m->d_logits), p_cls, seed, SITE_CLS,
                           stream);
@@ -1757,7 +1811,14 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
     if (x.rc) return x.rc;
   }
   if (!m->ev.empty()) { if (m->ev_seen_b % m->ev_stride == 0) m->ev_bwd++; m->ev_seen_b++; }
-  if (!x.rc) x.rc = side_join(m, stream);      // every gradient is complete on `stream` when backward returns
+  // every gradient is complete on `stream` when backward returns -- or, in a fused training step whose last optimizer launch can wait
+  // on the device (see mmda_misa::jflags), when that launch completes
+  if (!x.rc && m->flag_join_ok && m->adam_early_on && !is_gru(m) && !m->embed_early_done && m->use_side && m->side_pending && m->jflags) {
+    x.rc = side_flag_signal(m, 1);
+    m->fj2 = x.rc ? 0 : 1;
+    return x.rc;
+  }
+  if (!x.rc) x.rc = side_join(m, stream);
   if (!x.rc && is_gru(m)) {                    // fold the four-slot weight gradients into the torch-layout gradient buffer
     mmda_gru_pad_job gj[MMDA_GRU_PAD_MAX];
     int n = gru_jobs(m, m->G, true, gj);
@@ -1828,6 +1889,8 @@ extern "C" int mmda_misa_train_step(mmda_misa* m, const int64_t* t_ids, const fl
   m->zero_grad_pending = m->T > 0 ? 1 : 0;
   m->eager_losses = 1; m->eager_done = 0;
   m->emo_eager = emo; m->misc_deferred = nullptr;
+  static const int flag_join_on = getenv("MMDA_FLAG_JOIN") ? atoi(getenv("MMDA_FLAG_JOIN")) : 1;
+  m->flag_join_ok = (flag_join_on && m->use_side) ? 1 : 0; m->fj1 = m->fj2 = 0;
   int rc = m->zero_grad_pending ? MMDA_OK : mmda_misa_zero_grad(m, stream);
   if (rc) return rc;
   rc = mmda_misa_forward(m, t_ids, v, a, lengths, training, seed, stream);
@@ -1840,13 +1903,19 @@ extern "C" int mmda_misa_train_step(mmda_misa* m, const int64_t* t_ids, const fl
   m->adam_early_on = (do_adam && adam_split) ? 1 : 0; m->ae_lr = lr; m->ae_clip = clip; m->ae_step = step; m->adam_early_done = 0;
   m->embed_early_done = 0;
   rc = mmda_misa_backward(m, t_ids, v, a, lengths, stream);
-  m->adam_early_on = 0;
+  m->adam_early_on = 0; m->flag_join_ok = 0;
   if (rc) return rc;
+  if (m->fj1) { rc = flag_join_fallback(m, stream); m->fj1 = 0; if (rc) return rc; }      // (no stretch took it over: cannot happen)
+  if (m->fj2 && !do_adam) { rc = flag_join_fallback(m, stream); m->fj2 = 0; if (rc) return rc; }
   if (do_adam) {
     // the rest of the bucket (layer-1 recurrent layers, embedding -- or everything, if the backward pass stepped nothing early)
     const int64_t o = m->adam_early_done;
     const int64_t end = m->embed_early_done ? m->embed : m->flat;
-    rc = mmda_clamp_adam(m->P + o, m->G + o, m->M1 + o, m->V1 + o, end - o, lr, 0.9f, 0.999f, 1e-8f, clip, 1.0f, step, stream);
+    // (flag join: this launch does not complete before the side stream's weight-gradient GEMMs and early optimizer pass have)
+    const bool fj = m->fj2 != 0;
+    m->fj2 = 0;
+    rc = mmda_clamp_adam_wait(m->P + o, m->G + o, m->M1 + o, m->V1 + o, end - o, lr, 0.9f, 0.999f, 1e-8f, clip, 1.0f, step,
+                              fj ? m->jflags + 1 : nullptr, m->jval[1], fj ? m->jflags + 2 : nullptr, stream);
     if (!rc && m->embed_early_done)          // the rows of this batch (their gradient has just been scattered)
       rc = mmda_clamp_adam_rows(m->P + m->embed, m->G + m->embed, m->M1 + m->embed, m->V1 + m->embed, m->cfg.vocab, m->cfg.d_t,
                                 reinterpret_cast<const unsigned char*>(m->ws + m->touched), 1, lr, 0.9f, 0.999f, 1e-8f, clip, 1.0f, step, stream);

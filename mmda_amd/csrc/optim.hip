@@ -18,9 +18,12 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, flo
   p = __fmaf_rn(-step_size, __fdiv_rn(m, denom), p);
 }
 
+// wait_flag != nullptr (flag join, common.h): workgroup 0 does not finish before that word reaches wait_value -- so the completion of this
+// launch on its stream implies the completion of the other stream's chain (the update itself does not depend on it).
 __global__ __launch_bounds__(256) void clamp_adam_kernel(float* p, const float* __restrict__ g, float* m, float* v, int64_t n,
                                                          float b1, float b2, float eps, float clip, float gscale,
-                                                         float step_size, float inv_bc2_sqrt) {
+                                                         float step_size, float inv_bc2_sqrt, const unsigned* wait_flag,
+                                                         unsigned wait_value, unsigned* wait_err) {
   const int64_t n4 = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   float4* p4 = reinterpret_cast<float4*>(p);
@@ -37,6 +40,7 @@ __global__ __launch_bounds__(256) void clamp_adam_kernel(float* p, const float* 
   }
   for (int64_t i = (n4 << 2) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride)
     adam1(p[i], g[i], m[i], v[i], b1, b2, eps, clip, gscale, step_size, inv_bc2_sqrt);
+  if (blockIdx.x == 0) flag_wait(wait_flag, wait_value, wait_err);
 }
 
 // The same update over the ROWS of a (rows, dim) table whose mask byte equals `want` (dim % 4 == 0 or not: scalar tail per row).
@@ -99,9 +103,15 @@ __global__ void clamp_kernel(float* g, int64_t n, float clip) {
 
 extern "C" int mmda_clamp_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                                float eps, float clip, float grad_scale, int step, void* stream) {
+  return mmda_clamp_adam_wait(p, g, m, v, n, lr, beta1, beta2, eps, clip, grad_scale, step, nullptr, 0u, nullptr, stream);
+}
+
+// internal (misa.hip): the same launch, not complete before *wait_flag reaches wait_value (see clamp_adam_kernel)
+int mmda_clamp_adam_wait(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float clip,
+                         float grad_scale, int step, const unsigned* wait_flag, unsigned wait_value, unsigned* wait_err, void* stream) {
   if (!p || !g || !m || !v || n < 0 || step < 1) return MMDA_EINVAL;
   if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return MMDA_EINVAL;   // float4 path
-  if (n == 0) return MMDA_OK;
+  if (n == 0 && !wait_flag) return MMDA_OK;
   double bc1 = 1.0 - pow((double)beta1, (double)step);
   double bc2 = 1.0 - pow((double)beta2, (double)step);
   float step_size = (float)((double)lr / bc1);
@@ -110,7 +120,7 @@ extern "C" int mmda_clamp_adam(float* p, const float* g, float* m, float* v, int
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(clamp_adam_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, beta1, beta2, eps, clip,
-                     grad_scale, step_size, inv_bc2_sqrt);
+                     grad_scale, step_size, inv_bc2_sqrt, wait_flag, wait_value, wait_err);
   MMDA_CHECK_LAUNCH("mmda_clamp_adam");
   return MMDA_OK;
 }
