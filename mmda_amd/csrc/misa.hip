@@ -10,6 +10,10 @@ int64_t mmda_ln_parts_floats(const mmda_ln_bwd_args* a, int n);
 int mmda_ln_bwd_parts(const mmda_ln_bwd_args* a, int n, float* parts, void* stream);
 int mmda_ln_parts_finish(const mmda_ln_bwd_args* a, int n, float* parts, void* stream);
 int mmda_embed_scatter_add_masked(float* dW, const int64_t* ids, int rows, int dim, const float* dX, const int* lengths, int B, void* stream);
+bool mmda_embed_scatter_sorts(int rows);
+// ... and of dist.hip: the sort-based scatter in two halves (the sorted id list early, the sums behind the gradient rows)
+int mmda_embed_sort_ids(const int64_t* ids, int n, const int* lengths, int B, int table_rows, unsigned* sorted, void* stream);
+int mmda_embed_scatter_presorted(float* dW, const unsigned* sorted, int n, int D, int table_rows, const float* rows, void* stream);
 
 #include <map>
 #include <string>
@@ -120,6 +124,10 @@ struct mmda_misa {
   // behind each chain for the paths that cannot wait on the device.  MMDA_FLAG_JOIN=0: event joins as before.
   unsigned* jflags = nullptr;                // device: [0] forward chain done, [1] backward chain done, [2] a wait timed out
   unsigned jval[2] = {0u, 0u};
+  // The sort-based embedding scatter of a large batch in two halves: the sorted (id, position) list depends on the ids only and is
+  // made on the side stream beside the layer-2 backward recurrence (33 us of launches at B=256 that used to sit between the last
+  // GEMM and the optimizer); word [3] tells the main stream it is there (a one-wave wait launch in front of the sums).
+  int64_t esort = -1; int esort_valid = 0; unsigned esort_val = 0u;
   int flag_join_ok = 0, fj1 = 0, fj2 = 0;
   int ldR = 0;
   // cluster-exchange regions: at the front of the workspace, sized by B alone, so a change of T (every batch under the reference's
@@ -311,6 +319,7 @@ int64_t layout(mmda_misa* m, int B, int T, bool commit) {
   o->diff_work = k.take(mmda_loss_diff_work_floats(B, hs));
   o->ffn_parts = k.take((int64_t)(FFN / 32) * 6 * BH);      // partial products of the hidden-sliced feed-forward kernels (fused_rows.hip)
   o->ln_parts = k.take((int64_t)512 * 2 * 2 * (o->mod[0].H + o->mod[1].H + o->mod[2].H));   // <= 512 block partials of the three inter-layer LayerNorms' gamma / beta gradients (norm.hip)
+  o->esort = k.take(2 * (int64_t)B * T + 64);              // sorted (id, position) list of the step's text ids (dist.hip)
   o->pg_parts = k.take((int64_t)B * FUSED_PG_SLOTS * 2 * 128);      // per-sample LayerNorm gamma / beta gradient partials of the fused backward stretches
   o->touched = k.take((c.vocab + 3) / 4);              // one byte per embedding row: occurs in this batch (see mmda_clamp_adam_rows)
   o->head_wT = k.take((int64_t)6 * hs * NC); o->l2_wT = k.take((int64_t)FFN * hs); o->l1_wT = k.take((int64_t)hs * FFN);
@@ -443,12 +452,19 @@ void ev_rec(mmda_misa* m, int step, int slot, int which, void* stream) {
 // there; side_join() makes `main_stream` wait for it.  Without overlap the main stream itself is returned.
 int side_fork(mmda_misa* m, void* main_stream, void** out) {
   *out = main_stream;
-  if (!m->use_side) return MMDA_OK;
+  static const int no_side = getenv("MMDA_NO_SIDE") ? atoi(getenv("MMDA_NO_SIDE")) : 0;      // diagnostics: everything on one stream
+  if (!m->use_side || no_side) return MMDA_OK;
   if (!m->side) {
     if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess) return MMDA_ELAUNCH;
-    if (hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess) return MMDA_ELAUNCH;
-    if (hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess) return MMDA_ELAUNCH;
-    if (hipEventCreateWithFlags(&m->ev_pack, hipEventDisableTiming) != hipSuccess) return MMDA_ELAUNCH;
+    // The fork / join events order streams of ONE device: no system-scope fence with them (hipEventDisableSystemFence -- "device
+    // memory may not be visible to the host and other devices", neither of which waits on these events; every kernel still ends with
+    // its own device-scope release).  With the fence a recorded event costs the recording stream 6 us between two launches, without
+    // it 3 (tools/micro/fork_cost.hip).  MMDA_EVENT_SYSFENCE=1: with the fence.
+    static const int sysfence = getenv("MMDA_EVENT_SYSFENCE") ? atoi(getenv("MMDA_EVENT_SYSFENCE")) : 0;
+    const unsigned evf = hipEventDisableTiming | (sysfence ? 0u : hipEventDisableSystemFence);
+    if (hipEventCreateWithFlags(&m->ev_fork, evf) != hipSuccess) return MMDA_ELAUNCH;
+    if (hipEventCreateWithFlags(&m->ev_join, evf) != hipSuccess) return MMDA_ELAUNCH;
+    if (hipEventCreateWithFlags(&m->ev_pack, evf) != hipSuccess) return MMDA_ELAUNCH;
     if (hipMalloc(reinterpret_cast<void**>(&m->jflags), 64) != hipSuccess) { m->jflags = nullptr; return MMDA_ELAUNCH; }
     if (hipMemset(m->jflags, 0, 64) != hipSuccess) return MMDA_ELAUNCH;
   }
@@ -466,6 +482,7 @@ int side_launch(mmda_misa* m, std::vector<mmda_gemm_args>& list, void* main_stre
   list.clear();
   return rc;
 }
+__global__ void flag_wait_kernel(const unsigned* flag, unsigned value, unsigned* err) { flag_wait(flag, value, err); }
 __global__ void flag_set_kernel(unsigned* flag, unsigned value) {
   __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -1591,6 +1608,17 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
       m->misc_deferred = nullptr;
     }
     if (!x.rc && B <= SKINNY_MAX_B) x.rc = mmda_add(WS(m->x6), WS(m->x6 + 3 * BH), WS(m->rsum), 3 * BH, ss);
+    // the sorted id list of the embedding scatter (see mmda_misa::esort); MMDA_SORT_EARLY=0: made where the scatter runs
+    static const int sort_early = getenv("MMDA_SORT_EARLY") ? atoi(getenv("MMDA_SORT_EARLY")) : 1;
+    m->esort_valid = 0;
+    if (!x.rc && sort_early && T > 0 && m->esort >= 0 && mmda_embed_scatter_sorts(R)) {
+      x.rc = mmda_embed_sort_ids(t_ids, R, lengths, B, c.vocab, reinterpret_cast<unsigned*>(WS(m->esort)), ss);
+      if (!x.rc && ss != stream) {
+        hipLaunchKernelGGL(flag_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)ss, m->jflags + 3, ++m->esort_val);
+        if (hipGetLastError() != hipSuccess) x.rc = MMDA_ELAUNCH;
+      }
+      m->esort_valid = x.rc ? 0 : (ss != stream ? 2 : 1);
+    }
     if (!x.rc && pg_pending) {
       // gamma / beta gradients of the five LayerNorms the fused stretches walked: per-sample partials added in sample order
       float* dg[FUSED_PG_SLOTS] = {GG(m->n2_w), GG(m->n1_w), GG(m->mod[0].plw), GG(m->mod[1].plw), GG(m->mod[2].plw)};
@@ -1806,14 +1834,25 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
       }
     } else if (!x.rc) {
       // text: gradient w.r.t. the embedding rows, scattered densely into embed.weight.grad (sparse=False)
-      x.rc = mmda_embed_scatter_add_masked(GG(m->embed), t_ids, R, c.d_t, WS(m->mod[0].d_x), lengths, B, stream);
+      if (m->esort_valid) {
+        if (m->esort_valid == 2) {                         // made on the side stream: its word, waited for by one wave
+          hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, m->jflags + 3, m->esort_val, m->jflags + 2);
+          if (hipGetLastError() != hipSuccess) x.rc = MMDA_ELAUNCH;
+        }
+        if (!x.rc)
+          x.rc = mmda_embed_scatter_presorted(GG(m->embed), reinterpret_cast<const unsigned*>(WS(m->esort)), R, c.d_t, c.vocab,
+                                              WS(m->mod[0].d_x), stream);
+        m->esort_valid = 0;
+      } else {
+        x.rc = mmda_embed_scatter_add_masked(GG(m->embed), t_ids, R, c.d_t, WS(m->mod[0].d_x), lengths, B, stream);
+      }
     }
     if (x.rc) return x.rc;
   }
   if (!m->ev.empty()) { if (m->ev_seen_b % m->ev_stride == 0) m->ev_bwd++; m->ev_seen_b++; }
   // every gradient is complete on `stream` when backward returns -- or, in a fused training step whose last optimizer launch can wait
   // on the device (see mmda_misa::jflags), when that launch completes
-  if (!x.rc && m->flag_join_ok && m->adam_early_on && !is_gru(m) && !m->embed_early_done && m->use_side && m->side_pending && m->jflags) {
+  if (!x.rc && m->flag_join_ok && m->adam_early_on && !is_gru(m) && m->use_side && m->side_pending && m->jflags) {
     x.rc = side_flag_signal(m, 1);
     m->fj2 = x.rc ? 0 : 1;
     return x.rc;

@@ -7,6 +7,7 @@
 
 int mmda_embed_scatter_sorted(float* dW, const int64_t* ids, int n, int D, const float* rows, const int* lengths, int B, void* stream);   // dist.hip
 int mmda_embed_scatter_add_masked(float* dW, const int64_t* ids, int rows, int dim, const float* dX, const int* lengths, int B, void* stream);
+bool mmda_embed_scatter_sorts(int rows);
 
 namespace {
 
@@ -664,13 +665,17 @@ extern "C" int mmda_embed_scatter_add(float* dW, const int64_t* ids, int rows, i
   return mmda_embed_scatter_add_masked(dW, ids, rows, dim, dX, nullptr, 0, stream);
 }
 
+// (internal) lists of this length take the sort-based form
+bool mmda_embed_scatter_sorts(int rows) {
+  static const int sort_min_env = getenv("MMDA_SCATTER_SORT_MIN") ? atoi(getenv("MMDA_SCATTER_SORT_MIN")) : 3072;
+  const int sort_min = sort_min_env > ES_MAX ? ES_MAX + 1 : sort_min_env;
+  return rows >= sort_min;
+}
 // (internal, misa.hip) the same with the batch's lengths: positions p = t * B + b with t >= lengths[b] are padding and are skipped
 int mmda_embed_scatter_add_masked(float* dW, const int64_t* ids, int rows, int dim, const float* dX, const int* lengths, int B, void* stream) {
   if (!dW || !ids || !dX || rows < 0 || dim <= 0 || dim > 1024 || (lengths && B <= 0)) return MMDA_EINVAL;
   if (rows == 0) return MMDA_OK;
-  static const int sort_min_env = getenv("MMDA_SCATTER_SORT_MIN") ? atoi(getenv("MMDA_SCATTER_SORT_MIN")) : 3072;
-  const int sort_min = sort_min_env > ES_MAX ? ES_MAX + 1 : sort_min_env;
-  if (rows >= sort_min) return mmda_embed_scatter_sorted(dW, ids, rows, dim, dX, lengths, B, stream);
+  if (mmda_embed_scatter_sorts(rows)) return mmda_embed_scatter_sorted(dW, ids, rows, dim, dX, lengths, B, stream);
   hipLaunchKernelGGL(embed_scatter_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, dW, ids, rows, dim, dX, lengths, B);
   MMDA_CHECK_LAUNCH("mmda_embed_scatter_add");
   return MMDA_OK;

@@ -19,8 +19,11 @@ int main() {
   CK(hipStreamCreateWithFlags(&main_s, hipStreamNonBlocking));
   CK(hipStreamCreateWithFlags(&side_s, hipStreamNonBlocking));
   hipEvent_t ef, ej;
-  CK(hipEventCreateWithFlags(&ef, hipEventDisableTiming));
-  CK(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
+  for (int flavour = 0; flavour < 3; ++flavour) {
+  const unsigned fl = hipEventDisableTiming | (flavour == 1 ? hipEventDisableSystemFence : flavour == 2 ? hipEventReleaseToDevice : 0u);
+  printf("---- events created with hipEventDisableTiming%s\n", flavour == 1 ? " | hipEventDisableSystemFence" : flavour == 2 ? " | hipEventReleaseToDevice" : "");
+  CK(hipEventCreateWithFlags(&ef, fl));
+  CK(hipEventCreateWithFlags(&ej, fl));
   const long long T10 = 1000;     // wall_clock64 runs at 100 MHz: 10 us
   const int N = 300;
   int* sink = nullptr;
@@ -77,6 +80,8 @@ int main() {
       const char* names[6] = {"no fork (K1 K2)", "event fork", "ext-launch fork", "event fork + event join", "ext fork + ext join", "event fork + ext join"};
       if (rep == 1) printf("%-28s %7.2f us per iteration (2 x 10 us of kernels on the main stream)\n", names[variant], us);
     }
+  }
+  CK(hipEventDestroy(ef)); CK(hipEventDestroy(ej));
   }
   return 0;
 }

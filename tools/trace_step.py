@@ -4,7 +4,7 @@ f = sys.argv[1]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'clamp_adam' in r['Kernel_Name']]
-a, b = idx[-3], idx[-2]
+a, b = idx[-5], idx[-3]      # two optimizer launches per step (early prefix on the side stream, the rest at the end)
 t0 = int(rows[a]['End_Timestamp'])
 last_end = t0
 for r in rows[a + 1:b + 1]:
