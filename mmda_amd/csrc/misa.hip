@@ -770,8 +770,11 @@ int eager_side_losses(mmda_misa* m, void* stream, bool hseq2_t) {
   // The gradient bucket (43 MB, 11 us) is cleared on the MAIN stream behind the fork: since the row-local stretches were fused the
   // side stream's loss chain (72 us at B=32), not the main stream's fusion block (55 us), is what the join at the end of forward() waits
   // for.  (Nothing on either stream touches the bucket before the backward pass; MMDA_ZERO_GRAD_SIDE=1: the old place.)
-  static const int zg_side = getenv("MMDA_ZERO_GRAD_SIDE") ? atoi(getenv("MMDA_ZERO_GRAD_SIDE")) : 0;
-  if (!rc && m->zero_grad_pending) { rc = mmda_misa_zero_grad(m, zg_side ? ss : stream); m->zero_grad_pending = 0; }
+  // ... unless the main stream will not wait for this chain before the LayerNorm-1 stretch of the backward pass (flag join on the
+  // device, small batches: see mmda_misa::jflags) -- the chain then has two launches of slack and the clear comes back here.
+  static const int zg_side = getenv("MMDA_ZERO_GRAD_SIDE") ? atoi(getenv("MMDA_ZERO_GRAD_SIDE")) : -1;
+  const bool zg_here = zg_side >= 0 ? zg_side != 0 : (m->flag_join_ok && m->seed_recon && m->seed_cls && B <= 64);
+  if (!rc && m->zero_grad_pending) { rc = mmda_misa_zero_grad(m, zg_here ? ss : stream); m->zero_grad_pending = 0; }
   m->eager_done = 1;
   return rc;
 }
