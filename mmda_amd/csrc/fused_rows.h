@@ -16,6 +16,9 @@ struct FusedBwdC {
   float* d_hfused;                // (B, 6 hs)
   mmda_ln_bwd_args ln2;           // rows = 6 B (token-major), permute_S / permute_B set
   float* pg_parts;                // (B, 5, 2, hs): per-sample partial gamma / beta gradients of the block's five LayerNorms (slot 0: ln2)
+  // optional: rec_part (3, B, hs) = d_recon[i] W_rec[i], made by a second set of workgroups of this launch for stretch A (all three
+  // given or none)
+  const float* d_recon; const float* rec_wT; float* rec_part;
 };
 
 // stretch A: LayerNorm 1 backward -> d_ctx = d_attn_out W_out -> attention backward -> d_x6 = (d_x6 + d_qkv W_in + d_recon W_rec) s(1-s)
@@ -28,6 +31,7 @@ struct FusedBwdA {
   const float* qkv; const float* probs; float* d_qkv; float p_tf; uint64_t seed; int site_attn;
   const float* in_wT;             // (hs, 3 hs): K-major copy of in_proj_weight
   const float* d_recon;           // (3, B, hs)
+  const float* rec_part;          // optional (3, B, hs): d_recon[i] W_rec[i] already multiplied (see FusedBwdC); then rec_wT is not read
   const float* rec_wT;            // 3 x (hs, hs) K-major
   const float* x6;                // (6, B, hs) sigmoid outputs
   float* d_x6;                    // (6, B, hs)
@@ -54,6 +58,7 @@ struct FusedFwdA {
   // optional (training step): the reconstruction loss's gradient seeds, written where recon is produced instead of by the loss launch
   // behind the forward pass -- d_recon = 2 (recon - orig) recon_g, d_orig = -d_recon (stores: the buffers need not be cleared)
   const float* orig; float* d_recon; float* d_orig; float recon_inv_n, recon_scale;
+  int split_recon;                // set by mmda_fused_fwd_a: the reconstruction runs in workgroups of its own (twice the grid)
 };
 // forward stretch C: hfused = LayerNorm 2 (x1 + dropout(f2)) permuted to (B, 6 hs) -> logits = hfused W_head^T + b -> heads
 struct FusedFwdC {

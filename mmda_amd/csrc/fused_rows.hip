@@ -8,6 +8,7 @@
 #include "common.h"
 #include "rowlocal.h"
 #include "fused_rows.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -133,8 +134,42 @@ __device__ __forceinline__ void pg_zero_rest(float* parts, int b0, int nb, int k
   for (int e = threadIdx.x; e < (nb - 1) * 256; e += FR_THREADS) pg_slot(parts, b0 + 1 + e / 256, k)[e % 256] = 0.f;
 }
 
+// rec_part[i] = d_recon[i] W_rec[i] for the modality rows of `nb` samples (the term fused_bwd_a_kernel adds into d_x6 of the private and
+// the shared token of modality i): its operands exist before the backward pass starts, so workgroups [nblk, 2 nblk) of the stretch-C
+// launch make it beside that stretch instead of three extra rounds in the middle of stretch A's chain
+__device__ __forceinline__ void rec_part_rows(const FusedBwdC& P, int b0, int nb, float* lds_a, float* lds_w) {
+  const int B = P.B, hs = P.hs;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int nmod = 3 * nb;
+  const bool mok = r16 < nmod;
+  const int mi = mok ? r16 / nb : 0;
+  const int col = wave * 16 + r16;
+  stage_rows(lds_a, nmod, hs, [&](int r) { return P.d_recon + ((int64_t)(r / nb) * B + b0 + (r % nb)) * hs; });
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const float* row = mok ? lds_a + r16 * (hs + 4) : nullptr;
+  const float* const ar[3] = {(mok && mi == 0) ? row : nullptr, (mok && mi == 1) ? row : nullptr, (mok && mi == 2) ? row : nullptr};
+  const float* rw = P.rec_wT + (int64_t)wave * 16 * hs;
+  const float* const bb[3] = {rw, rw + (int64_t)hs * hs, rw + (int64_t)2 * hs * hs};
+  const int ld[3] = {hs, hs, hs};
+  tile_mac_chain<3>(acc, ar, bb, ld, lane, lds_w + wave * 16 * WL_LD);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = 4 * g + i;
+    if (r < nmod) P.rec_part[((int64_t)(r / nb) * B + b0 + (r % nb)) * hs + col] = acc[i];
+  }
+}
+
 __global__ __launch_bounds__(FR_THREADS) void fused_bwd_c_kernel(FusedBwdC P) {
   __shared__ float red[2 * 8 * 128];
+  __shared__ __attribute__((aligned(16))) float lds_a[6 * (128 + 4)];
+  __shared__ __attribute__((aligned(16))) float lds_w[8 * 16 * WL_LD];
+  const int nblk = (P.B + P.nb - 1) / P.nb;
+  if ((int)blockIdx.x >= nblk) {                         // workgroup-uniform; only launched with rec_part
+    const int rb0 = ((int)blockIdx.x - nblk) * P.nb;
+    rec_part_rows(P, rb0, min(P.nb, P.B - rb0), lds_a, lds_w);
+    return;
+  }
   const int b0 = (int)blockIdx.x * P.nb;
   const int nb = min(P.nb, P.B - b0);
   const int NC = 6 + P.ncls, B = P.B, hs = P.hs;
@@ -230,23 +265,34 @@ __global__ __launch_bounds__(FR_THREADS) void fused_bwd_a_kernel(FusedBwdA P) {
     // LDS: rows 0..ntok-1 = d_qkv rows (3 hs deep); behind them, at a stride of hs + 4, the d_recon row of every token row
     float* lds_r = lds_a + 12 * (3 * hs + 4);
     stage_rows(lds_a, ntok, 3 * hs, [&](int r) { return P.d_qkv + ((int64_t)(r / nb) * B + b0 + (r % nb)) * 3 * hs; });
-    stage_rows(lds_r, ntok, hs, [&](int r) { return P.d_recon + ((int64_t)((r / nb) % 3) * B + b0 + (r % nb)) * hs; });
-    const float* rec_row = rok ? lds_r + r16 * (hs + 4) : nullptr;
     const float* qrow = rok ? lds_a + r16 * (3 * hs + 4) : nullptr;
     const float* wrow = P.in_wT + (int64_t)wave * 16 * 3 * hs;
-    const float* const ar[6] = {qrow, qrow ? qrow + 128 : nullptr, qrow ? qrow + 256 : nullptr, (rok && tj % 3 == 0) ? rec_row : nullptr,
-                                (rok && tj % 3 == 1) ? rec_row : nullptr, (rok && tj % 3 == 2) ? rec_row : nullptr};
-    const float* recw = P.rec_wT + (int64_t)wave * 16 * hs;
-    const float* const bb[6] = {wrow, wrow + 128, wrow + 256, recw, recw + (int64_t)hs * hs, recw + (int64_t)2 * hs * hs};
-    const int ld[6] = {3 * hs, 3 * hs, 3 * hs, hs, hs, hs};
-    tile_mac_chain<6>(acc, ar, bb, ld, lane, lds_w + wave * 16 * WL_LD);
+    if (P.rec_part) {
+      // the reconstruction term d_recon[j % 3] W_rec[j % 3] was made by workgroups of the stretch-C launch (fused_bwd_c_kernel): three
+      // of this chain's six rounds are gone from it
+      const float* const ar[3] = {qrow, qrow ? qrow + 128 : nullptr, qrow ? qrow + 256 : nullptr};
+      const float* const bb[3] = {wrow, wrow + 128, wrow + 256};
+      const int ld[3] = {3 * hs, 3 * hs, 3 * hs};
+      tile_mac_chain<3>(acc, ar, bb, ld, lane, lds_w + wave * 16 * WL_LD);
+    } else {
+      stage_rows(lds_r, ntok, hs, [&](int r) { return P.d_recon + ((int64_t)((r / nb) % 3) * B + b0 + (r % nb)) * hs; });
+      const float* rec_row = rok ? lds_r + r16 * (hs + 4) : nullptr;
+      const float* const ar[6] = {qrow, qrow ? qrow + 128 : nullptr, qrow ? qrow + 256 : nullptr, (rok && tj % 3 == 0) ? rec_row : nullptr,
+                                  (rok && tj % 3 == 1) ? rec_row : nullptr, (rok && tj % 3 == 2) ? rec_row : nullptr};
+      const float* recw = P.rec_wT + (int64_t)wave * 16 * hs;
+      const float* const bb[6] = {wrow, wrow + 128, wrow + 256, recw, recw + (int64_t)hs * hs, recw + (int64_t)2 * hs * hs};
+      const int ld[6] = {3 * hs, 3 * hs, 3 * hs, hs, hs, hs};
+      tile_mac_chain<6>(acc, ar, bb, ld, lane, lds_w + wave * 16 * WL_LD);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = 4 * g + i;
       if (r < ntok) {
         const int64_t o = ((int64_t)(r / nb) * B + b0 + (r % nb)) * hs + col;
         const float s = P.x6[o];
-        P.d_x6[o] = (P.d_x6[o] + acc[i]) * (s * (1.f - s));
+        float t = acc[i];
+        if (P.rec_part) t += P.rec_part[((int64_t)((r / nb) % 3) * B + b0 + (r % nb)) * hs + col];
+        P.d_x6[o] = (P.d_x6[o] + t) * (s * (1.f - s));
       }
     }
   }
@@ -303,7 +349,12 @@ __global__ __launch_bounds__(FR_THREADS) void fused_bwd_a_kernel(FusedBwdA P) {
 __global__ __launch_bounds__(FR_THREADS) void fused_fwd_a_kernel(FusedFwdA P) {
   __shared__ __attribute__((aligned(16))) float lds_a[LDS_A_FLOATS];
   __shared__ __attribute__((aligned(16))) float lds_w[8 * 16 * WL_LD];
-  const int b0 = (int)blockIdx.x * P.nb;
+  // Roles (P.split_recon, small batches): the reconstruction reads x6 only and nothing of this stretch reads it, so it runs in
+  // workgroups of its own -- [nblk, 2 nblk) -- beside the qkv -> attention -> out-projection -> LayerNorm chain instead of in front of it
+  const int nblk = (P.B + P.nb - 1) / P.nb;
+  const bool do_recon = !P.split_recon || (int)blockIdx.x >= nblk;
+  const bool do_chain = !P.split_recon || (int)blockIdx.x < nblk;
+  const int b0 = ((int)blockIdx.x % nblk) * P.nb;
   const int nb = min(P.nb, P.B - b0);
   const int B = P.B, hs = P.hs;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -315,6 +366,7 @@ __global__ __launch_bounds__(FR_THREADS) void fused_fwd_a_kernel(FusedFwdA P) {
   const int col = wave * 16 + r16;
   // LDS: rows 0..ntok-1 = the x6 token rows; rows 12..12+nmod-1 = private + shared of (modality, sample)
   stage_rows(lds_a, ntok, hs, [&](int r) { return P.x6 + ((int64_t)(r / nb) * B + b0 + (r % nb)) * hs; });
+  if (do_recon) {                                          // workgroup-uniform
   for (int e = threadIdx.x; e < nmod * (hs / 4); e += FR_THREADS) {
     const int r = e / (hs / 4), c = e % (hs / 4);
     const f4 a = *reinterpret_cast<const f4*>(lds_a + r * (hs + 4) + 4 * c), b2 = *reinterpret_cast<const f4*>(lds_a + (nmod + r) * (hs + 4) + 4 * c);
@@ -346,6 +398,8 @@ __global__ __launch_bounds__(FR_THREADS) void fused_fwd_a_kernel(FusedFwdA P) {
       }
     }
   }
+  }
+  if (!do_chain) return;
   // ---- qkv = x6 W_in^T + b_in: token-row tile, 3 hs = 384 output columns = three passes of the eight waves
 #pragma unroll 1
   for (int pass = 0; pass < 3; ++pass) {
@@ -582,7 +636,12 @@ int mmda_fused_ffn_bwd(const FusedFfnBwd* a, void* stream) {
 int mmda_fused_fwd_a(const FusedFwdA* a, void* stream) {
   if (!a || a->B <= 0 || a->nb <= 0 || a->nb > 2 || a->hs != 128 || a->nhead != 2 || a->ln1.n != 128) return MMDA_EINVAL;
   if (a->d_recon && (!a->orig || !a->d_orig)) return MMDA_EINVAL;
-  hipLaunchKernelGGL(fused_fwd_a_kernel, dim3(ceil_div(a->B, a->nb)), dim3(FR_THREADS), 0, (hipStream_t)stream, *a);
+  // (the reconstruction in workgroups of its own while both roles together leave the chip half empty; MMDA_FUSED_SPLIT=0: never)
+  static const int split_on = getenv("MMDA_FUSED_SPLIT") ? atoi(getenv("MMDA_FUSED_SPLIT")) : 1;
+  FusedFwdA f = *a;
+  const int nblk = ceil_div(a->B, a->nb);
+  f.split_recon = (split_on && nblk <= 64) ? 1 : 0;
+  hipLaunchKernelGGL(fused_fwd_a_kernel, dim3(f.split_recon ? 2 * nblk : nblk), dim3(FR_THREADS), 0, (hipStream_t)stream, f);
   MMDA_CHECK_LAUNCH("mmda_fused_fwd_a");
   return MMDA_OK;
 }
@@ -640,7 +699,8 @@ int mmda_fused_pg_finish(const float* pg_parts, int B, int hs, float* const* dga
 int mmda_fused_bwd_c(const FusedBwdC* a, void* stream) {
   if (!a || a->B <= 0 || a->nb <= 0 || a->hs != 128 || a->ln2.n != 128) return MMDA_EINVAL;
   if ((a->ln2.dgamma || a->ln2.dbeta) && !a->pg_parts) return MMDA_EINVAL;       // parameter gradients go through the partials
-  hipLaunchKernelGGL(fused_bwd_c_kernel, dim3(ceil_div(a->B, a->nb)), dim3(FR_THREADS), 0, (hipStream_t)stream, *a);
+  if (a->rec_part && (!a->d_recon || !a->rec_wT || a->nb > 2)) return MMDA_EINVAL;
+  hipLaunchKernelGGL(fused_bwd_c_kernel, dim3(ceil_div(a->B, a->nb) * (a->rec_part ? 2 : 1)), dim3(FR_THREADS), 0, (hipStream_t)stream, *a);
   MMDA_CHECK_LAUNCH("mmda_fused_bwd_c");
   return MMDA_OK;
 }

@@ -128,6 +128,7 @@ struct mmda_misa {
   // made on the side stream beside the layer-2 backward recurrence (33 us of launches at B=256 that used to sit between the last
   // GEMM and the optimizer); word [3] tells the main stream it is there (a one-wave wait launch in front of the sums).
   int64_t esort = -1; int esort_valid = 0; unsigned esort_val = 0u;
+  int64_t rec_part = -1;
   int flag_join_ok = 0, fj1 = 0, fj2 = 0;
   int ldR = 0;
   // cluster-exchange regions: at the front of the workspace, sized by B alone, so a change of T (every batch under the reference's
@@ -319,6 +320,7 @@ int64_t layout(mmda_misa* m, int B, int T, bool commit) {
   o->diff_work = k.take(mmda_loss_diff_work_floats(B, hs));
   o->ffn_parts = k.take((int64_t)(FFN / 32) * 6 * BH);      // partial products of the hidden-sliced feed-forward kernels (fused_rows.hip)
   o->ln_parts = k.take((int64_t)512 * 2 * 2 * (o->mod[0].H + o->mod[1].H + o->mod[2].H));   // <= 512 block partials of the three inter-layer LayerNorms' gamma / beta gradients (norm.hip)
+  o->rec_part = k.take(3 * BH);                             // d_recon W_rec, made beside the backward pass's first stretch for its third (fused_rows.h)
   o->esort = k.take(2 * (int64_t)B * T + 64);              // sorted (id, position) list of the step's text ids (dist.hip)
   o->pg_parts = k.take((int64_t)B * FUSED_PG_SLOTS * 2 * 128);      // per-sample LayerNorm gamma / beta gradient partials of the fused backward stretches
   o->touched = k.take((c.vocab + 3) / 4);              // one byte per embedding row: occurs in this batch (see mmda_clamp_adam_rows)
@@ -1322,6 +1324,7 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
   // the dX chain (the critical path into the encoders) is through; their inputs are not modified afterwards.
   x.deferring = true;
   bool pg_pending = false;               // the fused stretches left LayerNorm parameter-gradient partials (mmda_fused_pg_finish)
+  bool rec_hoisted = false;              // stretch C's launch made d_recon W_rec for stretch A
   if (B <= SKINNY_MAX_B) {
     // ---- few rows: the dX chain on row-skinny GEMMs (13 launches); weight gradients deferred exactly as below
     mmda_skinny_args g[8];
@@ -1345,6 +1348,11 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
       // flag join pending: d_tcp is all zeros (no ConfidNet gradients in that mode), but cleared by the side stream's chain, which
       // this launch does not wait for -- NULL reads as zero
       if (m->fj1) f.d_tcp = nullptr;
+      // the reconstruction term of stretch A's d_x6 chain, in workgroups of this launch (small batches: both sets fit the chip twice
+      // over; MMDA_FUSED_SPLIT=0: inside stretch A as before)
+      static const int fsplit = getenv("MMDA_FUSED_SPLIT") ? atoi(getenv("MMDA_FUSED_SPLIT")) : 1;
+      rec_hoisted = fsplit && m->rec_part >= 0 && ceil_div(B, fuse_nb) <= 64;
+      if (rec_hoisted) { f.d_recon = WS(m->d_recon); f.rec_wT = WS(m->rec_wT); f.rec_part = WS(m->rec_part); }
       f.p_cls = p_cls; f.seed = seed; f.site_cls = SITE_CLS; f.head_w = PP(m->head_w); f.d_hfused = WS(m->d_hfused); f.ln2 = l2a;
       f.pg_parts = WS(m->pg_parts);
       x.rc = mmda_fused_bwd_c(&f, stream);
@@ -1392,6 +1400,7 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
       f.d_attn_out = WS(m->d_attn_out); f.out_wT = WS(m->out_wT); f.d_ctx = WS(m->d_ctx);
       f.qkv = WS(m->qkv); f.probs = WS(m->probs); f.d_qkv = WS(m->d_qkv); f.p_tf = p_tf; f.seed = seed; f.site_attn = SITE_ATTN;
       f.in_wT = WS(m->in_wT); f.d_recon = WS(m->d_recon); f.rec_wT = WS(m->rec_wT); f.x6 = WS(m->x6); f.d_x6 = WS(m->d_x6);
+      if (rec_hoisted) f.rec_part = WS(m->rec_part);
       f.priv_wT = WS(m->priv_wT); f.sh_wT = WS(m->sh_wT); f.d_orig = WS(m->d_orig);
       for (int i = 0; i < 3; ++i) {
         Mod& md = m->mod[i];
