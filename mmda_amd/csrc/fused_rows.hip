@@ -83,6 +83,35 @@ __device__ __forceinline__ float sum_parts(const float* __restrict__ p, int n, i
   return acc;
 }
 
+// The same sums for whole rows, workgroup-wide: `groups` = 16-byte column groups (row_off(g) = the group's float offset inside a
+// partial); the partials in two halves, each half by a thread of its own (sixteen 16-byte loads in flight: 64 partials are two batches
+// of latency per thread instead of four 4-byte batches), the two half sums -- in slice order each -- meet in LDS and
+// finish(g, lower half + upper half) stores them.  lds: 2 * groups float4.  Ends with a workgroup barrier.
+template <typename RowOff, typename Finish>
+__device__ __forceinline__ void sum_parts_rows(const float* __restrict__ parts, int n, int64_t stride, int groups, RowOff row_off, f4* lds,
+                                               Finish finish) {
+  const int n0 = (n + 1) >> 1;
+  for (int it = threadIdx.x; it < 2 * groups; it += FR_THREADS) {
+    const int gi = it % groups, half = it / groups;
+    const float* p = parts + row_off(gi) + (int64_t)(half ? n0 : 0) * stride;
+    const int cnt = half ? n - n0 : n0;
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    int q = 0;
+    for (; q + 16 <= cnt; q += 16) {
+      f4 v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const f4*>(p + (q + u) * stride);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc += v[u];
+    }
+    for (; q < cnt; ++q) acc += *reinterpret_cast<const f4*>(p + q * stride);
+    lds[half * groups + gi] = acc;
+  }
+  __syncthreads();
+  for (int gi = threadIdx.x; gi < groups; gi += FR_THREADS) finish(gi, lds[gi] + lds[groups + gi]);
+  __syncthreads();
+}
+
 // stage boundary: this workgroup's global stores are visible to all of its waves
 __device__ __forceinline__ void stage_sync() {
   __threadfence_block();
@@ -220,11 +249,11 @@ __global__ __launch_bounds__(FR_THREADS) void fused_bwd_a_kernel(FusedBwdA P) {
   // ---- d_x1 += sum of the feed-forward backward partials (slice order), for the token rows of these samples
   if (P.ffn_parts) {
     const int64_t MH = (int64_t)S6K * B * hs;
-    for (int e = threadIdx.x; e < S6K * nb * hs; e += FR_THREADS) {
-      const int i = e / hs, n = e % hs;
-      const int64_t o = ((int64_t)(i / nb) * B + b0 + (i % nb)) * hs + n;
-      P.d_x1[o] += sum_parts(P.ffn_parts + o, P.n_parts, MH);
-    }
+    auto off = [&](int gi) { const int i = gi / (hs / 4); return ((int64_t)(i / nb) * B + b0 + (i % nb)) * hs + 4 * (gi % (hs / 4)); };
+    sum_parts_rows(P.ffn_parts, P.n_parts, MH, S6K * nb * (hs / 4), off, reinterpret_cast<f4*>(lds_a), [&](int gi, f4 t) {
+      f4* d = reinterpret_cast<f4*>(P.d_x1 + off(gi));
+      *d = *d + t;
+    });
     stage_sync();
   }
   // ---- LayerNorm 1 backward: d_x6 += ..., d_attn_out
@@ -442,6 +471,7 @@ __global__ __launch_bounds__(FR_THREADS) void fused_fwd_a_kernel(FusedFwdA P) {
 }
 
 __global__ __launch_bounds__(FR_THREADS) void fused_fwd_c_kernel(FusedFwdC P) {
+  __shared__ f4 sp[2 * 12 * 32];                         // sum_parts_rows: two halves x (<= 12 rows x 32 column groups)
   const int b0 = (int)blockIdx.x * P.nb;
   const int nb = min(P.nb, P.B - b0);
   const int B = P.B, hs = P.hs, NC = 6 + P.ncls, W6 = 6 * hs;
@@ -449,11 +479,11 @@ __global__ __launch_bounds__(FR_THREADS) void fused_fwd_c_kernel(FusedFwdC P) {
   // ---- f2 = sum of the feed-forward partials (slice order) + b2, for the token rows of these samples
   if (P.ffn_parts) {
     const int64_t MH = (int64_t)S6K * B * hs;
-    for (int e = threadIdx.x; e < S6K * nb * hs; e += FR_THREADS) {
-      const int i = e / hs, n = e % hs;
-      const int64_t o = ((int64_t)(i / nb) * B + b0 + (i % nb)) * hs + n;
-      P.f2[o] = sum_parts(P.ffn_parts + o, P.n_parts, MH) + P.b2[n];
-    }
+    auto off = [&](int gi) { const int i = gi / (hs / 4); return ((int64_t)(i / nb) * B + b0 + (i % nb)) * hs + 4 * (gi % (hs / 4)); };
+    sum_parts_rows(P.ffn_parts, P.n_parts, MH, S6K * nb * (hs / 4), off, sp, [&](int gi, f4 t) {
+      const float* b = P.b2 + 4 * (gi % (hs / 4));            // (a parameter: 4-byte aligned only)
+      *reinterpret_cast<f4*>(P.f2 + off(gi)) = t + f4{b[0], b[1], b[2], b[3]};
+    });
     stage_sync();
   }
   // ---- LayerNorm 2 over the token rows, written in the (B, 6 hs) layout the heads read
@@ -647,7 +677,7 @@ int mmda_fused_fwd_a(const FusedFwdA* a, void* stream) {
 }
 
 int mmda_fused_fwd_c(const FusedFwdC* a, void* stream) {
-  if (!a || a->B <= 0 || a->nb <= 0 || a->hs != 128 || a->ln2.n != 128 || (a->d_scores && !a->emo)) return MMDA_EINVAL;
+  if (!a || a->B <= 0 || a->nb <= 0 || a->nb > 2 || a->hs != 128 || a->ln2.n != 128 || (a->d_scores && !a->emo)) return MMDA_EINVAL;
   hipLaunchKernelGGL(fused_fwd_c_kernel, dim3(ceil_div(a->B, a->nb)), dim3(FR_THREADS), 0, (hipStream_t)stream, *a);
   MMDA_CHECK_LAUNCH("mmda_fused_fwd_c");
   return MMDA_OK;
