@@ -779,7 +779,10 @@ extern "C" int mmda_gemm_bf16_grouped(const mmda_gemm_bf16_args* args, int n, vo
   bool fwd_only = n > 0;
   for (int i = 0; i < n; ++i) fwd_only = fwd_only && !args[i].accumulate && !args[i].tn && !args[i].bias_grad;
   const bool dma_call = dma_on && (call_rows >= dma_min_rows || (dma_fwd && fwd_only));
-  static const int dma_tall = getenv("MMDA_GEMM_DMA_TALL") ? atoi(getenv("MMDA_GEMM_DMA_TALL")) : 1;
+  // (OFF by default since the end of round 3: with the rest of the step as it is now the B=256 step measures 1.690 ms without the
+  //  class against 1.705 with it -- its 147 KB workgroups do not fit a CU beside a recurrent kernel's, and on the main stream they
+  //  are no faster than two 128-row workgroups per CU; MMDA_GEMM_DMA_TALL=1 switches it on)
+  static const int dma_tall = getenv("MMDA_GEMM_DMA_TALL") ? atoi(getenv("MMDA_GEMM_DMA_TALL")) : 0;
   static const int tall_stages = getenv("MMDA_GEMM_DMA_TALL_STAGES") ? atoi(getenv("MMDA_GEMM_DMA_TALL_STAGES")) : 3;
   auto class_of = [&](const mmda_gemm_bf16_args& a) {
     const int Ne = a.N + (a.bias_grad ? 1 : 0);

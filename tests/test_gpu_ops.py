@@ -107,9 +107,9 @@ def test_convert_bf16_16_byte_form(rows, cols):
                                    (300, 128, 1600), (8320, 2400, 300), (8200, 600, 1100), (8200, 300, 2400)])
 def test_gemm_bf16_operands_nt_bias(M, N, K):
     """C = A B^T + b + b2 on bf16 K-major operands: exact against fp32 matmul of the same bf16-rounded values (up to fp32
-    summation order), so the bar is the fp32 one.  The shapes with >= 8192 rows take the LDS-DMA pipelined kernel (round 3): 128 x 128
-    tiles for the short-K forward shape, 256 x 128 tiles (K >= 1024) for the input-gradient shapes, rows / columns / depth off the
-    tile grid."""
+    summation order), so the bar is the fp32 one.  The shapes with >= 8192 rows take the LDS-DMA pipelined kernel (round 3), rows /
+    columns / depth off the tile grid (128 x 128 tiles; the 256 x 128 class for K >= 1024 is off by default:
+    test_gemm_bf16_tall_class_in_a_fresh_process)."""
     from mmda_amd import ops
     torch.manual_seed(4)
     A = torch.randn(M, K); W = torch.randn(N, K) / math.sqrt(K); b = torch.randn(N); b2 = torch.randn(N)
@@ -911,6 +911,38 @@ def test_transpose_f32_multi():
     outs = ops.transpose_f32([m.to(dev()) for m in mats])
     for m, o in zip(mats, outs):
         assert torch.equal(o.cpu(), m.t().contiguous())
+
+
+def test_gemm_bf16_tall_class_in_a_fresh_process():
+    """The 256 x 128 tile class of the LDS-DMA GEMM (K >= 1024, M >= 512 in a call of >= 8192 rows) is off by default since the end of
+    round 3 (MMDA_GEMM_DMA_TALL=1 switches it on; read once per process, hence the subprocess): nt input-gradient shapes and a tn
+    weight-gradient shape with bias gradient and accumulation through it."""
+    import subprocess, sys
+    code = r'''
+import math, sys, torch
+sys.path.insert(0, %r)
+from mmda_amd import ops
+d = torch.device("cuda:0")
+rel = lambda a, b: float((a.cpu() - b).abs().max() / b.abs().max())
+torch.manual_seed(4)
+for M, N, K in [(8200, 600, 1100), (8200, 300, 2400)]:
+    A = torch.randn(M, K); W = torch.randn(N, K) / math.sqrt(K); b = torch.randn(N)
+    (Ap, _), (Wp, _) = ops.convert_bf16([(A.to(d), None, True, False), (W.to(d), None, True, False)])
+    ref = A.bfloat16().float() @ W.bfloat16().float().t() + b
+    out, = ops.gemm_bf16_grouped([dict(A=Ap, B=Wp, K=K, bias=b.to(d))])
+    assert rel(out, ref) < 1e-4, (M, N, K, rel(out, ref))
+# tn: C (M, N) += A^T B over K = 8320 rows, M = 2400 >= 512
+K, M, N = 8320, 2400, 304
+A = (torch.randn(K, M) / math.sqrt(K)).bfloat16(); Bm = torch.randn(K, N).bfloat16(); C0 = torch.randn(M, N)
+bg = torch.zeros(M)
+out, = ops.gemm_bf16_grouped([dict(A=A.to(d), B=Bm.to(d), M=M, N=N, K=K, tn=True, out=C0.clone().to(d), accumulate=True, bias_grad=bg.to(d))])
+ref = C0 + A.float().t() @ Bm.float()
+assert rel(out, ref) < 1e-4, rel(out, ref)
+print("ok")
+''' % ROOT
+    env = dict(os.environ, MMDA_GEMM_DMA_TALL="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("switches", [{"MMDA_XCD_LOCAL": "0"}, {"MMDA_XCD_LOCAL": "3"}, {"MMDA_LSTM_NO_QUAD": "1"},
