@@ -143,6 +143,10 @@ __device__ __forceinline__ float act_bwd_p(int act, float x, const mmda_act_para
   return x > 0.f ? 1.f : act_slope_p(act, p, idx);
 }
 
+// internal: two buffers cleared by one launch (optim.hip); the tail flag of the single-workgroup CMD launch (losses.hip)
+int mmda_zero2(float* a, int64_t na, float* b, int64_t nb, void* stream);
+bool mmda_loss_cmd_sets_flag(int B, int D);
+void mmda_loss_cmd_arm_flag(unsigned* flag, unsigned value);
 // internal: mmda_clamp_adam whose launch does not complete before *wait_flag reaches wait_value (optim.hip)
 int mmda_clamp_adam_wait(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float clip,
                          float grad_scale, int step, const unsigned* wait_flag, unsigned wait_value, unsigned* wait_err, void* stream);

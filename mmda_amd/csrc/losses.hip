@@ -480,8 +480,8 @@ __global__ __launch_bounds__(256) void cmd_kernel(const float* __restrict__ x, i
 // moments, gradient); cross-row reductions go through LDS.  cmd_kernel walks the rows serially per (tensor, column) with
 // one dependent global load per row and pass, which cost 41 us of the step for 48 KB of input.
 template <int CMD_RPT>                           // rows per thread: 4 (B <= 32) or 8 (B <= 64)
-__global__ __launch_bounds__(1024) void cmd_fast_kernel(const float* __restrict__ x, int64_t stride, int B, int D, float scale,
-                                                        float vscale, float* loss, float* dx, PairList pl, int nmom) {
+__device__ __forceinline__ void cmd_fast_body(const float* __restrict__ x, int64_t stride, int B, int D, float scale, float vscale,
+                                              float* loss, float* dx, const PairList& pl, int nmom) {
   extern __shared__ float sm[];
   float* P1 = sm;                                // [8][3][128]
   float* P2 = sm + 8 * 3 * 128;                  // [8][3][4][128]
@@ -603,6 +603,22 @@ __global__ __launch_bounds__(1024) void cmd_fast_kernel(const float* __restrict_
                       U[t][4] * 5.f * (d2 * d2 - mom[t][3]);
       dx[(int64_t)t * stride + (int64_t)r * D + c] = old[t][j] + gs * g;
     }
+}
+
+template <int CMD_RPT>
+// tail_flag (optional): set to tail_value when the (single) workgroup's stores are out -- the launch is the last of a stream's chain
+// and another stream's kernel waits for that word on the device (misa.hip: flag joins), instead of a one-thread launch behind it
+__global__ __launch_bounds__(1024) void cmd_fast_kernel(const float* __restrict__ x, int64_t stride, int B, int D, float scale,
+                                                        float vscale, float* loss, float* dx, PairList pl, int nmom,
+                                                        unsigned* tail_flag, unsigned tail_value) {
+  cmd_fast_body<CMD_RPT>(x, stride, B, D, scale, vscale, loss, dx, pl, nmom);
+  if (tail_flag) {                                  // launch-uniform
+    __syncthreads();                                // (every wave's stores have reached L2: vmcnt(0) in front of the barrier)
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __hip_atomic_store(tail_flag, tail_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // cmd_fast_kernel for any row count (B = 256 per GPU is BASELINE's data-parallel shape): same 128 columns x 8 row groups and the
@@ -1011,18 +1027,28 @@ extern "C" int mmda_loss_diff(const float* x, int64_t stride, int B, int D, floa
   return mmda_loss_diff_pairs(x, stride, 6, 6, pairs, B, D, scale, loss, dx, work, stream);
 }
 
+// internal (misa.hip): arm the NEXT mmda_loss_cmd* call of this thread to set *flag = value at the end of its launch -- honoured by the
+// single-workgroup form only (mmda_loss_cmd_sets_flag says whether a call of that shape will)
+static thread_local unsigned* g_cmd_tail_flag = nullptr;
+static thread_local unsigned g_cmd_tail_value = 0u;
+bool mmda_loss_cmd_sets_flag(int B, int D) { return D <= 128 && B <= 64; }
+void mmda_loss_cmd_arm_flag(unsigned* flag, unsigned value) { g_cmd_tail_flag = flag; g_cmd_tail_value = value; }
+
 extern "C" int mmda_loss_cmd_pairs(const float* x, int64_t stride, int nt, int np, const int* pairs_host, int n_moments, int B, int D,
                                    float scale, float value_scale, float* loss, float* dx, void* stream) {
+  unsigned* tflag = g_cmd_tail_flag;
+  const unsigned tvalue = g_cmd_tail_value;
+  g_cmd_tail_flag = nullptr;
   PairList pl;
   if (!x || B <= 0 || D <= 0 || n_moments < 1 || n_moments > 5 || !fill_pairs(pl, nt, np, pairs_host, 3)) return MMDA_EINVAL;
   if (nt <= 3 && D <= 128 && B <= 64) {
     const size_t lds_fast = sizeof(float) * (8 * 3 * 128 + 8 * 3 * 4 * 128 + 32);
     if (B <= 32)
       hipLaunchKernelGGL(cmd_fast_kernel<4>, dim3(1), dim3(1024), lds_fast, (hipStream_t)stream, x, stride, B, D, scale, value_scale,
-                         loss, dx, pl, n_moments);
+                         loss, dx, pl, n_moments, tflag, tvalue);
     else
       hipLaunchKernelGGL(cmd_fast_kernel<8>, dim3(1), dim3(1024), lds_fast, (hipStream_t)stream, x, stride, B, D, scale, value_scale,
-                         loss, dx, pl, n_moments);
+                         loss, dx, pl, n_moments, tflag, tvalue);
     MMDA_CHECK_LAUNCH("mmda_loss_cmd");
     return MMDA_OK;
   }

@@ -129,7 +129,7 @@ struct mmda_misa {
   // GEMM and the optimizer); word [3] tells the main stream it is there (a one-wave wait launch in front of the sums).
   int64_t esort = -1; int esort_valid = 0; unsigned esort_val = 0u;
   int64_t rec_part = -1;
-  int flag_join_ok = 0, fj1 = 0, fj2 = 0;
+  int flag_join_ok = 0, fj1 = 0, fj2 = 0, fj1_armed = 0;
   int ldR = 0;
   // cluster-exchange regions: at the front of the workspace, sized by B alone, so a change of T (every batch under the reference's
   // collate) neither moves nor clears them -- flags are monotonic epochs.  Cleared (on the caller's stream) only when the buffer
@@ -488,12 +488,15 @@ __global__ void flag_wait_kernel(const unsigned* flag, unsigned value, unsigned*
 __global__ void flag_set_kernel(unsigned* flag, unsigned value) {
   __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-// the side stream's chain ends here for the main stream: word `idx` is set behind it (flag join); ev_join is recorded too
-int side_flag_signal(mmda_misa* m, int idx) {
+// the side stream's chain ends here for the main stream: word `idx` is set behind it (flag join) -- or was, by the chain's last launch
+// itself (by_kernel) --; ev_join is recorded too
+int side_flag_signal(mmda_misa* m, int idx, bool by_kernel = false) {
   if (!m->side || !m->jflags) return MMDA_EINVAL;
   ++m->jval[idx];
-  hipLaunchKernelGGL(flag_set_kernel, dim3(1), dim3(1), 0, m->side, m->jflags + idx, m->jval[idx]);
-  MMDA_CHECK_LAUNCH("side_flag_signal");
+  if (!by_kernel) {
+    hipLaunchKernelGGL(flag_set_kernel, dim3(1), dim3(1), 0, m->side, m->jflags + idx, m->jval[idx]);
+    MMDA_CHECK_LAUNCH("side_flag_signal");
+  }
   if (hipEventRecord(m->ev_join, m->side) != hipSuccess) return MMDA_ELAUNCH;
   m->side_pending = 0;
   return MMDA_OK;
@@ -761,22 +764,33 @@ int eager_side_losses(mmda_misa* m, void* stream, bool hseq2_t) {
   // (large batches: the loss chain on the side stream is the longer one by far -- the weight transposes go to the main stream)
   if (!rc && m->wT_pending) rc = weight_transposes(m, B >= 128 ? stream : ss);
   (void)hseq2_t;                   // (the backward pass's operand copies are made by backward() itself: backward_only_jobs)
-  if (!rc) {
-    // (the forward stretches on the main stream STORE the seeds they own: clearing those here would race with them)
-    const int64_t end = m->seed_cls ? m->zero_cls : m->seed_recon ? m->zero_recon : m->zero_end;
-    if (hipMemsetAsync(WS(m->zero_begin), 0, sizeof(float) * (end - m->zero_begin), (hipStream_t)ss) != hipSuccess) rc = MMDA_ELAUNCH;
-  }
-  float* L = WS(m->losses);
-  if (!rc) rc = mmda_loss_diff(WS(m->x6), BH, B, hs, c.diff_weight, L + 1, WS(m->d_x6), WS(m->diff_work), ss);
-  if (!rc && c.use_cmd_sim) rc = mmda_loss_cmd(WS(m->x6 + 3 * BH), BH, B, hs, c.sim_weight, L + 2, WS(m->d_x6 + 3 * BH), ss);
+  // (the forward stretches on the main stream STORE the seeds they own: clearing those here would race with them)
+  const int64_t zend = m->seed_cls ? m->zero_cls : m->seed_recon ? m->zero_recon : m->zero_end;
   // The gradient bucket (43 MB, 11 us) is cleared on the MAIN stream behind the fork: since the row-local stretches were fused the
   // side stream's loss chain (72 us at B=32), not the main stream's fusion block (55 us), is what the join at the end of forward() waits
   // for.  (Nothing on either stream touches the bucket before the backward pass; MMDA_ZERO_GRAD_SIDE=1: the old place.)
   // ... unless the main stream will not wait for this chain before the LayerNorm-1 stretch of the backward pass (flag join on the
-  // device, small batches: see mmda_misa::jflags) -- the chain then has two launches of slack and the clear comes back here.
+  // device, small batches: see mmda_misa::jflags) -- the chain then has two launches of slack and the clear comes back here, in ONE
+  // launch with the activation-gradient region, at the head of the chain.
   static const int zg_side = getenv("MMDA_ZERO_GRAD_SIDE") ? atoi(getenv("MMDA_ZERO_GRAD_SIDE")) : -1;
-  const bool zg_here = zg_side >= 0 ? zg_side != 0 : (m->flag_join_ok && m->seed_recon && m->seed_cls && B <= 64);
-  if (!rc && m->zero_grad_pending) { rc = mmda_misa_zero_grad(m, zg_here ? ss : stream); m->zero_grad_pending = 0; }
+  const bool fj_plan = m->flag_join_ok && m->seed_recon && m->seed_cls && ss != stream && m->jflags;      // (what forward()'s end will decide)
+  const bool zg_here = zg_side >= 0 ? zg_side != 0 : (fj_plan && B <= 64);
+  if (!rc && zg_here && m->zero_grad_pending) {
+    rc = mmda_zero2(WS(m->zero_begin), zend - m->zero_begin, m->G, m->flat, ss);
+    m->zero_grad_pending = 0;
+  } else if (!rc) {
+    if (hipMemsetAsync(WS(m->zero_begin), 0, sizeof(float) * (zend - m->zero_begin), (hipStream_t)ss) != hipSuccess) rc = MMDA_ELAUNCH;
+  }
+  float* L = WS(m->losses);
+  if (!rc) rc = mmda_loss_diff(WS(m->x6), BH, B, hs, c.diff_weight, L + 1, WS(m->d_x6), WS(m->diff_work), ss);
+  // the chain's last launch sets the flag-join word itself where it can (single-workgroup CMD: no one-thread launch behind it)
+  m->fj1_armed = 0;
+  if (!rc && c.use_cmd_sim && fj_plan && mmda_loss_cmd_sets_flag(B, hs)) {
+    mmda_loss_cmd_arm_flag(m->jflags + 0, m->jval[0] + 1);
+    m->fj1_armed = 1;
+  }
+  if (!rc && c.use_cmd_sim) rc = mmda_loss_cmd(WS(m->x6 + 3 * BH), BH, B, hs, c.sim_weight, L + 2, WS(m->d_x6 + 3 * BH), ss);
+  if (!rc && m->zero_grad_pending) { rc = mmda_misa_zero_grad(m, stream); m->zero_grad_pending = 0; }
   m->eager_done = 1;
   return rc;
 }
@@ -1242,10 +1256,11 @@ extern "C" int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float
     if (!x.rc) x.rc = weight_transposes(m, ss);
   }
   if (!x.rc && m->flag_join_ok && m->seed_recon && m->seed_cls && m->side_pending && m->use_side && m->jflags) {
-    x.rc = side_flag_signal(m, 0);             // (see mmda_misa::jflags: fused_bwd_a_kernel waits for the loss chain)
-    m->fj1 = x.rc ? 0 : 1;
+    x.rc = side_flag_signal(m, 0, m->fj1_armed != 0);      // (see mmda_misa::jflags: fused_bwd_a_kernel waits for the loss chain)
+    m->fj1 = x.rc ? 0 : 1; m->fj1_armed = 0;
     return x.rc;
   }
+  if (m->fj1_armed) return MMDA_ELAUNCH;       // (the CMD launch was armed on the same condition: cannot happen)
   if (!x.rc) x.rc = side_join(m, stream);      // (the side stream finished long ago: this only orders later work behind it)
   return x.rc;
 }

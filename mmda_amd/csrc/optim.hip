@@ -94,6 +94,16 @@ __global__ __launch_bounds__(256) void clamp_rmsprop_kernel(float* p, const floa
   }
 }
 
+// two buffers cleared by one launch (16-byte stores; counts in floats, multiples of 4, 16-byte aligned bases)
+__global__ __launch_bounds__(256) void zero2_kernel(float4* a, int64_t na4, float4* b, int64_t nb4) {
+  const float4 z = {0.f, 0.f, 0.f, 0.f};
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < na4 + nb4; i += stride) {
+    if (i < na4) a[i] = z;
+    else b[i - na4] = z;
+  }
+}
+
 __global__ void clamp_kernel(float* g, int64_t n, float clip) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     g[i] = fminf(fmaxf(g[i], -clip), clip);
@@ -122,6 +132,24 @@ int mmda_clamp_adam_wait(float* p, const float* g, float* m, float* v, int64_t n
   hipLaunchKernelGGL(clamp_adam_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, beta1, beta2, eps, clip,
                      grad_scale, step_size, inv_bc2_sqrt, wait_flag, wait_value, wait_err);
   MMDA_CHECK_LAUNCH("mmda_clamp_adam");
+  return MMDA_OK;
+}
+
+// internal (misa.hip): a[0 .. na) = b[0 .. nb) = 0 in ONE launch (two memsets are two launches of ~5 us each on a latency-bound chain)
+int mmda_zero2(float* a, int64_t na, float* b, int64_t nb, void* stream) {
+  if (na < 0 || nb < 0 || (na && !a) || (nb && !b)) return MMDA_EINVAL;
+  if (((uintptr_t)a | (uintptr_t)b) & 15 || (na & 3) || (nb & 3)) {           // odd shapes: the runtime's fills
+    if (na && hipMemsetAsync(a, 0, sizeof(float) * na, (hipStream_t)stream) != hipSuccess) return MMDA_ELAUNCH;
+    if (nb && hipMemsetAsync(b, 0, sizeof(float) * nb, (hipStream_t)stream) != hipSuccess) return MMDA_ELAUNCH;
+    return MMDA_OK;
+  }
+  const int64_t n4 = (na + nb) >> 2;
+  if (n4 == 0) return MMDA_OK;
+  int64_t blocks = (n4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(zero2_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<float4*>(a), na >> 2,
+                     reinterpret_cast<float4*>(b), nb >> 2);
+  MMDA_CHECK_LAUNCH("mmda_zero2");
   return MMDA_OK;
 }
 
