@@ -507,6 +507,13 @@ int mmda_misa_forward(mmda_misa* m, const int64_t* t_ids, const float* v, const 
 /* solver.py:163-181: the six losses into `losses`; with_grads != 0 also zeroes and seeds the d_* activation gradients
  * with the weighted loss gradients (loss.backward() seeds). emo (B,ncls) fp32. */
 int mmda_misa_losses(mmda_misa* m, const float* emo, int with_grads, void* stream);
+/* Data-parallel "global statistics" mode (no reference counterpart: the reference is single-device, where DiffLoss
+ * functions.py:64-76, CMD :89-108 and the confidence loss solver.py:451-462 see the whole batch).  on != 0: the next mmda_misa_losses
+ * (with_grads) does NOT clear the activation gradients and does not compute DiffLoss / CMD / conf -- the caller has, behind
+ * mmda_misa_zero_act_grads, on the all-gathered tensors of every rank with mmda_loss_diff / mmda_loss_cmd / mmda_loss_conf, added
+ * the sums into losses[1], [2], [4] and this rank's gradient rows (times the world size: the exchange averages) into d_x6 / d_scores /
+ * d_tcp (mmda_misa_tensor_offset).  cls, recon and the weighted total are added as usual. */
+int mmda_misa_set_external_batch_losses(mmda_misa* m, int on);
 /* solver.py:183 loss.backward(): from d_scores/d_tcp/d_x6/d_orig/d_recon/d_dom to every parameter gradient
  * (ACCUMULATED into the bound grad bucket: zero it first with mmda_misa_zero_grad).  External seeds (the autograd
  * compat path) are whatever the caller left in the d_* buffers. */

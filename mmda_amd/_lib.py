@@ -207,6 +207,7 @@ SIGNATURES = {
     "mmda_misa_cluster_status": (_I, [_P, C.POINTER(_I)]),
     "mmda_misa_forward": (_I, [_P, _P, _P, _P, _P, _I, _U64, _P]),
     "mmda_misa_losses": (_I, [_P, _P, _I, _P]),
+    "mmda_misa_set_external_batch_losses": (_I, [_P, _I]),
     "mmda_misa_backward": (_I, [_P, _P, _P, _P, _P, _P]),
     "mmda_misa_zero_grad": (_I, [_P, _P]),
     "mmda_misa_zero_act_grads": (_I, [_P, _P]),

@@ -63,7 +63,7 @@ DEFAULTS = dict(
     reverse_grad_weight=1.0, activation="leakyrelu", threshold=0.35, model="MISA",
     # added for the MI355X build (not reference flags)
     visual_size=35, acoustic_size=74, vocab_size=20000, precision="bf16", seq_len=50, pretrained_emb=None,
-    fusion_fp8=False,
+    fusion_fp8=False, dp_global_stats=False,
 )
 
 

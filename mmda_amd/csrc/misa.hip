@@ -107,6 +107,11 @@ struct mmda_misa {
   // train_step: the losses that read only the private/shared representations (diff, CMD) are issued by forward() on the side
   // stream as soon as those exist, beside the transformer layer and the heads; mmda_misa_losses() then adds the rest
   int eager_losses = 0, eager_done = 0;
+  // Data-parallel "global statistics" mode (mmda_misa_set_external_batch_losses): the batch-statistic losses -- DiffLoss, CMD and the
+  // confidence loss -- were computed by the caller on the batch of ALL ranks (all-gathered inputs, the same loss entry points), their
+  // sums written into losses[1], [2], [4] and their gradient rows of THIS rank added into d_x6 / d_scores / d_tcp behind
+  // mmda_misa_zero_act_grads: mmda_misa_losses then only adds what is a mean over samples (cls, recon) and the weighted total.
+  int ext_batch_losses = 0;
   // Loss seeds (training step, fused row-local stretches): the forward stretches store the gradient seeds of the reconstruction loss
   // (d_recon, d_orig) and -- without ConfidNet, whose loss adds into the same buffer -- of the classification loss (d_scores) where
   // they produce recon / scores, so the launch that computes cls / conf / recon and the weighted total has no gradient to seed and
@@ -680,6 +685,11 @@ extern "C" int64_t mmda_misa_early_grad_floats(const mmda_misa* m) {
 extern "C" int mmda_misa_wait_early_grads(mmda_misa* m, void* stream) {
   if (!m || !m->early_valid || !m->ev_early) return MMDA_EINVAL;
   if (hipStreamWaitEvent((hipStream_t)stream, m->ev_early, 0) != hipSuccess) return MMDA_ELAUNCH;
+  return MMDA_OK;
+}
+extern "C" int mmda_misa_set_external_batch_losses(mmda_misa* m, int on) {
+  if (!m) return MMDA_EINVAL;
+  m->ext_batch_losses = on ? 1 : 0;
   return MMDA_OK;
 }
 extern "C" int mmda_misa_set_inference(mmda_misa* m, int forward_only) {
@@ -1281,7 +1291,8 @@ extern "C" int mmda_misa_losses(mmda_misa* m, const float* emo, int with_grads, 
   hipStream_t s = (hipStream_t)stream;
   int rc = MMDA_OK;
   float* L = WS(m->losses);
-  const bool eager = m->eager_done && with_grads;        // forward() already cleared the region and ran diff (+ CMD) on the side stream
+  const bool ext = m->ext_batch_losses && with_grads && c.use_cmd_sim;      // the caller did (see mmda_misa::ext_batch_losses)
+  const bool eager = (m->eager_done || ext) && with_grads;        // forward() already cleared the region and ran diff (+ CMD) on the side stream
   m->eager_done = 0;
   const bool s_recon = eager && m->seed_recon, s_cls = eager && m->seed_cls;      // seeds the forward stretches stored already
   m->seed_recon = m->seed_cls = 0;
@@ -1308,7 +1319,7 @@ extern "C" int mmda_misa_losses(mmda_misa* m, const float* emo, int with_grads, 
     return MMDA_OK;
   }
   return mmda_loss_misc(WS(m->scores), WS(m->tcp), emo, B, c.ncls, (with_grads && !s_cls) ? WS(m->d_scores) : nullptr,
-                        (with_grads && !s_cls) ? WS(m->d_tcp) : nullptr, c.ncls == 6, with_grads && c.use_confidNet, c.conf_weight,
+                        (with_grads && !s_cls) ? WS(m->d_tcp) : nullptr, c.ncls == 6 && !ext, with_grads && c.use_confidNet && !ext, c.conf_weight,
                         WS(m->recon), WS(m->orig), 3 * BH, c.recon_weight, (with_grads && !s_recon) ? WS(m->d_recon) : nullptr,
                         (with_grads && !s_recon) ? WS(m->d_orig) : nullptr, L, c.diff_weight, c.sim_weight, c.recon_weight, c.conf_weight,
                         c.use_confidNet, stream);

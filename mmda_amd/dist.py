@@ -22,7 +22,7 @@ import torch.distributed as dist
 
 class DataParallelSync:
     def __init__(self, group=None, bucket_mb: float = 0.0, sparse_embedding=None, overlap: bool = True, equal_shapes: bool = False,
-                 force_collectives: bool = False):
+                 force_collectives: bool = False, global_stats: bool = False):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
@@ -41,6 +41,15 @@ class DataParallelSync:
         # test hook: a ONE-rank group still walks the whole exchange (communication stream, early event wait, early clip + Adam,
         # all-reduces, both all-gathers, segment sum) instead of returning at once -- the way to run the RCCL branch on a box with one GPU
         self.force_collectives = bool(force_collectives)
+        # "global statistics" (optional mode): DiffLoss (batch mean + Gram contracted over the batch, reference
+        # utils/functions.py:64-76), CMD (batch moments, :89-108) and the confidence loss (per-class nnz and batch softmax,
+        # solver.py:451-462) are functions of the WHOLE batch, so the mean of the ranks' shard gradients is not the gradient of the
+        # global-batch loss.  Default (False): DDP semantics -- every rank is the reference at batch_size = B_local.  True: the
+        # model's training step gathers the 128-wide utterance vectors (and scores / tcp / labels) of all ranks, evaluates those three
+        # losses on the gathered batch with the same loss kernels, and back-propagates its own rows of their gradients (times the world
+        # size: the exchange averages), so world x B_local behaves like ONE batch (mmda_amd/models.py: MISA._global_stats_step).  A
+        # fidelity mode: the step is no longer one native call, and the gathered losses run on every rank.
+        self.global_stats = bool(global_stats)
         self._comm = None
         # Optional optimizer hook for the early prefix: `early_step(n_floats, stream)` is called on the communication stream right behind
         # the early all-reduce (the prefix's gradients are then final and summed), and `early_stepped` tells the caller how many leading
@@ -124,6 +133,14 @@ class DataParallelSync:
             out = torch.empty(flat_shape, dtype=t.dtype, device=t.device)
             dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
         return out.view((self.world,) + tuple(t.shape))
+
+    def gather_rows(self, t: torch.Tensor, dim: int = 0) -> torch.Tensor:
+        """The ranks' tensors (equal shapes) concatenated along `dim` in rank order -- rank r's rows at [r * n, (r + 1) * n) --, on
+        every rank, contiguous."""
+        g = self._all_gather(t.contiguous())                      # (world, *t.shape)
+        if dim == 0:
+            return g.reshape((self.world * t.shape[0],) + tuple(t.shape[1:]))
+        return torch.cat(list(g.unbind(0)), dim=dim).contiguous()
 
     def _use_sparse(self, flat_grads, dense_floats, model) -> bool:
         if self.sparse_embedding is False or model is None or dense_floats >= flat_grads.numel():

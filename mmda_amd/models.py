@@ -446,10 +446,14 @@ class MISA(nn.Module):
             self._step += 1                        # (a custom optimizer counts its own steps on the same counter)
         s = _lib.stream_ptr()
         fused_adam = do_adam and grad_sync is None and not custom
-        _lib.check(self._lib.mmda_misa_train_step(self._h, t.data_ptr(), v.data_ptr(), a.data_ptr(), len_dev.data_ptr(),
-                                                  emo.data_ptr(), int(training), seed, int(fused_adam), lr, clip, max(self._step, 1), s),
-                   "mmda_misa_train_step")
-        self._fwd_id += 1
+        gs_owner = getattr(grad_sync, "__self__", None)
+        if gs_owner is not None and getattr(gs_owner, "global_stats", False) and (gs_owner.world > 1 or gs_owner.force_collectives):
+            self._global_stats_step(t, v, a, len_dev, emo, training, seed, gs_owner)
+        else:
+            _lib.check(self._lib.mmda_misa_train_step(self._h, t.data_ptr(), v.data_ptr(), a.data_ptr(), len_dev.data_ptr(),
+                                                      emo.data_ptr(), int(training), seed, int(fused_adam), lr, clip, max(self._step, 1), s),
+                       "mmda_misa_train_step")
+            self._fwd_id += 1
         self._last = dict(t=t, v=v, a=a, len_dev=len_dev, emo=emo)
         if custom:
             scale = 1.0
@@ -488,6 +492,56 @@ class MISA(nn.Module):
                            "adam(rest)")
             else:
                 _lib.check(self._lib.mmda_misa_adam_step(self._h, lr, clip, float(scale), self._step, s), "adam_step")
+
+    def _global_stats_step(self, t, v, a, len_dev, emo, training: bool, seed: int, dp) -> None:
+        """forward + losses + backward of one step with the batch-statistic losses on the batch of ALL ranks (DataParallelSync
+        global_stats=True).  Reference: on one device DiffLoss (utils/functions.py:64-76), CMD (:89-108) and the
+        confidence loss (solver.py:451-462) see the whole batch; here every rank gathers the (6, B, hs) private / shared utterance
+        vectors -- and scores, tcp, labels for the confidence loss -- of all ranks, runs the SAME loss entry points on the gathered
+        batch, keeps the loss sums and adds ITS rows of the gradients, times the world size (the gradient exchange averages over
+        ranks; cls and recon are means over samples, for which the average of the shard gradients already is the global gradient).
+        Equal batch shapes on all ranks."""
+        lib, h, cfg = self._lib, self._h, self.config
+        if not cfg.use_cmd_sim:
+            raise NotImplementedError("global_stats: the CMD similarity branch only (config.use_cmd_sim)")
+        s = _lib.stream_ptr()
+        W, r = int(dp.world), int(dp.rank)
+        _lib.check(lib.mmda_misa_zero_grad(h, s), "zero_grad")
+        self._forward_raw(t, v, a, len_dev, training, seed, inference=False)
+        _lib.check(lib.mmda_misa_zero_act_grads(h, s), "zero_act_grads")
+        B, _ = self._ws_shape
+        hs, nc = int(cfg.hidden_size), int(cfg.num_classes)
+        Bg = W * B
+        L = self._ws_view("losses", (8,))
+        X = dp.gather_rows(self._ws_view("x6", (6, B, hs)), dim=1)                    # (6, W B, hs): rank r at rows [r B, (r + 1) B)
+        dX = torch.zeros_like(X)
+        work = torch.empty(int(lib.mmda_loss_diff_work_floats(Bg, hs)), dtype=torch.float32, device=X.device)
+        _lib.check(lib.mmda_loss_diff(X.data_ptr(), Bg * hs, Bg, hs, float(getattr(cfg, "diff_weight", 0.3)), L.data_ptr() + 4, dX.data_ptr(),
+                                      work.data_ptr(), s), "loss_diff(global)")
+        _lib.check(lib.mmda_loss_cmd(X[3:].data_ptr(), Bg * hs, Bg, hs, float(getattr(cfg, "sim_weight", 0.7)), L.data_ptr() + 8,
+                                     dX[3:].data_ptr(), s), "loss_cmd(global)")
+        self._ws_view("d_x6", (6, B, hs)).add_(dX[:, r * B:(r + 1) * B], alpha=float(W))
+        if nc == 6:
+            S = dp.gather_rows(self._ws_view("scores", (B, nc)))
+            Tc = dp.gather_rows(self._ws_view("tcp", (B, 6)))
+            E = dp.gather_rows(emo)
+            with_g = bool(getattr(cfg, "use_confidNet", False))
+            dS = torch.zeros_like(S) if with_g else None
+            dT = torch.zeros_like(Tc) if with_g else None
+            _lib.check(lib.mmda_loss_conf(S.data_ptr(), Tc.data_ptr(), E.data_ptr(), Bg, nc, float(getattr(cfg, "conf_weight", 0.3)),
+                                          L.data_ptr() + 16, dS.data_ptr() if with_g else None, dT.data_ptr() if with_g else None, s),
+                       "loss_conf(global)")
+            if with_g:
+                self._ws_view("d_scores", (B, nc)).add_(dS[r * B:(r + 1) * B], alpha=float(W))
+                self._ws_view("d_tcp", (B, 6)).add_(dT[r * B:(r + 1) * B], alpha=float(W))
+        _lib.check(lib.mmda_misa_set_external_batch_losses(h, 1), "set_external_batch_losses")
+        try:
+            _lib.check(lib.mmda_misa_losses(h, emo.data_ptr(), 1, s), "mmda_misa_losses")
+        finally:
+            lib.mmda_misa_set_external_batch_losses(h, 0)
+        _lib.check(lib.mmda_misa_backward(h, t.data_ptr(), v.data_ptr(), a.data_ptr(), len_dev.data_ptr(), s), "mmda_misa_backward")
+        # (keep the gathered tensors alive until the stream has run the launches that read them)
+        self._gs_keep = (X, dX, work)
 
     # ------------------------------------------------------------------ early part of the gradient bucket (data parallel)
     def early_grad_floats(self) -> int:

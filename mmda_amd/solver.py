@@ -63,7 +63,9 @@ class Solver(object):
             if hasattr(self.optimizer, "attach"):
                 self.optimizer.attach(self.model)
         if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-            self.dp = DataParallelSync()
+            # config.dp_global_stats (not a reference option: the reference is single-device): the batch-statistic losses on the
+            # batch of all ranks instead of DDP semantics (mmda_amd/dist.py)
+            self.dp = DataParallelSync(global_stats=bool(getattr(cfg, "dp_global_stats", False)))
             self.dp.broadcast_parameters(self.model)
         return self
 

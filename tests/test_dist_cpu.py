@@ -179,3 +179,70 @@ def test_bench_launches_its_own_ranks():
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env2,
                         capture_output=True, text=True, timeout=300)
     assert r2.returncode == 0 and len([x for x in r2.stdout.splitlines() if x.startswith("{")]) == 1 and not r2.stderr.strip().startswith("{")
+
+
+def _global_stats_worker(rank, world, port, q):
+    """The protocol of DataParallelSync(global_stats=True) (mmda_amd/models.py: MISA._global_stats_step) with the oracle's loss
+    functions standing in for the HIP loss kernels: gather the ranks' rows, evaluate the batch-statistic loss on the gathered batch,
+    back-propagate THIS rank's rows of its gradient times the world size, average the parameter gradients."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from types import SimpleNamespace
+        from oracle import misa_oracle as orc
+        dp = DataParallelSync(global_stats=True)
+        B, D = 5, 16
+        W = torch.randn(6, D, D, generator=torch.Generator().manual_seed(7)).requires_grad_(True)      # the "model": six D x D maps
+        u = torch.randn(B, D, generator=torch.Generator().manual_seed(50 + rank))                      # this rank's inputs
+
+        def x6_of(inp, Wm):
+            return torch.sigmoid(torch.einsum("bd,kde->kbe", inp, Wm))                                 # (6, B, D)
+
+        def batch_losses(x6):
+            o = SimpleNamespace(utt_private_t=x6[0], utt_private_v=x6[1], utt_private_a=x6[2], utt_shared_t=x6[3], utt_shared_v=x6[4],
+                                utt_shared_a=x6[5])
+            return 0.3 * orc.diff_loss(o) + 0.7 * orc.cmd_loss(o), x6.mean()                           # (batch-statistic, per-sample mean)
+
+        x6 = x6_of(u, W)
+        X = dp.gather_rows(x6.detach(), dim=1).requires_grad_(True)                                    # (6, world B, D)
+        ok_rows = torch.equal(X[:, rank * B:(rank + 1) * B], x6.detach())
+        Lg, _ = batch_losses(X)
+        Lg.backward()
+        mine = X.grad[:, rank * B:(rank + 1) * B] * world                                              # this rank's rows, times world
+        (x6 * mine).sum().backward(retain_graph=True)                                                  # into dW through the local graph
+        x6.mean().backward()                                                                           # the per-sample-mean part
+        g = W.grad.reshape(-1).clone()
+        scale = dp.sync(g, g.numel())
+        got = g * scale
+        # one "device": the same losses on the concatenated batch
+        W1 = W.detach().clone().requires_grad_(True)
+        U = torch.cat([torch.randn(B, D, generator=torch.Generator().manual_seed(50 + r)) for r in range(world)], 0)
+        Lb, Lm = batch_losses(x6_of(U, W1))
+        (Lb + Lm).backward()
+        ref = W1.grad.reshape(-1)
+        q.put((rank, ok_rows, float((got - ref).abs().max() / ref.abs().max()), float(Lg), float(Lb)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_global_statistics_protocol_world2():
+    """SURVEY.md 8e's optional mode, host side: with the gathered rows, `own rows x world` and the averaging exchange, two ranks give
+    the gradient (and the loss) of ONE batch of both shards."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_global_stats_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok_rows, err, Lg, Lb in res:
+        assert ok_rows
+        assert err < 1e-5, err
+        assert abs(Lg - Lb) < 1e-6 * abs(Lb) + 1e-7

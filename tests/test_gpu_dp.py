@@ -247,3 +247,86 @@ def test_one_rank_rccl_group_walks_the_whole_exchange(precision):
                 np.testing.assert_allclose(sd[k], plain[k], rtol=0, atol=2e-6, err_msg=k)
             else:
                 np.testing.assert_array_equal(sd[k], plain[k], err_msg=f"{form}: {k}")
+
+
+def _global_stats_worker(rank, world, port, q, confid):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import misa_oracle as orc
+        from mmda_amd import make_config, MISA
+        from mmda_amd.dist import DataParallelSync
+        cfg = orc.default_config(vocab_size=120, use_confidNet=confid)
+        m = MISA(make_config(precision="fp32", device="cuda:0", **vars(cfg)))
+        m.load_state_dict(orc.synth_params(cfg, 21))
+        m.to("cuda:0")
+        dp = DataParallelSync(overlap=True, global_stats=True)
+        batch = orc.synth_batch(cfg, 8, 9, 60 + rank, ragged=True)
+        d = {k: (v.to("cuda:0") if k != "l" else v) for k, v in batch.items()}
+        # the global-statistics step (gathers inside), then the gradient exchange by hand so that the averaged bucket can be looked at
+        m.train_step(d["t"], d["v"], d["a"], d["l"], d["emo"], lr=1e-3, clip=1.0, training=False, do_adam=False, grad_sync=dp.sync)
+        L = m.read_losses()
+        scale = dp.sync(m._G, m._dense_floats, m)
+        torch.cuda.synchronize()
+        layout = {k: (off, tuple(shape)) for k, (off, shape) in m._layout.items()}
+        q.put((rank, scale, m._G.detach().cpu().numpy().copy(), L, layout))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("confid", [False, True], ids=["default", "confidnet"])
+def test_two_rank_global_statistics_step_is_the_step_on_the_concatenated_batch(confid):
+    """DataParallelSync(global_stats=True) (SURVEY.md 8e's optional mode): DiffLoss, CMD and the confidence loss are evaluated on the
+    batch of ALL ranks.  Two ranks of B = 8 on one GPU: the exchanged (averaged) gradient bucket must be the oracle's gradient of ONE
+    step on the concatenated batch of 16 -- every tensor to the fp32 bar -- and the DiffLoss / CMD / conf sums every rank reports must
+    be that batch's.  (With the default DDP semantics the same comparison fails: the mean of shard gradients of a batch-statistic loss
+    is not the gradient of the global loss -- checked below on the oracle itself.)"""
+    from oracle import misa_oracle as orc
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_global_stats_worker, args=(r, world, port, q, confid)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, scale, G, L, layout = q.get(timeout=150)
+        res[rank] = (scale, G, L)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    cfg = orc.default_config(vocab_size=120, use_confidNet=confid)
+    P = orc.synth_params(cfg, 21)
+    shards = [orc.synth_batch(cfg, 8, 9, 60 + r, ragged=True) for r in range(world)]
+    whole = {k: torch.cat([s[k] for s in shards], dim=(0 if k in ("l", "emo") else 1)) for k in shards[0]}
+    _, Lw, Gw = orc.loss_and_grads(P, cfg, whole)
+    Gs = [orc.loss_and_grads(P, cfg, s)[2] for s in shards]
+    assert res[0][0] == 0.5
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    G0 = res[0][1] * res[0][0]
+    worst_ddp = 0.0
+    for k, (off, shape) in layout.items():
+        if Gw[k] is None:
+            continue
+        ref = Gw[k].numpy().ravel().astype(np.float64)
+        got = G0[off:off + ref.size].astype(np.float64)
+        ddp = ((Gs[0][k] + Gs[1][k]) / 2).numpy().ravel().astype(np.float64)
+        if k.endswith("self_attn.in_proj_bias"):
+            hs = cfg.hidden_size
+            keep = np.ones(3 * hs, bool); keep[hs:2 * hs] = False
+            ref, got, ddp = ref[keep], got[keep], ddp[keep]
+        nr = np.linalg.norm(ref)
+        if nr == 0:
+            continue
+        assert np.linalg.norm(got - ref) / nr < 2e-4, (k, np.linalg.norm(got - ref) / nr)
+        worst_ddp = max(worst_ddp, np.linalg.norm(ddp - ref) / nr)
+    assert worst_ddp > 1e-2          # ... which the shard-mean gradient is NOT (the reason the mode exists)
+    for rnk in range(world):
+        L = res[rnk][2]
+        for name, ref in (("diff", Lw.diff), ("sim", Lw.sim), ("conf", Lw.conf)):
+            ref = float(ref.detach())
+            assert abs(L[name] - ref) < 1e-4 * abs(ref) + 1e-7, (name, L[name], ref)
