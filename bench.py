@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--confidnet", type=int, default=0)
     ap.add_argument("--rnncell", default="lstm", choices=["lstm", "gru"], help="config.rnncell (the headline config is lstm)")
     ap.add_argument("--fp8-fusion", type=int, default=0, help="BASELINE configs[4]: the fusion layer's feed-forward products on block-scaled fp8 (forward)")
+    ap.add_argument("--global-stats", type=int, default=0, help="N > 1: DiffLoss / CMD / conf on the batch of all ranks (config.dp_global_stats; the headline runs keep DDP semantics)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streaming-recurrence", action="store_true", help="bf16: stream W_hh from L2 per step instead of LDS-resident")
     ap.add_argument("--cpu-steps", type=int, default=0, help="0 = pick a count that takes ~10-30 s")
@@ -116,7 +117,7 @@ def main():
     torch.manual_seed(0)
     cfg = make_config(vocab_size=args.vocab, precision=args.precision, device=str(dev), batch_size=args.batch,
                       seq_len=args.seq_len, use_confidNet=bool(args.confidnet), rnncell=args.rnncell, pretrained_emb=torch.randn(args.vocab, 300),
-                      fusion_fp8=bool(args.fp8_fusion))
+                      fusion_fp8=bool(args.fp8_fusion), dp_global_stats=bool(args.global_stats))
     solver = Solver(cfg, cfg, cfg, None, None, None, is_train=True).build()
     model = solver.model
     model.train()
@@ -231,7 +232,7 @@ def main():
                                f"{'ragged' if args.ragged else 'full'} lengths",
                    "global_batch": args.batch * world, "seq_len": args.seq_len,
                    "parallelism": f"dp{world}" if world > 1 else "single", "use_confidNet": bool(args.confidnet),
-                   "rnncell": args.rnncell},
+                   "rnncell": args.rnncell, "dp_global_stats": bool(args.global_stats) and world > 1},
         "gflop_per_sample": 1.184 if args.seq_len == 50 else round(3 * (7736080 * args.seq_len + 7832576) / 1e9, 3),
         "roofline": roofline,
         "roofline_serial_chain": roofline_chain,
