@@ -497,7 +497,9 @@ int mmda_misa_wait_early_grads(mmda_misa* m, void* stream);
 /* 1 (default) = weight-gradient GEMMs run on an internal side stream underneath the recurrent kernels (joined before
  * mmda_misa_backward returns control of `stream`); 0 = everything on `stream` */
 int mmda_misa_set_overlap(mmda_misa* m, int side_stream);
-/* *aborted_host = 1 if a cluster exchange ever timed out (results after that are invalid); synchronous D2H, off the step path */
+/* *aborted_host: bit 0 = a cluster exchange of a recurrence ever timed out, bit 1 = a kernel of the fused training step ever timed
+ * out waiting on the device for the other stream's chain (flag joins: e.g. under a tool that serialises dispatches -- run those with
+ * MMDA_FLAG_JOIN=0 MMDA_SORT_EARLY=0); results after either are invalid.  Synchronous D2H, off the step path */
 int mmda_misa_cluster_status(const mmda_misa* m, int* aborted_host);
 
 /* models.py:282-285 forward.  t_ids (T,B) int64, v (T,B,d_v), a (T,B,d_a) device; lengths (B) int32 device.

@@ -704,7 +704,7 @@ extern "C" int mmda_misa_cluster_status(const mmda_misa* m, int* aborted_host) {
   if (m->jflags) {                          // a flag join timed out (see mmda_misa::jflags)
     unsigned w = 0;
     if (hipMemcpy(&w, m->jflags + 2, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) return MMDA_ELAUNCH;
-    if (w) *aborted_host = 1;
+    if (w) *aborted_host |= 2;                 // (bit 1: a stream-to-stream flag wait, not a recurrence)
   }
   for (int i = 0; i < 3; ++i) {
     if (m->mod[i].xchg < 0) continue;

@@ -620,6 +620,7 @@ class MISA(nn.Module):
         flag = ctypes.c_int(0)
         _lib.check(self._lib.mmda_misa_cluster_status(self._h, ctypes.byref(flag)), "cluster_status")
         self._abort_seen = self._abort_seen or bool(flag.value)
+        self._abort_bits = getattr(self, "_abort_bits", 0) | int(flag.value)
         return self._abort_seen
 
     def check_cluster(self, where: str = ""):
@@ -637,6 +638,9 @@ class MISA(nn.Module):
             what = ("non-finite values reached a recurrence (diverged run: NaN / inf in the losses or parameters), which its data-tagged "
                     "hand-off reports as a cluster time-out" if nonfinite else
                     "a resident-weights recurrence timed out waiting for its workgroup cluster")
+            if not nonfinite and (getattr(self, "_abort_bits", 0) & 2):
+                what = ("a kernel of the fused training step timed out waiting on the device for the side stream's chain (flag join): are "
+                        "kernel dispatches being serialised (profiler counters)?  Run such tools with MMDA_FLAG_JOIN=0 MMDA_SORT_EARLY=0")
             raise _lib.MMDAError(what + (f" ({where})" if where else "") + ": results since then are invalid")
 
     def set_recurrence(self, resident_weights: bool):
