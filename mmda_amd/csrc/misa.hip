@@ -1890,7 +1890,10 @@ extern "C" int mmda_misa_backward(mmda_misa* m, const int64_t* t_ids, const floa
   if (!m->ev.empty()) { if (m->ev_seen_b % m->ev_stride == 0) m->ev_bwd++; m->ev_seen_b++; }
   // every gradient is complete on `stream` when backward returns -- or, in a fused training step whose last optimizer launch can wait
   // on the device (see mmda_misa::jflags), when that launch completes
-  if (!x.rc && m->flag_join_ok && m->adam_early_on && !is_gru(m) && m->use_side && m->side_pending && m->jflags) {
+  // (only where every gradient the side stream computes lies in the prefix it also stepped -- the bf16 step, whose layer-2 weight
+  //  gradients ran there in front of the early optimizer pass: the launch that waits READS the rest of the bucket before it waits)
+  if (!x.rc && m->flag_join_ok && m->adam_early_on && !is_gru(m) && m->use_side && m->side_pending && m->jflags &&
+      m->adam_early_done > 0 && m->adam_early_done == m->rnn1_begin) {
     x.rc = side_flag_signal(m, 1);
     m->fj2 = x.rc ? 0 : 1;
     return x.rc;
